@@ -1,0 +1,93 @@
+// dev_common.h — device helpers shared by the generic scan and grid kernels.
+#pragma once
+#include "pcq_internal.h"
+
+// The reference (Rust) never contracts a*b+c (last.rs:156-160, grid_sampling.rs:51-95); hipcc's
+// default is -ffp-contract=fast.  The build passes -ffp-contract=off and this pragma pins it.
+#pragma clang fp contract(off)
+
+namespace pcqdev {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+constexpr int ITEMS = 8;                       // points per thread in the tiled (order-preserving) kernels
+constexpr int TILE = BLOCK * ITEMS;            // points per block
+
+__device__ __forceinline__ int32_t ld_i32(const uint8_t *p) {
+    if (((uintptr_t)p & 3) == 0) return *reinterpret_cast<const int32_t *>(p);
+    return (int32_t)((uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24));
+}
+__device__ __forceinline__ uint16_t ld_u16(const uint8_t *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+
+struct RawPoint {
+    int32_t x, y, z;
+};
+
+__device__ __forceinline__ RawPoint ld_xyz(const DevCols &c, uint64_t i) {
+    const uint8_t *p = c.xyz + i * c.xyz_stride;
+    RawPoint r;
+    r.x = ld_i32(p);
+    r.y = ld_i32(p + 4);
+    r.z = ld_i32(p + 8);
+    return r;
+}
+
+// The predicate of last.rs:122-135 (bounds) / last.rs:259-262 (class).  For bounds `rp` is loaded.
+__device__ __forceinline__ bool eval_pred(const DevCols &c, const DevPred &pr, uint64_t i, RawPoint &rp,
+                                          bool &have_xyz) {
+    if (pr.kind == PCQ_PRED_BOUNDS) {
+        if (pr.empty) return false;
+        rp = ld_xyz(c, i);
+        have_xyz = true;
+        return ((uint32_t)(rp.x - pr.lo[0]) <= pr.width[0]) & ((uint32_t)(rp.y - pr.lo[1]) <= pr.width[1]) &
+               ((uint32_t)(rp.z - pr.lo[2]) <= pr.width[2]);
+    }
+    have_xyz = false;
+    return (uint32_t)c.cls[i * c.cls_stride] == pr.cls;
+}
+
+// last.rs:156-160 — (i as f64 * scale) + offset, two roundings.
+__device__ __forceinline__ double world(int32_t v, double scale, double offset) {
+    const double m = (double)v * scale;
+    return m + offset;
+}
+
+// Rust `f64 as u64`: truncate, saturate, NaN -> 0.
+__device__ __forceinline__ uint64_t f64_as_u64(double v) {
+    if (!(v > 0.0)) return 0;
+    if (v >= 18446744073709551616.0) return ~0ull;
+    return (uint64_t)v;
+}
+
+// Builds the 31-byte result record of readers/src/lib.rs:10-19 for matched point i.
+__device__ __forceinline__ void make_point(const DevCols &c, uint64_t i, const RawPoint &rp, pcq_point &out) {
+    out.x = world(rp.x, c.scale[0], c.offset[0]);
+    out.y = world(rp.y, c.scale[1], c.offset[1]);
+    out.z = world(rp.z, c.scale[2], c.offset[2]);
+    if (c.rgb) {  // last.rs:145-153
+        const uint8_t *q = c.rgb + i * c.rgb_stride;
+        out.r = ld_u16(q);
+        out.g = ld_u16(q + 2);
+        out.b = ld_u16(q + 4);
+    } else {
+        out.r = out.g = out.b = 0;
+    }
+    out.classification = c.cls ? c.cls[i * c.cls_stride] : 0;  // last.rs:138-142
+}
+
+__device__ __forceinline__ void store_point31(uint8_t *dst, const pcq_point &p) {
+    const uint8_t *s = reinterpret_cast<const uint8_t *>(&p);
+#pragma unroll
+    for (int k = 0; k < 31; k++) dst[k] = s[k];
+}
+
+__device__ __forceinline__ uint64_t hash64(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdull;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ull;
+    k ^= k >> 33;
+    return k;
+}
+
+}  // namespace pcqdev

@@ -1,0 +1,490 @@
+// grid.hip — GridSampledCollector / SparseGrid on the device (kernel K4).
+//
+// Restates query/src/grid_sampling.rs:49-105 (SparseGrid::insert_point) for a massively parallel
+// device.  The reference folds points sequentially into a HashMap<u64, Point>: a cell keeps the point
+// closest to the cell centre, replaced only when a later point is STRICTLY closer, so the earliest
+// point in file order wins ties.  For every cell key whose points all fall into the same unmasked
+// cell (always, except the mask-aliasing case below) that fold is the lexicographic arg-min of
+// (squared distance, file-order index), computed here in three order-independent passes over the
+// matched points against an open-addressing hash table in HBM:
+//   A  insert key; atomicMin of the f64 distance bits (monotone for d >= 0); a slot whose minimum
+//      was lowered in this scan has its winner index reset;
+//   B  points whose distance equals the slot minimum: atomicMin of the file-order index;
+//   C  the unique winner materialises its 31-byte Point into the slot.
+// Scans into one collector are issued in file order with increasing `first_index`, which keeps
+// "first seen wins" across chunks and across files (sequential mode, main.rs:129-133).
+//
+// Mask aliasing (grid_sampling.rs:62-82): the key masks each axis to `bits`, but the cell centre
+// uses the UNMASKED cell, so a cell >= 2^bits folds onto another key while comparing against a
+// different centre.  For such keys the result depends on the visiting order; they are flagged in
+// pass A and re-folded exactly, in file order, by pass R (one thread per flagged key).
+//
+// HBM-bound random access (one 8-byte atomic + probes per matched point); not reshaped into GEMMs.
+#include "dev_common.h"
+
+using namespace pcqdev;
+
+int pcq_emit_prepare(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint64_t *matches, hipStream_t s);
+
+namespace {
+
+constexpr uint8_t F_HAS_POINT = 1;  // pts[slot] holds a materialised winner
+constexpr uint8_t F_ALIAS = 2;      // key has seen a point whose unmasked cell differs from the masked one
+
+struct CellInfo {
+    uint64_t key;
+    uint64_t cell[3];  // unmasked
+    bool alias;
+};
+
+// grid_sampling.rs:51-70
+__device__ __forceinline__ CellInfo cell_of(const DevGrid &g, double px, double py, double pz) {
+    const double p[3] = {px, py, pz};
+    CellInfo ci;
+    ci.alias = false;
+    ci.key = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double num = (p[a] - g.bmin[a]) * g.dims_f[a];
+        const double r = num / (g.bmax[a] - g.bmin[a]);
+        const uint64_t cell = f64_as_u64(r);
+        ci.cell[a] = cell;
+        const uint64_t masked = cell & g.mask[a];
+        ci.alias |= masked != cell;
+        ci.key |= masked << g.shift[a];
+    }
+    return ci;
+}
+
+// grid_sampling.rs:78-95 — squared distance of (px,py,pz) to the centre of the unmasked cell.
+__device__ __forceinline__ double centre_dist(const DevGrid &g, const uint64_t (&cell)[3], double px, double py,
+                                              double pz) {
+    const double cx = ((double)cell[0] + 0.5) * g.cell_size + g.bmin[0];
+    const double cy = ((double)cell[1] + 0.5) * g.cell_size + g.bmin[1];
+    const double cz = ((double)cell[2] + 0.5) * g.cell_size + g.bmin[2];
+    const double dx = px - cx, dy = py - cy, dz = pz - cz;
+    const double a = dx * dx, b = dy * dy, c = dz * dz;
+    return (a + b) + c;
+}
+
+__device__ __forceinline__ uint64_t find_or_insert(const DevGridTable &t, uint64_t key) {
+    const uint64_t m = t.cap - 1;
+    uint64_t h = hash64(key) & m;
+    for (;;) {
+        uint64_t k = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == key) return h;
+        if (k == PCQ_EMPTY_KEY) {
+            const uint64_t prev = atomicCAS((unsigned long long *)&t.keys[h], (unsigned long long)PCQ_EMPTY_KEY,
+                                            (unsigned long long)key);
+            if (prev == PCQ_EMPTY_KEY) {
+                atomicAdd((unsigned long long *)t.occupied, 1ull);
+                return h;
+            }
+            if (prev == key) return h;
+        }
+        h = (h + 1) & m;
+    }
+}
+
+__device__ __forceinline__ uint64_t find_slot(const DevGridTable &t, uint64_t key) {
+    const uint64_t m = t.cap - 1;
+    uint64_t h = hash64(key) & m;
+    for (;;) {
+        const uint64_t k = t.keys[h];
+        if (k == key) return h;
+        if (k == PCQ_EMPTY_KEY) return PCQ_NO_INDEX;  // cannot happen after pass A
+        h = (h + 1) & m;
+    }
+}
+
+struct Matched {
+    bool pass;
+    double px, py, pz;
+    RawPoint rp;
+};
+
+__device__ __forceinline__ Matched match_point(const DevCols &c, const DevPred &pr, uint64_t i) {
+    Matched m;
+    bool have = false;
+    m.pass = i < c.n && eval_pred(c, pr, i, m.rp, have);
+    if (m.pass) {
+        if (!have) m.rp = ld_xyz(c, i);
+        m.px = world(m.rp.x, c.scale[0], c.offset[0]);
+        m.py = world(m.rp.y, c.scale[1], c.offset[1]);
+        m.pz = world(m.rp.z, c.scale[2], c.offset[2]);
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_grid_pass_a(DevCols c, DevPred pr, DevGrid g, DevGridTable t) {
+    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < c.n; i += nthreads) {
+        const Matched m = match_point(c, pr, i);
+        if (!m.pass) continue;
+        const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
+        const uint64_t h = find_or_insert(t, ci.key);
+        const double d = centre_dist(g, ci.cell, m.px, m.py, m.pz);
+        const uint64_t db = (uint64_t)__double_as_longlong(d);
+        const uint64_t old = atomicMin((unsigned long long *)&t.dist[h], (unsigned long long)db);
+        if (db < old) t.widx[h] = PCQ_NO_INDEX;
+        if (ci.alias) {
+            t.flags[h] |= F_ALIAS;  // racing writers all set the same bit; bit0 is not written in pass A
+            atomicAdd((unsigned long long *)t.n_alias, 1ull);
+        }
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_grid_pass_b(DevCols c, DevPred pr, DevGrid g, DevGridTable t) {
+    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < c.n; i += nthreads) {
+        const Matched m = match_point(c, pr, i);
+        if (!m.pass) continue;
+        const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
+        const uint64_t h = find_slot(t, ci.key);
+        if (h == PCQ_NO_INDEX) continue;
+        const double d = centre_dist(g, ci.cell, m.px, m.py, m.pz);
+        if ((uint64_t)__double_as_longlong(d) == t.dist[h])
+            atomicMin((unsigned long long *)&t.widx[h], (unsigned long long)(c.first_index + i));
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_grid_pass_c(DevCols c, DevPred pr, DevGrid g, DevGridTable t) {
+    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < c.n; i += nthreads) {
+        const Matched m = match_point(c, pr, i);
+        if (!m.pass) continue;
+        const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
+        const uint64_t h = find_slot(t, ci.key);
+        if (h == PCQ_NO_INDEX) continue;
+        if (t.flags[h] & F_ALIAS) continue;  // resolved by pass R
+        if (t.widx[h] == c.first_index + i) {
+            pcq_point pt;
+            make_point(c, i, m.rp, pt);
+            store_point31(t.pts + h * 32, pt);
+            t.flags[h] |= F_HAS_POINT;
+        }
+    }
+}
+
+// Pass R: exact sequential fold for aliased keys.  `list` / `lkeys` hold, in file order, the local
+// index and the key of this scan's matched points whose key is flagged.  The thread of the FIRST list
+// entry of a key owns that key: it walks the rest of the list and applies insert_point
+// (grid_sampling.rs:72-103) to the entries of its key, starting from the slot's state before the scan.
+__global__ __launch_bounds__(BLOCK) void k_grid_pass_r(DevCols c, DevGrid g, DevGridTable t,
+                                                       const uint64_t *__restrict__ list,
+                                                       const uint64_t *__restrict__ lkeys, uint64_t nlist) {
+    const uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= nlist) return;
+    const uint64_t key = lkeys[e];
+    for (uint64_t q = 0; q < e; q++)
+        if (lkeys[q] == key) return;  // an earlier entry owns this key
+    const uint64_t h = find_slot(t, key);
+    if (h == PCQ_NO_INDEX) return;
+    bool has = (t.flags[h] & F_HAS_POINT) != 0;
+    pcq_point cur;
+    if (has) {
+        const uint8_t *s = t.pts + h * 32;
+        uint8_t *d = reinterpret_cast<uint8_t *>(&cur);
+        for (int k = 0; k < 31; k++) d[k] = s[k];
+    }
+    for (uint64_t q = e; q < nlist; q++) {
+        if (lkeys[q] != key) continue;
+        const uint64_t i = list[q];
+        const RawPoint rp = ld_xyz(c, i);
+        const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]),
+                     pz = world(rp.z, c.scale[2], c.offset[2]);
+        bool take;
+        if (!has) {
+            take = true;  // grid_sampling.rs:73-76
+        } else {          // :77-103 — both distances against the NEW point's (unmasked) cell centre
+            const CellInfo ci = cell_of(g, px, py, pz);
+            const double cur_d = centre_dist(g, ci.cell, cur.x, cur.y, cur.z);
+            const double new_d = centre_dist(g, ci.cell, px, py, pz);
+            take = new_d < cur_d;
+        }
+        if (take) {
+            make_point(c, i, rp, cur);
+            has = true;
+        }
+    }
+    if (has) {
+        store_point31(t.pts + h * 32, cur);
+        t.flags[h] |= F_HAS_POINT;
+    }
+}
+
+// Selector for pass R's list: matched && key flagged (two-pass stable compaction of local indices).
+__global__ __launch_bounds__(BLOCK) void k_alias_tile_counts(DevCols c, DevPred pr, DevGrid g, DevGridTable t,
+                                                             uint64_t *__restrict__ counts) {
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    uint32_t cnt = 0;
+    for (int j = 0; j < ITEMS; j++) {
+        const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
+        const Matched m = match_point(c, pr, i);
+        bool sel = false;
+        if (m.pass) {
+            const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
+            const uint64_t h = find_slot(t, ci.key);
+            sel = h != PCQ_NO_INDEX && (t.flags[h] & F_ALIAS);
+        }
+        cnt += (uint32_t)__popcll(__ballot(sel));
+    }
+    __shared__ uint32_t s_w[WAVES];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tt = 0;
+        for (int i = 0; i < WAVES; i++) tt += s_w[i];
+        counts[blockIdx.x] = tt;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_alias_emit(DevCols c, DevPred pr, DevGrid g, DevGridTable t,
+                                                      const uint64_t *__restrict__ offsets, uint64_t *__restrict__ list,
+                                                      uint64_t *__restrict__ lkeys) {
+    __shared__ uint32_t s_w[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    uint64_t run = offsets[blockIdx.x];
+    for (int j = 0; j < ITEMS; j++) {
+        const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
+        const Matched m = match_point(c, pr, i);
+        bool sel = false;
+        uint64_t key = 0;
+        if (m.pass) {
+            const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
+            const uint64_t h = find_slot(t, ci.key);
+            sel = h != PCQ_NO_INDEX && (t.flags[h] & F_ALIAS);
+            key = ci.key;
+        }
+        const uint64_t mask = __ballot(sel);
+        if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (int w = 0; w < WAVES; w++) {
+            const uint32_t v = s_w[w];
+            before += w < wave ? v : 0;
+            all += v;
+        }
+        if (sel) {
+            const uint64_t pos = run + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            list[pos] = i;
+            lkeys[pos] = key;
+        }
+        run += all;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *__restrict__ counts, uint64_t n, uint64_t *__restrict__ total_out) {
+    __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < n ? counts[i] : 0;
+        uint64_t incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t up = __shfl_up((unsigned long long)incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint64_t wave_off = 0;
+        for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+        const uint64_t carry = s_carry;
+        if (i < n) counts[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = s_carry;
+}
+
+// Re-insert every used slot of `src` into `dst` (table growth).
+__global__ __launch_bounds__(BLOCK) void k_grid_rehash(DevGridTable src, DevGridTable dst) {
+    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t h = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; h < src.cap; h += nthreads) {
+        const uint64_t key = src.keys[h];
+        if (key == PCQ_EMPTY_KEY) continue;
+        const uint64_t m = dst.cap - 1;
+        uint64_t d = hash64(key) & m;
+        for (;;) {
+            const uint64_t prev = atomicCAS((unsigned long long *)&dst.keys[d], (unsigned long long)PCQ_EMPTY_KEY,
+                                            (unsigned long long)key);
+            if (prev == PCQ_EMPTY_KEY) break;
+            d = (d + 1) & m;
+        }
+        dst.dist[d] = src.dist[h];
+        dst.widx[d] = src.widx[h];
+        dst.flags[d] = src.flags[h];
+        const uint4 *sp = reinterpret_cast<const uint4 *>(src.pts + h * 32);
+        uint4 *dp = reinterpret_cast<uint4 *>(dst.pts + d * 32);
+        dp[0] = sp[0];
+        dp[1] = sp[1];
+    }
+}
+
+// Drain: compact used slots (slot order) into packed 31-byte points + keys.
+__global__ __launch_bounds__(BLOCK) void k_grid_drain(DevGridTable t, uint8_t *__restrict__ out31, uint64_t *__restrict__ keys_out,
+                                                      uint64_t *__restrict__ cursor) {
+    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t h = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; h < t.cap; h += nthreads) {
+        if (t.keys[h] == PCQ_EMPTY_KEY || !(t.flags[h] & F_HAS_POINT)) continue;
+        const uint64_t pos = atomicAdd((unsigned long long *)cursor, 1ull);
+        const uint8_t *s = t.pts + h * 32;
+        uint8_t *d = out31 + pos * 31;
+        for (int k = 0; k < 31; k++) d[k] = s[k];
+        keys_out[pos] = t.keys[h];
+    }
+}
+
+}  // namespace
+
+void pcq_grid_release(pcq_collector *c) {
+    DevGridTable &t = c->table;
+    if (t.keys) (void)hipFree(t.keys);
+    if (t.dist) (void)hipFree(t.dist);
+    if (t.widx) (void)hipFree(t.widx);
+    if (t.pts) (void)hipFree(t.pts);
+    if (t.flags) (void)hipFree(t.flags);
+    if (t.occupied) (void)hipFree(t.occupied);
+    t = DevGridTable{};
+}
+
+static int table_alloc(pcq_ctx *ctx, DevGridTable *t, uint64_t cap, hipStream_t s) {
+    *t = DevGridTable{};
+    t->cap = cap;
+    PCQ_HIP(hipMalloc((void **)&t->keys, cap * 8));
+    PCQ_HIP(hipMalloc((void **)&t->dist, cap * 8));
+    PCQ_HIP(hipMalloc((void **)&t->widx, cap * 8));
+    PCQ_HIP(hipMalloc((void **)&t->pts, cap * 32));
+    PCQ_HIP(hipMalloc((void **)&t->flags, cap));
+    PCQ_HIP(hipMalloc((void **)&t->occupied, 16));
+    t->n_alias = t->occupied + 1;
+    PCQ_HIP(hipMemsetAsync(t->keys, 0xff, cap * 8, s));
+    PCQ_HIP(hipMemsetAsync(t->dist, 0xff, cap * 8, s));
+    PCQ_HIP(hipMemsetAsync(t->widx, 0xff, cap * 8, s));
+    PCQ_HIP(hipMemsetAsync(t->flags, 0, cap, s));
+    PCQ_HIP(hipMemsetAsync(t->occupied, 0, 16, s));
+    (void)ctx;
+    return PCQ_OK;
+}
+
+int pcq_grid_alloc(pcq_ctx *ctx, pcq_collector *c, uint64_t cap) {
+    return table_alloc(ctx, &c->table, cap, ctx->stream);
+}
+
+static uint64_t next_pow2(uint64_t v) {
+    uint64_t p = 1024;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+static int grid_blocks(pcq_ctx *ctx, uint64_t n) {
+    uint64_t want = (n + BLOCK - 1) / BLOCK;
+    const uint64_t cap = (uint64_t)ctx->num_cus * 16;
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+// Make room for `additional` new cells: load factor <= 1/2.
+static int grid_reserve(pcq_ctx *ctx, pcq_collector *c, uint64_t additional, hipStream_t s) {
+    const uint64_t need = next_pow2(2 * (c->table_used_bound + additional) + 1);
+    if (c->table.keys && c->table.cap >= need) return PCQ_OK;
+    if (!c->table.keys) return table_alloc(ctx, &c->table, need, s);
+    DevGridTable nt;
+    int rc = table_alloc(ctx, &nt, need, s);
+    if (rc) return rc;
+    // carry the counters over, then re-insert
+    PCQ_HIP(hipMemcpyAsync(nt.occupied, c->table.occupied, 16, hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(k_grid_rehash, dim3(grid_blocks(ctx, c->table.cap)), dim3(BLOCK), 0, s, c->table, nt);
+    PCQ_HIP(hipGetLastError());
+    PCQ_HIP(hipStreamSynchronize(s));
+    pcq_grid_release(c);
+    c->table = nt;
+    return PCQ_OK;
+}
+
+int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const DevPred &pred,
+                  uint64_t matches_upper_bound, hipStream_t s) {
+    if (cols.n == 0 || matches_upper_bound == 0) return PCQ_OK;
+    // new cells <= matches, and <= the number of distinct keys the bit layout can express
+    const uint64_t bitsum = c->bits[0] + c->bits[1] + c->bits[2];
+    uint64_t additional = matches_upper_bound;
+    if (bitsum < 62) {
+        const uint64_t keyspace = 1ull << bitsum;
+        const uint64_t room = keyspace > c->table_used_bound ? keyspace - c->table_used_bound : 0;
+        if (additional > room) additional = room;
+    }
+    int rc = grid_reserve(ctx, c, additional, s);
+    if (rc) return rc;
+    const int grid = grid_blocks(ctx, cols.n);
+    const DevGrid &g = c->grid;
+    DevGridTable &t = c->table;
+    // alias counter is per scan
+    PCQ_HIP(hipMemsetAsync(t.n_alias, 0, 8, s));
+    hipLaunchKernelGGL(k_grid_pass_a, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
+    hipLaunchKernelGGL(k_grid_pass_b, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
+    PCQ_HIP(hipGetLastError());
+    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, t.occupied, 16, hipMemcpyDeviceToHost, s));
+    PCQ_HIP(hipStreamSynchronize(s));
+    c->table_used_bound = ctx->h_scalars[0];
+    if (ctx->h_scalars[1]) c->grid_has_alias = true;  // sticky: flagged keys stay flagged
+    if (c->grid_has_alias) {
+        const uint64_t nblocks = (cols.n + TILE - 1) / TILE;
+        rc = pcq_ensure_partials(ctx, (size_t)nblocks);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_alias_tile_counts, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, g, t, ctx->d_partials);
+        hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, ctx->d_partials, nblocks, ctx->d_scalars);
+        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 8, hipMemcpyDeviceToHost, s));
+        PCQ_HIP(hipStreamSynchronize(s));
+        const uint64_t nlist = ctx->h_scalars[0];
+        if (nlist) {
+            uint64_t *d_list = nullptr;
+            PCQ_HIP(hipMalloc((void **)&d_list, nlist * 16));
+            uint64_t *d_lkeys = d_list + nlist;
+            hipLaunchKernelGGL(k_alias_emit, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, g, t, ctx->d_partials,
+                               d_list, d_lkeys);
+            hipLaunchKernelGGL(k_grid_pass_r, dim3((unsigned)((nlist + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, cols, g, t,
+                               d_list, d_lkeys, nlist);
+            hipError_t e = hipStreamSynchronize(s);
+            (void)hipFree(d_list);
+            if (e != hipSuccess) return pcq_fail(PCQ_ERR_HIP, "grid pass R failed: %s", hipGetErrorString(e));
+        }
+    }
+    hipLaunchKernelGGL(k_grid_pass_c, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
+    PCQ_HIP(hipGetLastError());
+    return PCQ_OK;
+}
+
+int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_t cap, uint64_t *out_n) {
+    pcq_ctx *ctx = c->ctx;
+    hipStream_t s = ctx->stream;
+    *out_n = 0;
+    if (!c->table.keys) return PCQ_OK;
+    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->table.occupied, 8, hipMemcpyDeviceToHost, s));
+    PCQ_HIP(hipStreamSynchronize(s));
+    const uint64_t n = ctx->h_scalars[0];
+    *out_n = n;
+    if ((!out && !keys_out) || n == 0) return PCQ_OK;
+    if (cap < n) return pcq_fail(PCQ_ERR_CAPACITY, "grid collector holds %llu points, capacity %llu", (unsigned long long)n,
+                                 (unsigned long long)cap);
+    uint8_t *d_out = nullptr;
+    uint64_t *d_keys = nullptr;
+    PCQ_HIP(hipMalloc((void **)&d_out, n * 31));
+    PCQ_HIP(hipMalloc((void **)&d_keys, n * 8));
+    PCQ_HIP(hipMemsetAsync(ctx->d_scalars, 0, 8, s));
+    hipLaunchKernelGGL(k_grid_drain, dim3(grid_blocks(ctx, c->table.cap)), dim3(BLOCK), 0, s, c->table, d_out, d_keys,
+                       ctx->d_scalars);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && out) e = hipMemcpyAsync(out, d_out, n * 31, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess && keys_out) e = hipMemcpyAsync(keys_out, d_keys, n * 8, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    (void)hipFree(d_out);
+    (void)hipFree(d_keys);
+    if (e != hipSuccess) return pcq_fail(PCQ_ERR_HIP, "grid drain failed: %s", hipGetErrorString(e));
+    return PCQ_OK;
+}

@@ -1,0 +1,663 @@
+// pcq_api.hip — the C ABI of include/pcq.h: context, device-resident collectors, the scan entry
+// points and the host-block streaming pipeline.
+//
+// Everything here is plumbing around the kernels of scan_count.hip / scan_generic.hip / grid.hip.
+// There is deliberately no CPU implementation of any scan in this library: if no HIP device is
+// usable, pcq_init fails and nothing else can be called.
+#include "pcq_internal.h"
+
+#include <cmath>
+#include <new>
+
+// ---------------------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------------------
+static thread_local char g_err[1024];
+
+int pcq_fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" const char *pcq_last_error(void) { return g_err; }
+extern "C" int pcq_abi_version(void) { return PCQ_ABI_VERSION; }
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
+    if (!out_ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_init: out_ctx is null");
+    *out_ctx = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return pcq_fail(PCQ_ERR_HIP, "pcq_init: no HIP device available (%s); this library has no CPU path",
+                        e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device < 0 || device >= ndev) return pcq_fail(PCQ_ERR_ARG, "pcq_init: device %d out of range [0,%d)", device, ndev);
+    PCQ_HIP(hipSetDevice(device));
+    pcq_ctx *ctx = new (std::nothrow) pcq_ctx();
+    if (!ctx) return pcq_fail(PCQ_ERR_NOMEM, "pcq_init: out of memory");
+    ctx->device = device;
+    e = hipGetDeviceProperties(&ctx->prop, device);
+    if (e != hipSuccess) {
+        delete ctx;
+        return pcq_fail(PCQ_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    }
+    ctx->num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess) {
+        pcq_shutdown(ctx);
+        return pcq_fail(PCQ_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < 2; i++) {
+        if ((e = hipEventCreateWithFlags(&ctx->copied[i], hipEventDisableTiming)) != hipSuccess ||
+            (e = hipEventCreateWithFlags(&ctx->consumed[i], hipEventDisableTiming)) != hipSuccess) {
+            pcq_shutdown(ctx);
+            return pcq_fail(PCQ_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(e));
+        }
+    }
+    if ((e = hipMalloc((void **)&ctx->d_scalars, 64 * sizeof(uint64_t))) != hipSuccess ||
+        (e = hipHostMalloc((void **)&ctx->h_scalars, 64 * sizeof(uint64_t), hipHostMallocDefault)) != hipSuccess) {
+        pcq_shutdown(ctx);
+        return pcq_fail(PCQ_ERR_HIP, "scratch allocation: %s", hipGetErrorString(e));
+    }
+    int rc = pcq_ensure_partials(ctx, (size_t)ctx->num_cus * 16);
+    if (rc) {
+        pcq_shutdown(ctx);
+        return rc;
+    }
+    *out_ctx = ctx;
+    return PCQ_OK;
+}
+
+extern "C" int pcq_shutdown(pcq_ctx *ctx) {
+    if (!ctx) return PCQ_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->copied[i]) (void)hipEventDestroy(ctx->copied[i]);
+        if (ctx->consumed[i]) (void)hipEventDestroy(ctx->consumed[i]);
+        if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
+        if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
+    }
+    if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
+    if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
+    if (ctx->d_segments) (void)hipFree(ctx->d_segments);
+    if (ctx->h_segments) (void)hipHostFree(ctx->h_segments);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
+    delete ctx;
+    return PCQ_OK;
+}
+
+int pcq_ensure_partials(pcq_ctx *ctx, size_t n) {
+    if (n <= ctx->partials_cap) return PCQ_OK;
+    // The old buffer may still be referenced by enqueued kernels.
+    if (ctx->d_partials) {
+        PCQ_HIP(hipStreamSynchronize(ctx->stream));
+        PCQ_HIP(hipFree(ctx->d_partials));
+        ctx->d_partials = nullptr;
+        ctx->partials_cap = 0;
+    }
+    size_t cap = 4096;
+    while (cap < n) cap <<= 1;
+    PCQ_HIP(hipMalloc((void **)&ctx->d_partials, cap * sizeof(uint64_t)));
+    ctx->partials_cap = cap;
+    return PCQ_OK;
+}
+
+extern "C" int pcq_get_device_info(pcq_ctx *ctx, pcq_device_info *out) {
+    if (!ctx || !out) return pcq_fail(PCQ_ERR_ARG, "pcq_get_device_info: null argument");
+    memset(out, 0, sizeof *out);
+    snprintf(out->name, sizeof out->name, "%s", ctx->prop.name);
+    snprintf(out->gcn_arch, sizeof out->gcn_arch, "%s", ctx->prop.gcnArchName);
+    out->compute_units = ctx->prop.multiProcessorCount;
+    out->wavefront_size = ctx->prop.warpSize;
+    out->hbm_bytes = (uint64_t)ctx->prop.totalGlobalMem;
+    out->lds_bytes_per_block = (uint64_t)ctx->prop.sharedMemPerBlock;
+    out->clock_khz = ctx->prop.clockRate;
+    return PCQ_OK;
+}
+
+extern "C" void *pcq_ctx_stream(pcq_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" int pcq_ctx_synchronize(pcq_ctx *ctx) {
+    if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_ctx_synchronize: null context");
+    PCQ_HIP(hipStreamSynchronize(ctx->stream));
+    PCQ_HIP(hipStreamSynchronize(ctx->copy_stream));
+    return PCQ_OK;
+}
+
+extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
+    if (!ctx || !key) return pcq_fail(PCQ_ERR_ARG, "pcq_set_option: null argument");
+    if (!strcmp(key, "k1_variant")) {
+        if (value < 0 || value > 3) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..3");
+        ctx->k1_variant = (int)value;
+    } else if (!strcmp(key, "blocks_per_cu")) {
+        if (value < 1 || value > 16) return pcq_fail(PCQ_ERR_ARG, "blocks_per_cu must be 1..16");
+        ctx->grid_blocks_per_cu = (int)value;
+    } else if (!strcmp(key, "chunk_points")) {
+        if (value < 1024) return pcq_fail(PCQ_ERR_ARG, "chunk_points must be >= 1024");
+        ctx->chunk_points = (uint64_t)value;
+    } else {
+        return pcq_fail(PCQ_ERR_ARG, "unknown option '%s'", key);
+    }
+    return PCQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device memory helpers
+// ---------------------------------------------------------------------------------------------
+extern "C" int pcq_device_alloc(pcq_ctx *ctx, uint64_t bytes, void **out) {
+    if (!ctx || !out) return pcq_fail(PCQ_ERR_ARG, "pcq_device_alloc: null argument");
+    *out = nullptr;
+    PCQ_HIP(hipSetDevice(ctx->device));
+    PCQ_HIP(hipMalloc(out, bytes ? bytes : 16));
+    return PCQ_OK;
+}
+extern "C" int pcq_device_free(pcq_ctx *ctx, void *p) {
+    if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_device_free: null context");
+    if (p) PCQ_HIP(hipFree(p));
+    return PCQ_OK;
+}
+extern "C" int pcq_copy_to_device(pcq_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return pcq_fail(PCQ_ERR_ARG, "pcq_copy_to_device: null argument");
+    if (bytes) PCQ_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return PCQ_OK;
+}
+extern "C" int pcq_copy_to_host(pcq_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    if (!ctx || (!dst && bytes) || (!src && bytes)) return pcq_fail(PCQ_ERR_ARG, "pcq_copy_to_host: null argument");
+    if (bytes) {
+        PCQ_HIP(hipStreamSynchronize(ctx->stream));
+        PCQ_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    }
+    return PCQ_OK;
+}
+extern "C" int pcq_device_memset(pcq_ctx *ctx, void *dst, int value, uint64_t bytes, void *stream) {
+    if (!ctx || (!dst && bytes)) return pcq_fail(PCQ_ERR_ARG, "pcq_device_memset: null argument");
+    if (bytes) PCQ_HIP(hipMemsetAsync(dst, value, bytes, stream ? (hipStream_t)stream : ctx->stream));
+    return PCQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side math of the boundary
+// ---------------------------------------------------------------------------------------------
+
+// Rust `f64 as i64`: truncate toward zero, saturate, NaN -> 0.
+static int64_t rust_f64_as_i64(double v) {
+    if (std::isnan(v)) return 0;
+    if (v >= 9223372036854775808.0) return INT64_MAX;
+    if (v <= -9223372036854775808.0) return INT64_MIN;
+    return (int64_t)v;
+}
+static uint64_t rust_f64_as_u64(double v) {
+    if (!(v > 0.0)) return 0;
+    if (v >= 18446744073709551616.0) return UINT64_MAX;
+    return (uint64_t)v;
+}
+
+// last.rs:98-109 / las.rs:88-99
+extern "C" int pcq_box_to_local(const double bmin[3], const double bmax[3], const double scale[3],
+                                const double offset[3], int64_t lmin[3], int64_t lmax[3]) {
+    if (!bmin || !bmax || !scale || !offset || !lmin || !lmax) return pcq_fail(PCQ_ERR_ARG, "pcq_box_to_local: null argument");
+    for (int a = 0; a < 3; a++) {
+        lmin[a] = rust_f64_as_i64((bmin[a] - offset[a]) / scale[0]);  // sic: x scale on every axis (last.rs:100-102)
+        lmax[a] = rust_f64_as_i64((bmax[a] - offset[a]) / scale[a]);
+    }
+    for (int a = 0; a < 3; a++)
+        if (lmin[a] > lmax[a])
+            return pcq_fail(PCQ_ERR_PANIC, "AABB::from_min_max: Minimum position must be <= maximum position!");
+    return PCQ_OK;
+}
+
+int pcq_make_dev_pred(const pcq_predicate *p, DevPred *out) {
+    memset(out, 0, sizeof *out);
+    out->kind = p->kind;
+    if (p->kind == PCQ_PRED_CLASS) {
+        out->cls = p->cls;
+        return PCQ_OK;
+    }
+    if (p->kind != PCQ_PRED_BOUNDS) return pcq_fail(PCQ_ERR_ARG, "unknown predicate kind %d", p->kind);
+    for (int a = 0; a < 3; a++) {
+        const int64_t lo = p->lmin[a] < INT32_MIN ? (int64_t)INT32_MIN : p->lmin[a];
+        const int64_t hi = p->lmax[a] > INT32_MAX ? (int64_t)INT32_MAX : p->lmax[a];
+        if (lo > hi) {  // covers lmin > lmax as well as boxes outside the i32 value range
+            out->empty = 1;
+            out->lo[a] = 0;
+            out->width[a] = 0;
+        } else {
+            out->lo[a] = (int32_t)lo;
+            out->width[a] = (uint32_t)(hi - lo);
+        }
+    }
+    return PCQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// collectors
+// ---------------------------------------------------------------------------------------------
+static int new_collector(pcq_ctx *ctx, int kind, pcq_collector **out) {
+    if (!ctx || !out) return pcq_fail(PCQ_ERR_ARG, "collector: null argument");
+    *out = nullptr;
+    pcq_collector *c = new (std::nothrow) pcq_collector();
+    if (!c) return pcq_fail(PCQ_ERR_NOMEM, "collector: out of memory");
+    c->kind = kind;
+    c->ctx = ctx;
+    c->table = DevGridTable{};
+    *out = c;
+    return PCQ_OK;
+}
+
+extern "C" int pcq_collector_new_count(pcq_ctx *ctx, pcq_collector **out) {
+    int rc = new_collector(ctx, COLL_COUNT, out);
+    if (rc) return rc;
+    pcq_collector *c = *out;
+    hipError_t e = hipMalloc((void **)&c->d_count, 16);
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_count, 0, 16, ctx->stream);
+    if (e != hipSuccess) {
+        delete c;
+        *out = nullptr;
+        return pcq_fail(PCQ_ERR_HIP, "count collector: %s", hipGetErrorString(e));
+    }
+    c->owns_count = true;
+    return PCQ_OK;
+}
+
+extern "C" int pcq_collector_new_count_at(pcq_ctx *ctx, uint64_t *device_counter, pcq_collector **out) {
+    if (!device_counter) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_new_count_at: null counter");
+    int rc = new_collector(ctx, COLL_COUNT, out);
+    if (rc) return rc;
+    (*out)->d_count = device_counter;
+    (*out)->owns_count = false;
+    return PCQ_OK;
+}
+
+extern "C" int pcq_collector_new_buffer(pcq_ctx *ctx, pcq_collector **out) { return new_collector(ctx, COLL_BUFFER, out); }
+
+// SparseGrid::new — grid_sampling.rs:18-47
+extern "C" int pcq_collector_new_grid(pcq_ctx *ctx, const double bmin[3], const double bmax[3], double cell_size,
+                                      pcq_collector **out) {
+    if (!bmin || !bmax) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_new_grid: null bounds");
+    int rc = new_collector(ctx, COLL_GRID, out);
+    if (rc) return rc;
+    pcq_collector *c = *out;
+    uint64_t bitsum = 0;
+    for (int a = 0; a < 3; a++) {
+        c->bmin[a] = bmin[a];
+        c->bmax[a] = bmax[a];
+        const double extent = bmax[a] - bmin[a];          // :19-23
+        const double ncells = std::ceil(extent / cell_size);  // :24-28
+        c->bits[a] = rust_f64_as_u64(std::ceil(std::log2(ncells)));  // :29-31
+        c->dims[a] = rust_f64_as_u64(ncells);             // :39-43
+        bitsum += c->bits[a];
+    }
+    c->cell_size = cell_size;
+    if (bitsum > 64) {  // :32-34
+        delete c;
+        *out = nullptr;
+        return pcq_fail(PCQ_ERR_GRID, "Too many cells ({}*{}*{}) in SparseGrid! The number of cells exceeds the capacity of a u64 index!");
+    }
+    if (bitsum == 64) {  // all-ones is a legal key then, which this table reserves as "empty"
+        delete c;
+        *out = nullptr;
+        return pcq_fail(PCQ_ERR_UNSUPPORTED, "SparseGrid with exactly 64 key bits is not supported by the device hash table");
+    }
+    if (!std::isfinite(cell_size) || !std::isfinite(bmin[0]) || !std::isfinite(bmin[1]) || !std::isfinite(bmin[2]) ||
+        !std::isfinite(bmax[0]) || !std::isfinite(bmax[1]) || !std::isfinite(bmax[2])) {
+        delete c;
+        *out = nullptr;
+        return pcq_fail(PCQ_ERR_UNSUPPORTED, "SparseGrid with non-finite bounds or cell size is not supported");
+    }
+    DevGrid &g = c->grid;
+    for (int a = 0; a < 3; a++) {
+        g.bmin[a] = bmin[a];
+        g.bmax[a] = bmax[a];
+        g.dims_f[a] = (double)c->dims[a];
+        g.mask[a] = (1ull << (c->bits[a] & 63)) - 1;  // Rust release `1u64 << n` masks n to 6 bits
+    }
+    g.cell_size = cell_size;
+    g.shift[0] = 0;
+    g.shift[1] = (uint32_t)(c->bits[0] & 63);
+    g.shift[2] = (uint32_t)((c->bits[0] + c->bits[1]) & 63);
+    return PCQ_OK;
+}
+
+extern "C" int pcq_collector_free(pcq_collector *c) {
+    if (!c) return PCQ_OK;
+    if (c->ctx) (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->owns_count && c->d_count) (void)hipFree(c->d_count);
+    if (c->d_points) (void)hipFree(c->d_points);
+    if (c->kind == COLL_GRID) pcq_grid_release(c);
+    delete c;
+    return PCQ_OK;
+}
+
+extern "C" int pcq_collector_reset(pcq_collector *c) {
+    if (!c) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_reset: null collector");
+    hipStream_t s = c->ctx->stream;
+    c->next_index = 0;
+    if (c->kind == COLL_COUNT) PCQ_HIP(hipMemsetAsync(c->d_count, 0, 8, s));
+    if (c->kind == COLL_BUFFER) c->n_points = 0;
+    if (c->kind == COLL_GRID) {
+        PCQ_HIP(hipStreamSynchronize(s));
+        pcq_grid_release(c);
+        c->table_used_bound = 0;
+        c->grid_has_alias = false;
+    }
+    return PCQ_OK;
+}
+
+extern "C" int pcq_collector_has_points(const pcq_collector *c) { return c && c->kind != COLL_COUNT; }
+
+extern "C" int pcq_collector_point_count(pcq_collector *c, uint64_t *out) {
+    if (!c || !out) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_point_count: null argument");
+    pcq_ctx *ctx = c->ctx;
+    switch (c->kind) {
+    case COLL_COUNT:
+        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PCQ_HIP(hipStreamSynchronize(ctx->stream));
+        *out = ctx->h_scalars[0];
+        return PCQ_OK;
+    case COLL_BUFFER:
+        PCQ_HIP(hipStreamSynchronize(ctx->stream));
+        *out = c->n_points;
+        return PCQ_OK;
+    default:
+        return pcq_grid_drain(c, nullptr, nullptr, 0, out);
+    }
+}
+
+extern "C" int pcq_collector_points(pcq_collector *c, pcq_point *out, uint64_t cap, uint64_t *out_n) {
+    if (!c || !out_n) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_points: null argument");
+    pcq_ctx *ctx = c->ctx;
+    *out_n = 0;
+    if (c->kind == COLL_COUNT) return PCQ_OK;  // points() is None (collect_points.rs:87-93)
+    if (c->kind == COLL_BUFFER) {
+        PCQ_HIP(hipStreamSynchronize(ctx->stream));
+        *out_n = c->n_points;
+        if (!out || c->n_points == 0) return PCQ_OK;
+        if (cap < c->n_points)
+            return pcq_fail(PCQ_ERR_CAPACITY, "buffer collector holds %llu points, capacity %llu",
+                            (unsigned long long)c->n_points, (unsigned long long)cap);
+        PCQ_HIP(hipMemcpy(out, c->d_points, c->n_points * 31, hipMemcpyDeviceToHost));
+        return PCQ_OK;
+    }
+    return pcq_grid_drain(c, out, nullptr, cap, out_n);
+}
+
+extern "C" int pcq_collector_grid_cells(pcq_collector *c, uint64_t *out, uint64_t cap, uint64_t *out_n) {
+    if (!c || !out_n) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_grid_cells: null argument");
+    if (c->kind != COLL_GRID) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_grid_cells: not a grid collector");
+    return pcq_grid_drain(c, nullptr, out, cap, out_n);
+}
+
+extern "C" int pcq_collector_grid_params(const pcq_collector *c, uint64_t dims[3], uint64_t bits[3]) {
+    if (!c || c->kind != COLL_GRID || !dims || !bits) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_grid_params: not a grid collector");
+    for (int a = 0; a < 3; a++) dims[a] = c->dims[a], bits[a] = c->bits[a];
+    return PCQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan over device-resident columns
+// ---------------------------------------------------------------------------------------------
+static int validate_scan(const pcq_columns *cols, const pcq_predicate *pred, const pcq_collector *c) {
+    if (!cols || !pred || !c) return pcq_fail(PCQ_ERR_ARG, "scan: null argument");
+    if (pred->kind != PCQ_PRED_BOUNDS && pred->kind != PCQ_PRED_CLASS) return pcq_fail(PCQ_ERR_ARG, "scan: bad predicate kind %d", pred->kind);
+    if (cols->n == 0) return PCQ_OK;
+    const bool need_xyz = pred->kind == PCQ_PRED_BOUNDS || c->kind != COLL_COUNT;
+    const bool need_cls = pred->kind == PCQ_PRED_CLASS || c->kind != COLL_COUNT;
+    if (need_xyz && (!cols->xyz || cols->xyz_stride < 12)) return pcq_fail(PCQ_ERR_ARG, "scan: positions column missing or stride < 12");
+    if (need_cls && (!cols->cls || cols->cls_stride < 1)) return pcq_fail(PCQ_ERR_ARG, "scan: classification column missing");
+    if (cols->rgb && cols->rgb_stride < 6) return pcq_fail(PCQ_ERR_ARG, "scan: colour stride < 6");
+    return PCQ_OK;
+}
+
+static DevCols to_dev_cols(const pcq_columns *cols) {
+    DevCols d;
+    d.xyz = (const uint8_t *)cols->xyz;
+    d.cls = (const uint8_t *)cols->cls;
+    d.rgb = (const uint8_t *)cols->rgb;
+    d.xyz_stride = cols->xyz_stride;
+    d.cls_stride = cols->cls_stride;
+    d.rgb_stride = cols->rgb_stride;
+    d.n = cols->n;
+    d.first_index = cols->first_index;
+    for (int a = 0; a < 3; a++) d.scale[a] = cols->scale[a], d.offset[a] = cols->offset[a];
+    return d;
+}
+
+// Count of matches into *d_count (+=), choosing the fast kernels where the layout allows.
+static int count_into(pcq_ctx *ctx, const DevCols &dc, const DevPred &dp, uint64_t *d_count, hipStream_t s) {
+    if (dc.n == 0) return PCQ_OK;
+    if (dp.kind == PCQ_PRED_BOUNDS) {
+        if (dp.empty) return PCQ_OK;
+        if (dc.xyz_stride == 12 && ((uintptr_t)dc.xyz & 3) == 0) {
+            // peel the (at most 3) points in front of the first 16-byte aligned point boundary
+            uint64_t head = ((uintptr_t)dc.xyz & 15) / 4;  // 12*head == -addr (mod 16)
+            if (head > dc.n) head = dc.n;
+            if (head) {
+                DevCols h = dc;
+                h.n = head;
+                int rc = pcq_launch_generic_count(ctx, h, dp, d_count, s);
+                if (rc) return rc;
+            }
+            return pcq_launch_bounds_count_xyz12(ctx, dc.xyz + 12 * head, dc.n - head, dp, d_count, s);
+        }
+        return pcq_launch_generic_count(ctx, dc, dp, d_count, s);
+    }
+    if (dc.cls_stride == 1) return pcq_launch_class_count_u8(ctx, dc.cls, dc.n, (uint8_t)dp.cls, d_count, s);
+    return pcq_launch_generic_count(ctx, dc, dp, d_count, s);
+}
+
+static int buffer_reserve(pcq_collector *c, uint64_t need, hipStream_t s) {
+    if (need <= c->cap_points) return PCQ_OK;
+    uint64_t cap = c->cap_points ? c->cap_points : 4096;
+    while (cap < need) cap *= 2;
+    uint8_t *nb = nullptr;
+    PCQ_HIP(hipMalloc((void **)&nb, cap * 31));
+    if (c->n_points) PCQ_HIP(hipMemcpyAsync(nb, c->d_points, c->n_points * 31, hipMemcpyDeviceToDevice, s));
+    PCQ_HIP(hipStreamSynchronize(s));
+    if (c->d_points) PCQ_HIP(hipFree(c->d_points));
+    c->d_points = nb;
+    c->cap_points = cap;
+    return PCQ_OK;
+}
+
+static int scan_dev_impl(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c, hipStream_t s) {
+    int rc = validate_scan(cols, pred, c);
+    if (rc) return rc;
+    if (cols->n == 0) return PCQ_OK;
+    DevPred dp;
+    rc = pcq_make_dev_pred(pred, &dp);
+    if (rc) return rc;
+    DevCols dc = to_dev_cols(cols);
+    switch (c->kind) {
+    case COLL_COUNT:
+        return count_into(ctx, dc, dp, c->d_count, s);
+    case COLL_BUFFER: {
+        if (dp.kind == PCQ_PRED_BOUNDS && dp.empty) return PCQ_OK;
+        uint64_t matches = 0;
+        rc = pcq_emit_prepare(ctx, dc, dp, &matches, s);
+        if (rc || matches == 0) return rc;
+        rc = buffer_reserve(c, c->n_points + matches, s);
+        if (rc) return rc;
+        rc = pcq_launch_emit_points(ctx, dc, dp, c->d_points, c->n_points, matches, s);
+        if (rc) return rc;
+        c->n_points += matches;
+        return PCQ_OK;
+    }
+    case COLL_GRID: {
+        if (dp.kind == PCQ_PRED_BOUNDS && dp.empty) return PCQ_OK;
+        // the number of matches bounds the number of new cells (sizes the hash table)
+        PCQ_HIP(hipMemsetAsync(ctx->d_scalars + 8, 0, 8, s));
+        rc = count_into(ctx, dc, dp, ctx->d_scalars + 8, s);
+        if (rc) return rc;
+        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars + 8, 8, hipMemcpyDeviceToHost, s));
+        PCQ_HIP(hipStreamSynchronize(s));
+        const uint64_t matches = ctx->h_scalars[8];
+        if (matches == 0) return PCQ_OK;
+        return pcq_grid_scan(ctx, c, dc, dp, matches, s);
+    }
+    }
+    return pcq_fail(PCQ_ERR_ARG, "scan: unknown collector kind");
+}
+
+extern "C" int pcq_scan_dev(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c, void *stream) {
+    if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_dev: null context");
+    return scan_dev_impl(ctx, cols, pred, c, stream ? (hipStream_t)stream : ctx->stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// scan over host-resident columns: pinned double buffers + hipMemcpyAsync overlapped with kernels
+// ---------------------------------------------------------------------------------------------
+static int ensure_stage(pcq_ctx *ctx, size_t bytes) {
+    if (ctx->stage_bytes >= bytes) return PCQ_OK;
+    PCQ_HIP(hipStreamSynchronize(ctx->stream));
+    PCQ_HIP(hipStreamSynchronize(ctx->copy_stream));
+    for (int i = 0; i < 2; i++) {
+        if (ctx->h_stage[i]) PCQ_HIP(hipHostFree(ctx->h_stage[i]));
+        if (ctx->d_stage[i]) PCQ_HIP(hipFree(ctx->d_stage[i]));
+        ctx->h_stage[i] = nullptr;
+        ctx->d_stage[i] = nullptr;
+    }
+    ctx->stage_bytes = 0;
+    for (int i = 0; i < 2; i++) {
+        PCQ_HIP(hipHostMalloc((void **)&ctx->h_stage[i], bytes, hipHostMallocDefault));
+        PCQ_HIP(hipMalloc((void **)&ctx->d_stage[i], bytes));
+    }
+    ctx->stage_bytes = bytes;
+    return PCQ_OK;
+}
+
+struct StagePlan {
+    bool aos;                  // LAS records: one interleaved range
+    bool need_xyz, need_cls, need_rgb;
+    uint64_t bytes_per_point;  // staged bytes per point (without per-region alignment slack)
+    const uint8_t *aos_base;   // lowest needed column pointer of the first record
+    uint64_t stride;           // aos stride
+    uint64_t span;             // bytes from aos_base to the end of the last needed column of a record
+};
+
+static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+extern "C" int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
+    if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_host: null context");
+    int rc = validate_scan(cols, pred, c);
+    if (rc) return rc;
+    if (cols->n == 0) return PCQ_OK;
+    PCQ_HIP(hipSetDevice(ctx->device));
+
+    StagePlan pl{};
+    pl.need_xyz = pred->kind == PCQ_PRED_BOUNDS || c->kind != COLL_COUNT;
+    pl.need_cls = pred->kind == PCQ_PRED_CLASS || c->kind != COLL_COUNT;
+    pl.need_rgb = c->kind != COLL_COUNT && cols->rgb != nullptr;
+    const uint8_t *hx = (const uint8_t *)cols->xyz, *hc = (const uint8_t *)cols->cls, *hr = (const uint8_t *)cols->rgb;
+    // AoS (LAS): every needed column has the same stride and lives inside one record
+    {
+        const uint64_t st = pl.need_xyz ? cols->xyz_stride : cols->cls_stride;
+        bool same = st > 12 || (!pl.need_xyz && st > 1);
+        if (pl.need_xyz && cols->xyz_stride != st) same = false;
+        if (pl.need_cls && cols->cls_stride != st) same = false;
+        if (pl.need_rgb && cols->rgb_stride != st) same = false;
+        const uint8_t *lo = nullptr, *hi = nullptr;
+        auto upd = [&](const uint8_t *p, uint64_t sz) {
+            if (!lo || p < lo) lo = p;
+            if (!hi || p + sz > hi) hi = p + sz;
+        };
+        if (pl.need_xyz) upd(hx, 12);
+        if (pl.need_cls) upd(hc, 1);
+        if (pl.need_rgb) upd(hr, 6);
+        if (same && lo && (uint64_t)(hi - lo) <= st && st > 1) {
+            pl.aos = true;
+            pl.aos_base = lo;
+            pl.stride = st;
+            pl.span = (uint64_t)(hi - lo);
+            pl.bytes_per_point = st;
+        }
+    }
+    if (!pl.aos) {
+        if ((pl.need_xyz && cols->xyz_stride != 12) || (pl.need_cls && cols->cls_stride != 1) ||
+            (pl.need_rgb && cols->rgb_stride != 6))
+            return pcq_fail(PCQ_ERR_ARG, "pcq_scan_host: columns must be packed blocks (LAST) or one interleaved record (LAS)");
+        pl.bytes_per_point = (pl.need_xyz ? 12 : 0) + (pl.need_cls ? 1 : 0) + (pl.need_rgb ? 6 : 0);
+    }
+
+    uint64_t chunk = ctx->chunk_points;
+    if (chunk > cols->n) chunk = cols->n;
+    // keep each staging buffer <= 512 MiB
+    const uint64_t max_stage = 512ull << 20;
+    if (chunk * pl.bytes_per_point > max_stage) chunk = max_stage / pl.bytes_per_point;
+    if (chunk < 1) chunk = 1;
+    chunk = (chunk + 3) & ~3ull;  // multiples of 4 points keep 12-byte blocks 16-byte aligned per chunk
+    const size_t stage_need = (size_t)(chunk * pl.bytes_per_point) + 64;
+    rc = ensure_stage(ctx, stage_need);
+    if (rc) return rc;
+
+    hipStream_t s = ctx->stream, cs = ctx->copy_stream;
+    const uint64_t nchunks = (cols->n + chunk - 1) / chunk;
+
+    // region offsets inside a staging buffer (SoA case)
+    const size_t off_xyz = 0;
+    const size_t off_cls = pl.need_xyz ? align16((size_t)chunk * 12) : 0;
+    const size_t off_rgb = off_cls + (pl.need_cls ? align16((size_t)chunk) : 0);
+
+    auto stage = [&](uint64_t k) -> int {
+        const int b = (int)(k & 1);
+        const uint64_t first = k * chunk;
+        const uint64_t cnt = cols->n - first < chunk ? cols->n - first : chunk;
+        if (k >= 2) PCQ_HIP(hipEventSynchronize(ctx->consumed[b]));  // kernels of chunk k-2 are done with d_stage[b]
+        uint8_t *h = ctx->h_stage[b];
+        size_t bytes;
+        if (pl.aos) {
+            // up to the last needed byte of the last record (never past the caller's mapping)
+            bytes = (size_t)((cnt - 1) * pl.stride + pl.span);
+            memcpy(h, pl.aos_base + first * pl.stride, bytes);
+        } else {
+            if (pl.need_xyz) memcpy(h + off_xyz, hx + first * 12, (size_t)cnt * 12);
+            if (pl.need_cls) memcpy(h + off_cls, hc + first, (size_t)cnt);
+            if (pl.need_rgb) memcpy(h + off_rgb, hr + first * 6, (size_t)cnt * 6);
+            bytes = off_rgb + (pl.need_rgb ? (size_t)cnt * 6 : 0);
+            if (!pl.need_rgb) bytes = off_cls + (pl.need_cls ? (size_t)cnt : 0);
+            if (!pl.need_cls && !pl.need_rgb) bytes = (size_t)cnt * 12;
+        }
+        PCQ_HIP(hipMemcpyAsync(ctx->d_stage[b], h, bytes, hipMemcpyHostToDevice, cs));
+        PCQ_HIP(hipEventRecord(ctx->copied[b], cs));
+        return PCQ_OK;
+    };
+
+    rc = stage(0);
+    if (rc) return rc;
+    for (uint64_t k = 0; k < nchunks; k++) {
+        const int b = (int)(k & 1);
+        if (k + 1 < nchunks) {  // stage the next chunk while this one is scanned
+            rc = stage(k + 1);
+            if (rc) return rc;
+        }
+        const uint64_t first = k * chunk;
+        const uint64_t cnt = cols->n - first < chunk ? cols->n - first : chunk;
+        PCQ_HIP(hipStreamWaitEvent(s, ctx->copied[b], 0));
+        pcq_columns dcols = *cols;
+        const uint8_t *d = ctx->d_stage[b];
+        if (pl.aos) {
+            dcols.xyz = pl.need_xyz ? d + (hx - pl.aos_base) : nullptr;
+            dcols.cls = pl.need_cls ? d + (hc - pl.aos_base) : nullptr;
+            dcols.rgb = pl.need_rgb ? d + (hr - pl.aos_base) : nullptr;
+        } else {
+            dcols.xyz = pl.need_xyz ? d + off_xyz : nullptr;
+            dcols.cls = pl.need_cls ? d + off_cls : nullptr;
+            dcols.rgb = pl.need_rgb ? d + off_rgb : nullptr;
+        }
+        dcols.n = cnt;
+        dcols.first_index = cols->first_index + first;
+        rc = scan_dev_impl(ctx, &dcols, pred, c, s);
+        if (rc) return rc;
+        PCQ_HIP(hipEventRecord(ctx->consumed[b], s));
+    }
+    PCQ_HIP(hipStreamSynchronize(s));
+    return PCQ_OK;
+}

@@ -1,0 +1,160 @@
+// pcq_internal.h — shared declarations of libpcq.so (not part of the public ABI; see include/pcq.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+
+#include "pcq.h"
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------
+int pcq_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define PCQ_HIP(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return pcq_fail(PCQ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                            __FILE__, __LINE__);                                                \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device-side views
+// ---------------------------------------------------------------------------------------------
+
+// Predicate in device form.  The i64 box of the reference (last.rs:98-109) is clamped to the i32
+// value range of the stored coordinates; `(uint32)(v - lo) <= width` is then exactly
+// `lo <= v && v <= hi` on sign-extended values (last.rs:122-135).
+struct DevPred {
+    int32_t kind;      // pcq_predicate_kind
+    int32_t empty;     // 1: no i32 coordinate can match (box entirely outside the i32 range)
+    int32_t lo[3];
+    uint32_t width[3];
+    uint32_t cls;
+};
+
+struct DevCols {
+    const uint8_t *xyz;
+    const uint8_t *cls;
+    const uint8_t *rgb;
+    uint64_t xyz_stride, cls_stride, rgb_stride;
+    uint64_t n;
+    uint64_t first_index;
+    double scale[3];
+    double offset[3];
+};
+
+// One segment of a batched count launch.
+struct DevSegment {
+    const int4 *xyz;       // 16-byte aligned positions block
+    uint64_t n;            // points
+    uint64_t tile_begin;   // first global wave-tile index of this segment
+    int32_t lo[3];
+    uint32_t width[3];
+    int32_t empty;
+    int32_t _pad;
+};
+
+// SparseGrid parameters (grid_sampling.rs:9-47) in device form.
+struct DevGrid {
+    double bmin[3], bmax[3];
+    double cell_size;
+    double dims_f[3];     // dims as f64 (`self.dimensions.x as f64`, grid_sampling.rs:51)
+    uint64_t mask[3];     // (1 << bits) - 1
+    uint32_t shift[3];    // 0, bits_x, bits_x + bits_y  (already & 63)
+};
+
+// HBM hash table behind the grid collector.
+struct DevGridTable {
+    uint64_t *keys;       // PCQ_EMPTY_KEY = free
+    uint64_t *dist;       // f64 bits of the winning squared distance (monotone for d >= 0)
+    uint64_t *widx;       // file-order index of the winner
+    uint8_t *pts;         // 32-byte slots holding the winner's pcq_point (31 bytes used)
+    uint8_t *flags;       // bit0: slot holds a materialised point, bit1: key saw an aliased cell
+    uint64_t cap;         // power of two
+    uint64_t *occupied;   // device counter of used slots
+    uint64_t *n_alias;    // device counter of aliased points seen
+};
+
+constexpr uint64_t PCQ_EMPTY_KEY = ~0ull;
+constexpr uint64_t PCQ_NO_INDEX = ~0ull;
+
+// ---------------------------------------------------------------------------------------------
+// host-side objects
+// ---------------------------------------------------------------------------------------------
+struct pcq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;       // compute stream
+    hipStream_t copy_stream = nullptr;  // H2D stream
+    hipEvent_t copied[2] = {nullptr, nullptr};
+    hipEvent_t consumed[2] = {nullptr, nullptr};
+    int num_cus = 0;
+    hipDeviceProp_t prop;
+    // scratch: per-block partial counts / block offsets
+    uint64_t *d_partials = nullptr;
+    size_t partials_cap = 0;
+    uint64_t *d_scalars = nullptr;      // a few device u64 scratch words
+    uint64_t *h_scalars = nullptr;      // pinned mirror
+    // staging for pcq_scan_host
+    uint8_t *h_stage[2] = {nullptr, nullptr};
+    uint8_t *d_stage[2] = {nullptr, nullptr};
+    size_t stage_bytes = 0;
+    // segment table for batched launches
+    DevSegment *d_segments = nullptr;
+    DevSegment *h_segments = nullptr;
+    size_t segments_cap = 0;
+    // options
+    int k1_variant = 0;
+    int grid_blocks_per_cu = 8;
+    uint64_t chunk_points = 8ull << 20;
+};
+
+enum { COLL_COUNT = 0, COLL_BUFFER = 1, COLL_GRID = 2 };
+
+struct pcq_collector {
+    int kind = COLL_COUNT;
+    pcq_ctx *ctx = nullptr;
+    // count
+    uint64_t *d_count = nullptr;
+    bool owns_count = false;
+    // buffer: packed 31-byte points in HBM
+    uint8_t *d_points = nullptr;
+    uint64_t n_points = 0, cap_points = 0;
+    // grid
+    double bmin[3], bmax[3], cell_size = 0;
+    uint64_t dims[3], bits[3];
+    DevGrid grid;
+    DevGridTable table;
+    uint64_t table_used_bound = 0;      // host-side count of occupied slots after the last scan
+    bool grid_has_alias = false;        // sticky: some key has seen an aliased cell (grid.hip pass R)
+    uint64_t next_index = 0;            // file-order index the next scan starts at
+};
+
+// ---------------------------------------------------------------------------------------------
+// internal entry points (defined across the .hip files)
+// ---------------------------------------------------------------------------------------------
+int pcq_make_dev_pred(const pcq_predicate *p, DevPred *out);
+int pcq_ensure_partials(pcq_ctx *ctx, size_t n);
+
+// scan_count.hip
+int pcq_launch_bounds_count_xyz12(pcq_ctx *ctx, const void *d_xyz, uint64_t n, const DevPred &pred,
+                                  uint64_t *d_count, hipStream_t s);
+int pcq_launch_class_count_u8(pcq_ctx *ctx, const void *d_cls, uint64_t n, uint8_t cls,
+                              uint64_t *d_count, hipStream_t s);
+// scan_generic.hip
+int pcq_launch_generic_count(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred,
+                             uint64_t *d_count, hipStream_t s);
+int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint8_t *d_out31,
+                           uint64_t out_base, uint64_t expected, hipStream_t s);
+int pcq_emit_prepare(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint64_t *matches, hipStream_t s);
+// grid.hip
+int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const DevPred &pred,
+                  uint64_t matches_upper_bound, hipStream_t s);
+int pcq_grid_alloc(pcq_ctx *ctx, pcq_collector *c, uint64_t cap);
+void pcq_grid_release(pcq_collector *c);
+int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_t cap, uint64_t *out_n);

@@ -1,0 +1,379 @@
+// scan_count.hip — the count-only fast paths of the predicate scan (kernels K1 and K2).
+//
+// K1 bounds_count restates the loop of search_last_file_by_bounds_optimized
+//    (query/src/search/last.rs:117-135) feeding a CountCollector (collect_points.rs:83-85):
+//    count of points with lmin <= (x,y,z) <= lmax over the LAST positions block, N x {i32 x,y,z}.
+// K2 class_count restates search_last_file_by_classification_optimized (last.rs:253-262):
+//    count of classification bytes equal to `cls` over the LAST classification block, N x u8.
+//
+// Both are pure HBM streaming reads (12 B/point, 1 B/point): no MFMA, no reuse.  Design for gfx950:
+//  * every global load is a fully coalesced 16 B/lane access (1 KiB per wave-instruction),
+//    issued non-temporal (the stream is read once);
+//  * a 12-byte point is not a power of two, so a wave owns a 768-dword tile (= 256 whole points,
+//    3 KiB) loaded by three dwordx4 instructions; instead of transposing through LDS, each dword is
+//    range-tested against the bound of ITS component ((k + lane + j) mod 3, rotated per lane once)
+//    and the 64-bit compare masks (wave64: v_cmp writes an SGPR pair) are combined with scalar
+//    shifts/ANDs into "three consecutive dwords pass" bits, popcounted with s_bcnt1 — the VALU sees
+//    two instructions per dword, everything else runs on the scalar unit;
+//  * persistent grid (blocks_per_cu x 256 CUs, 256 threads) with a tile-stride loop; per-block
+//    partial counts are written with plain stores and folded by a 1-block finishing kernel, so no
+//    same-address atomic storm at the tail.
+#include "pcq_internal.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+constexpr int TILE_POINTS = 256;  // per wave: 768 dwords = 3 x (64 lanes x 16 B)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr uint64_t R0 = 0x9249249249249249ull;  // lanes with lane % 3 == 0
+constexpr uint64_t R1 = 0x2492492492492492ull;  // lane % 3 == 1
+constexpr uint64_t R2 = 0x4924924924924924ull;  // lane % 3 == 2
+
+// lanes l for which dword (k, l, j) of a tile is the first component of a point:
+// (k + l + j) % 3 == 0  <=>  l % 3 == (3 - (k + j) % 3) % 3
+__device__ __forceinline__ constexpr uint64_t start_lanes(int s) {
+    return (s % 3) == 0 ? R0 : ((s % 3) == 1 ? R2 : R1);
+}
+
+__device__ __forceinline__ v4i ld_nt(const v4i *p) { return __builtin_nontemporal_load(p); }
+
+struct LaneBox {
+    int lo[3];        // lo[(lane%3 + t) % 3], t = 0..2
+    uint32_t w[3];
+};
+
+__device__ __forceinline__ LaneBox rotate_box(const int32_t (&lo)[3], const uint32_t (&w)[3], int lane) {
+    const int r = lane % 3;
+    LaneBox b;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int c = (r + t) % 3;
+        b.lo[t] = c == 0 ? lo[0] : (c == 1 ? lo[1] : lo[2]);
+        b.w[t] = c == 0 ? w[0] : (c == 1 ? w[1] : w[2]);
+    }
+    return b;
+}
+
+// Count of matching points in one 768-dword wave tile, mask-algebra form (wave-uniform result).
+__device__ __forceinline__ uint32_t tile_count_masks(const v4i *tile, int lane, const LaneBox &b) {
+    v4i v[3];
+    v[0] = ld_nt(tile + lane);
+    v[1] = ld_nt(tile + 64 + lane);
+    v[2] = ld_nt(tile + 128 + lane);
+    uint64_t m[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int t = (k + j) % 3;
+            m[k][j] = __ballot((uint32_t)(v[k][j] - b.lo[t]) <= b.w[t]);
+        }
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint64_t m0 = m[k][0], m1 = m[k][1], m2 = m[k][2], m3 = m[k][3];
+        // dwords 4l+4, 4l+5: lane l+1 of this load, or lane 0 of the next one.  The tile ends on a
+        // point boundary, so nothing is carried out of k == 2.
+        const uint64_t c0 = k < 2 ? m[k < 2 ? k + 1 : k][0] : 0ull;
+        const uint64_t c1 = k < 2 ? m[k < 2 ? k + 1 : k][1] : 0ull;
+        const uint64_t n0 = (m0 >> 1) | (c0 << 63);
+        const uint64_t n1 = (m1 >> 1) | (c1 << 63);
+        const uint64_t a = m1 & m2;
+        const uint64_t t0 = m0 & a;      // dwords j=0,1,2 of lane l
+        const uint64_t t1 = a & m3;      // j=1,2,3
+        const uint64_t bb = m3 & n0;
+        const uint64_t t2 = m2 & bb;     // j=2,3 and next lane's 0
+        const uint64_t t3 = bb & n1;     // j=3 and next lane's 0,1
+        const uint64_t s012 = (t0 & start_lanes(k)) | (t1 & start_lanes(k + 1)) | (t2 & start_lanes(k + 2));
+        cnt += (uint32_t)__popcll(s012) + (uint32_t)__popcll(t3 & start_lanes(k + 3));
+    }
+    return cnt;
+}
+
+// One point per lane per load (global_load_dwordx3), 4 loads per tile.
+struct __attribute__((packed, aligned(4))) P3 {
+    int x, y, z;
+};
+
+__device__ __forceinline__ uint32_t tile_count_x3(const v4i *tile, int lane, const int32_t (&lo)[3],
+                                                  const uint32_t (&w)[3]) {
+    const P3 *pts = reinterpret_cast<const P3 *>(tile);
+    P3 p[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) p[q] = pts[q * 64 + lane];
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const bool pass = ((uint32_t)(p[q].x - lo[0]) <= w[0]) & ((uint32_t)(p[q].y - lo[1]) <= w[1]) &
+                          ((uint32_t)(p[q].z - lo[2]) <= w[2]);
+        cnt += (uint32_t)__popcll(__ballot(pass));
+    }
+    return cnt;
+}
+
+// Four whole points per lane: 48 contiguous bytes as three 16-byte loads at a 48-byte lane stride.
+__device__ __forceinline__ uint32_t tile_count_lane48(const v4i *tile, int lane, const int32_t (&lo)[3],
+                                                      const uint32_t (&w)[3]) {
+    const v4i a = ld_nt(tile + 3 * lane), b = ld_nt(tile + 3 * lane + 1), c = ld_nt(tile + 3 * lane + 2);
+    const int d[12] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], c[0], c[1], c[2], c[3]};
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const bool pass = ((uint32_t)(d[3 * q] - lo[0]) <= w[0]) & ((uint32_t)(d[3 * q + 1] - lo[1]) <= w[1]) &
+                          ((uint32_t)(d[3 * q + 2] - lo[2]) <= w[2]);
+        cnt += (uint32_t)__popcll(__ballot(pass));
+    }
+    return cnt;
+}
+
+__device__ __forceinline__ void block_store_partial(uint64_t wave_total, uint64_t *partials) {
+    __shared__ uint64_t s_w[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) s_w[wave] = wave_total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) t += s_w[i];
+        partials[blockIdx.x] = t;
+    }
+}
+
+// K1.  VARIANT 0: mask algebra (default) · 1: dwordx3 per lane · 2: 48-byte lane stride
+//      · 3: mask algebra, two tiles in flight per wave.
+template <int VARIANT>
+__global__ __launch_bounds__(BLOCK) void k_bounds_count_xyz12(const v4i *__restrict__ base, uint64_t n,
+                                                              DevPred pred, uint64_t *__restrict__ partials) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t tiles = n / TILE_POINTS;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const uint64_t stride = (uint64_t)gridDim.x * WAVES;
+    uint64_t total = 0;  // wave-uniform
+    const LaneBox lb = rotate_box(pred.lo, pred.width, lane);
+    if (VARIANT == 3) {
+        uint64_t t = wave_id;
+        for (; t + stride < tiles; t += 2 * stride) {
+            total += tile_count_masks(base + t * 192, lane, lb);
+            total += tile_count_masks(base + (t + stride) * 192, lane, lb);
+        }
+        if (t < tiles) total += tile_count_masks(base + t * 192, lane, lb);
+    } else {
+        for (uint64_t t = wave_id; t < tiles; t += stride) {
+            const v4i *tile = base + t * 192;  // 192 x 16 B = 3 KiB
+            if (VARIANT == 0) total += tile_count_masks(tile, lane, lb);
+            else if (VARIANT == 1) total += tile_count_x3(tile, lane, pred.lo, pred.width);
+            else total += tile_count_lane48(tile, lane, pred.lo, pred.width);
+        }
+    }
+    // ragged tail: fewer than 256 points, one per thread of the first block
+    const uint64_t rem_first = tiles * TILE_POINTS;
+    if (blockIdx.x == 0) {
+        const uint64_t p = rem_first + threadIdx.x;
+        bool pass = false;
+        if (p < n) {
+            const int *q = reinterpret_cast<const int *>(base) + 3 * p;
+            pass = ((uint32_t)(q[0] - pred.lo[0]) <= pred.width[0]) & ((uint32_t)(q[1] - pred.lo[1]) <= pred.width[1]) &
+                   ((uint32_t)(q[2] - pred.lo[2]) <= pred.width[2]);
+        }
+        total += (uint64_t)__popcll(__ballot(pass));
+    }
+    block_store_partial(total, partials);
+}
+
+// Batched K1: many device-resident LAST position blocks (one per file) in one launch.
+__global__ __launch_bounds__(BLOCK) void k_bounds_count_batch(const DevSegment *__restrict__ segs, int nseg,
+                                                              uint64_t total_tiles, uint64_t *__restrict__ partials) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const uint64_t stride = (uint64_t)gridDim.x * WAVES;
+    uint64_t total = 0;
+    int s = 0;
+    uint64_t seg_begin = 0, seg_end = 0;  // tile range of the cached segment
+    const v4i *seg_base = nullptr;
+    LaneBox lb = {};
+    bool seg_empty = true;
+    for (uint64_t t = wave_id; t < total_tiles; t += stride) {
+        if (t >= seg_end) {
+            while (s + 1 < nseg && t >= segs[s + 1].tile_begin) s++;
+            seg_begin = segs[s].tile_begin;
+            seg_end = seg_begin + segs[s].n / TILE_POINTS;
+            seg_base = reinterpret_cast<const v4i *>(segs[s].xyz);
+            seg_empty = segs[s].empty != 0;
+            lb = rotate_box(segs[s].lo, segs[s].width, lane);
+        }
+        if (!seg_empty) total += tile_count_masks(seg_base + (t - seg_begin) * 192, lane, lb);
+    }
+    // ragged tails: segment i's tail belongs to block i % gridDim.x
+    for (int i = blockIdx.x; i < nseg; i += gridDim.x) {
+        const uint64_t n = segs[i].n;
+        const uint64_t p = (n / TILE_POINTS) * TILE_POINTS + threadIdx.x;
+        bool pass = false;
+        if (p < n && !segs[i].empty) {
+            const int *q = reinterpret_cast<const int *>(segs[i].xyz) + 3 * p;
+            pass = ((uint32_t)(q[0] - segs[i].lo[0]) <= segs[i].width[0]) &
+                   ((uint32_t)(q[1] - segs[i].lo[1]) <= segs[i].width[1]) &
+                   ((uint32_t)(q[2] - segs[i].lo[2]) <= segs[i].width[2]);
+        }
+        total += (uint64_t)__popcll(__ballot(pass));
+    }
+    block_store_partial(total, partials);
+}
+
+// Bytes of a dword equal to zero -> 0x80 in that byte (exact, no borrow artefacts).
+__device__ __forceinline__ uint32_t zero_bytes(uint32_t x) {
+    const uint32_t t = (x & 0x7f7f7f7fu) + 0x7f7f7f7fu;
+    return ~(t | x | 0x7f7f7f7fu);
+}
+
+// K2.  `body` is the 16-byte aligned part of the classification block; head/tail bytes are
+// handled by the first block.
+__global__ __launch_bounds__(BLOCK) void k_class_count_u8(const uint8_t *__restrict__ cls, uint64_t n, uint32_t pat,
+                                                          uint64_t head, uint64_t nvec, uint64_t *__restrict__ partials) {
+    const v4i *body = reinterpret_cast<const v4i *>(cls + head);
+    const uint64_t tid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
+    uint32_t cnt = 0;
+    uint64_t i = tid;
+    for (; i + 3 * nthreads < nvec; i += 4 * nthreads) {
+        const v4i a = ld_nt(body + i), b = ld_nt(body + i + nthreads), c = ld_nt(body + i + 2 * nthreads),
+                  d = ld_nt(body + i + 3 * nthreads);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            cnt += __popc(zero_bytes((uint32_t)a[j] ^ pat));
+            cnt += __popc(zero_bytes((uint32_t)b[j] ^ pat));
+            cnt += __popc(zero_bytes((uint32_t)c[j] ^ pat));
+            cnt += __popc(zero_bytes((uint32_t)d[j] ^ pat));
+        }
+    }
+    for (; i < nvec; i += nthreads) {
+        const v4i a = ld_nt(body + i);
+#pragma unroll
+        for (int j = 0; j < 4; j++) cnt += __popc(zero_bytes((uint32_t)a[j] ^ pat));
+    }
+    if (blockIdx.x == 0) {
+        const uint8_t c8 = (uint8_t)(pat & 0xff);
+        // head: [0, head)   tail: [head + 16*nvec, n)   (each < 16 bytes)
+        if (threadIdx.x < 16) {
+            const uint64_t p = threadIdx.x;
+            if (p < head && cls[p] == c8) cnt++;
+        } else if (threadIdx.x < 32) {
+            const uint64_t p = head + 16 * nvec + (threadIdx.x - 16);
+            if (p < n && cls[p] == c8) cnt++;
+        }
+    }
+    // wave reduce
+    uint64_t w = cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down((unsigned long long)w, off, 64);
+    block_store_partial(w, partials);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_finish_count(const uint64_t *__restrict__ partials, int nblocks,
+                                                        uint64_t *__restrict__ d_count) {
+    __shared__ uint64_t s[BLOCK];
+    uint64_t t = 0;
+    for (int i = threadIdx.x; i < nblocks; i += BLOCK) t += partials[i];
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd((unsigned long long *)d_count, (unsigned long long)s[0]);
+}
+
+}  // namespace
+
+static int grid_for(pcq_ctx *ctx, uint64_t work_items_per_block_min, uint64_t items) {
+    uint64_t want = (items + work_items_per_block_min - 1) / work_items_per_block_min;
+    uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->grid_blocks_per_cu;
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+int pcq_launch_bounds_count_xyz12(pcq_ctx *ctx, const void *d_xyz, uint64_t n, const DevPred &pred,
+                                  uint64_t *d_count, hipStream_t s) {
+    if (n == 0 || pred.empty) return PCQ_OK;
+    if (((uintptr_t)d_xyz & 15) != 0) return pcq_fail(PCQ_ERR_ARG, "bounds_count_xyz12: positions block must be 16-byte aligned");
+    const int grid = grid_for(ctx, (uint64_t)WAVES * TILE_POINTS, n);
+    int rc = pcq_ensure_partials(ctx, (size_t)grid);
+    if (rc) return rc;
+    const v4i *base = reinterpret_cast<const v4i *>(d_xyz);
+    switch (ctx->k1_variant) {
+    case 1: hipLaunchKernelGGL(k_bounds_count_xyz12<1>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
+    case 2: hipLaunchKernelGGL(k_bounds_count_xyz12<2>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
+    case 3: hipLaunchKernelGGL(k_bounds_count_xyz12<3>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
+    default: hipLaunchKernelGGL(k_bounds_count_xyz12<0>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
+    }
+    hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, grid, d_count);
+    PCQ_HIP(hipGetLastError());
+    return PCQ_OK;
+}
+
+int pcq_launch_class_count_u8(pcq_ctx *ctx, const void *d_cls, uint64_t n, uint8_t cls, uint64_t *d_count,
+                              hipStream_t s) {
+    if (n == 0) return PCQ_OK;
+    uint64_t head = (uint64_t)((16 - ((uintptr_t)d_cls & 15)) & 15);
+    if (head > n) head = n;
+    const uint64_t nvec = (n - head) / 16;
+    const int grid = grid_for(ctx, (uint64_t)BLOCK * 4, nvec ? nvec : 1);
+    int rc = pcq_ensure_partials(ctx, (size_t)grid);
+    if (rc) return rc;
+    const uint32_t pat = 0x01010101u * (uint32_t)cls;
+    hipLaunchKernelGGL(k_class_count_u8, dim3(grid), dim3(BLOCK), 0, s, reinterpret_cast<const uint8_t *>(d_cls), n, pat,
+                       head, nvec, ctx->d_partials);
+    hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, grid, d_count);
+    PCQ_HIP(hipGetLastError());
+    return PCQ_OK;
+}
+
+extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *preds,
+                                        size_t nsegments, uint64_t *device_total, void *stream) {
+    if (!ctx || (!cols && nsegments) || (!preds && nsegments) || !device_total)
+        return pcq_fail(PCQ_ERR_ARG, "pcq_scan_dev_count_batch: null argument");
+    if (nsegments == 0) return PCQ_OK;
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (nsegments > ctx->segments_cap) {
+        if (ctx->d_segments) (void)hipFree(ctx->d_segments);
+        if (ctx->h_segments) (void)hipHostFree(ctx->h_segments);
+        ctx->d_segments = nullptr;
+        ctx->h_segments = nullptr;
+        ctx->segments_cap = 0;
+        size_t cap = nsegments < 64 ? 64 : nsegments;
+        PCQ_HIP(hipMalloc((void **)&ctx->d_segments, cap * sizeof(DevSegment)));
+        PCQ_HIP(hipHostMalloc((void **)&ctx->h_segments, cap * sizeof(DevSegment), hipHostMallocDefault));
+        ctx->segments_cap = cap;
+    }
+    // The pinned table is reused by the next call: wait for the previous upload to be consumed.
+    PCQ_HIP(hipStreamSynchronize(s));
+    uint64_t tiles = 0, points = 0;
+    for (size_t i = 0; i < nsegments; i++) {
+        if (preds[i].kind != PCQ_PRED_BOUNDS) return pcq_fail(PCQ_ERR_ARG, "count_batch: only bounds predicates");
+        if (cols[i].xyz_stride != 12) return pcq_fail(PCQ_ERR_ARG, "count_batch: LAST positions blocks only (stride 12)");
+        if (((uintptr_t)cols[i].xyz & 15) != 0) return pcq_fail(PCQ_ERR_ARG, "count_batch: positions block %zu not 16-byte aligned", i);
+        DevPred dp;
+        int rc = pcq_make_dev_pred(&preds[i], &dp);
+        if (rc) return rc;
+        DevSegment &g = ctx->h_segments[i];
+        g.xyz = reinterpret_cast<const int4 *>(cols[i].xyz);
+        g.n = cols[i].n;
+        g.tile_begin = tiles;
+        for (int a = 0; a < 3; a++) g.lo[a] = dp.lo[a], g.width[a] = dp.width[a];
+        g.empty = dp.empty;
+        g._pad = 0;
+        tiles += cols[i].n / TILE_POINTS;
+        points += cols[i].n;
+    }
+    PCQ_HIP(hipMemcpyAsync(ctx->d_segments, ctx->h_segments, nsegments * sizeof(DevSegment), hipMemcpyHostToDevice, s));
+    const int grid = grid_for(ctx, (uint64_t)WAVES * TILE_POINTS, points ? points : 1);
+    int rc = pcq_ensure_partials(ctx, (size_t)grid);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_bounds_count_batch, dim3(grid), dim3(BLOCK), 0, s, ctx->d_segments, (int)nsegments, tiles,
+                       ctx->d_partials);
+    hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, grid, device_total);
+    PCQ_HIP(hipGetLastError());
+    return PCQ_OK;
+}

@@ -1,0 +1,181 @@
+// scan_generic.hip — layout-generic scan kernels (any column strides: LAST column blocks or LAS
+// AoS records), used where the count-only fast paths of scan_count.hip do not apply:
+//   * strided count            — LAS bounds/class count (las.rs:101-119, :221-231), unaligned LAST
+//   * order-preserving emit    — BufferCollector semantics (collect_points.rs:29-31): matches are
+//                                appended in file order, as 31-byte Point records built like
+//                                last.rs:137-163.
+// The emit is a two-pass stable stream compaction: (1) per-tile match counts, (2) exclusive scan of
+// the tile counts, (3) re-evaluate the predicate and write each match at
+// tile_offset + rank-in-tile, where the rank comes from a wave64 ballot prefix
+// (popcount(mask & lanes_below)) plus an LDS prefix over the block's four waves.
+#include "dev_common.h"
+
+using namespace pcqdev;
+
+namespace {
+
+__global__ __launch_bounds__(BLOCK) void k_generic_count(DevCols c, DevPred pr, uint64_t *__restrict__ partials) {
+    const uint64_t tid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
+    uint64_t cnt = 0;
+    for (uint64_t i = tid; i < c.n; i += nthreads) {
+        RawPoint rp;
+        bool have;
+        cnt += eval_pred(c, pr, i, rp, have) ? 1 : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down((unsigned long long)cnt, off, 64);
+    __shared__ uint64_t s_w[WAVES];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int i = 0; i < WAVES; i++) t += s_w[i];
+        partials[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_sum_partials(const uint64_t *__restrict__ partials, int nblocks,
+                                                        uint64_t *__restrict__ d_count) {
+    __shared__ uint64_t s[BLOCK];
+    uint64_t t = 0;
+    for (int i = threadIdx.x; i < nblocks; i += BLOCK) t += partials[i];
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd((unsigned long long *)d_count, (unsigned long long)s[0]);
+}
+
+// Pass 1: block b owns points [b*TILE, (b+1)*TILE); counts[b] = matches in the tile.
+__global__ __launch_bounds__(BLOCK) void k_tile_counts(DevCols c, DevPred pr, uint64_t *__restrict__ counts) {
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) {
+        const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
+        RawPoint rp;
+        bool have;
+        const bool pass = i < c.n && eval_pred(c, pr, i, rp, have);
+        cnt += (uint32_t)__popcll(__ballot(pass));  // wave-uniform
+    }
+    __shared__ uint32_t s_w[WAVES];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int i = 0; i < WAVES; i++) t += s_w[i];
+        counts[blockIdx.x] = t;
+    }
+}
+
+// Pass 2: in-place exclusive scan of counts[0..n) by one block; total -> *total_out.
+__global__ __launch_bounds__(1024) void k_exclusive_scan(uint64_t *__restrict__ counts, uint64_t n,
+                                                         uint64_t *__restrict__ total_out) {
+    __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < n; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const uint64_t v = i < n ? counts[i] : 0;
+        uint64_t incl = v;  // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint64_t up = __shfl_up((unsigned long long)incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint64_t wave_off = 0;
+        for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+        const uint64_t carry = s_carry;
+        if (i < n) counts[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = s_carry;
+}
+
+// Pass 3: write each match of tile b at out[(out_base + offsets[b] + rank) * 31].
+__global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, const uint64_t *__restrict__ offsets,
+                                                       uint8_t *__restrict__ out31, uint64_t out_base) {
+    __shared__ uint32_t s_w[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    uint64_t run = out_base + offsets[blockIdx.x];
+#pragma unroll 1
+    for (int j = 0; j < ITEMS; j++) {
+        const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
+        RawPoint rp;
+        bool have = false;
+        const bool pass = i < c.n && eval_pred(c, pr, i, rp, have);
+        const uint64_t mask = __ballot(pass);
+        if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; w++) {
+            const uint32_t v = s_w[w];
+            before += w < wave ? v : 0;
+            all += v;
+        }
+        if (pass) {
+            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (!have) rp = ld_xyz(c, i);
+            pcq_point pt;
+            make_point(c, i, rp, pt);
+            store_point31(out31 + (run + before + rank) * 31ull, pt);
+        }
+        run += all;
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+int pcq_launch_generic_count(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint64_t *d_count,
+                             hipStream_t s) {
+    if (cols.n == 0) return PCQ_OK;
+    uint64_t want = (cols.n + BLOCK * 4 - 1) / (BLOCK * 4);
+    const uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->grid_blocks_per_cu;
+    const int grid = (int)(want < cap ? want : cap);
+    int rc = pcq_ensure_partials(ctx, (size_t)grid);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_generic_count, dim3(grid), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials);
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, grid, d_count);
+    PCQ_HIP(hipGetLastError());
+    return PCQ_OK;
+}
+
+// Runs passes 1+2 and returns the number of matches (synchronises `s`).
+int pcq_emit_prepare(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint64_t *matches, hipStream_t s) {
+    *matches = 0;
+    if (cols.n == 0) return PCQ_OK;
+    const uint64_t nblocks = (cols.n + TILE - 1) / TILE;
+    if (nblocks > 0x7fffffffull) return pcq_fail(PCQ_ERR_ARG, "scan chunk too large (%llu points)", (unsigned long long)cols.n);
+    int rc = pcq_ensure_partials(ctx, (size_t)nblocks);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials);
+    hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, ctx->d_partials, nblocks, ctx->d_scalars);
+    PCQ_HIP(hipGetLastError());
+    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    PCQ_HIP(hipStreamSynchronize(s));
+    *matches = ctx->h_scalars[0];
+    return PCQ_OK;
+}
+
+int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint8_t *d_out31,
+                           uint64_t out_base, uint64_t expected, hipStream_t s) {
+    (void)expected;
+    if (cols.n == 0) return PCQ_OK;
+    const uint64_t nblocks = (cols.n + TILE - 1) / TILE;
+    hipLaunchKernelGGL(k_emit_points, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials, d_out31,
+                       out_base);
+    PCQ_HIP(hipGetLastError());
+    return PCQ_OK;
+}

@@ -1,0 +1,194 @@
+/*
+ * pcq.h — C ABI of the MI355X-native point-cloud predicate path ("libpcq.so").
+ *
+ * This is the drop-in boundary for the reference's `--optimized` predicate-evaluation hot path.
+ * The reference (Rust) has no FFI for this path: the seam is the body of the four free functions
+ *
+ *     search_last_file_by_bounds_optimized           query/src/search/last.rs:46-166
+ *     search_last_file_by_classification_optimized   query/src/search/last.rs:213-293
+ *     search_las_file_by_bounds_optimized            query/src/search/las.rs:52-148
+ *     search_las_file_by_classification_optimized    query/src/search/las.rs:192-261
+ *
+ * after they have mmapped the file and parsed the LAS header: a per-point loop that evaluates a
+ * predicate over column data and pushes every match into a `&mut dyn ResultCollector`
+ * (query/src/collect_points.rs:7-12).  The entry points below replace exactly that loop plus the
+ * collector it feeds; file IO and header parsing stay on the host side of the boundary (in the
+ * reference: readers/src + las crate; here: adhoc-queries-pointclouds_amd/host/).
+ *
+ * Plain pointers and sizes only.  `stream` arguments are hipStream_t passed as void*; NULL = the
+ * context's own stream.  All functions return 0 (PCQ_OK) or a negative pcq_status; the message of
+ * the last failure on the calling thread is available from pcq_last_error().
+ * No function falls back to a CPU implementation: without a usable HIP device pcq_init fails.
+ *
+ * INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add to bind these.
+ */
+#ifndef PCQ_H
+#define PCQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCQ_ABI_VERSION 1
+
+typedef enum pcq_status {
+    PCQ_OK = 0,
+    PCQ_ERR_IO = -1,          /* reserved for the host layer: File::open / mmap     (last.rs:27-34)  */
+    PCQ_ERR_HEADER = -2,      /* reserved for the host layer: LAS header parse      (last.rs:53-54)  */
+    PCQ_ERR_FORMAT = -3,      /* reserved for the host layer: "Invalid LAS format"  (last.rs:72-78)  */
+    PCQ_ERR_EXTENSION = -4,   /* reserved for the host layer: unsupported extension (searcher.rs:84) */
+    PCQ_ERR_EOF = -5,         /* column block extends past the mapped file                           */
+    PCQ_ERR_GRID = -6,        /* SparseGrid::new: too many cells                (grid_sampling.rs:32)*/
+    PCQ_ERR_PANIC = -7,       /* AABB::from_min_max min > max                       (last.rs:98)     */
+    PCQ_ERR_ARG = -8,         /* invalid argument                                                    */
+    PCQ_ERR_HIP = -9,         /* a HIP runtime call failed / no device                               */
+    PCQ_ERR_CAPACITY = -10,   /* caller buffer too small; required size reported through out param   */
+    PCQ_ERR_UNSUPPORTED = -11,/* valid in the reference but not representable here   */
+    PCQ_ERR_NOMEM = -12
+} pcq_status;
+
+/* readers/src/lib.rs:10-19 — `#[repr(C, packed)] struct Point`, 31 bytes. */
+#pragma pack(push, 1)
+typedef struct pcq_point {
+    double x, y, z;             /* position        @0  */
+    uint16_t r, g, b;           /* color           @24 */
+    uint8_t classification;     /* classification  @30 */
+} pcq_point;
+#pragma pack(pop)
+
+typedef struct pcq_ctx pcq_ctx;
+typedef struct pcq_collector pcq_collector;
+
+/* ---------------------------------------------------------------------------------------------
+ * Context: one per (thread, GPU).  Owns a HIP stream, pinned staging buffers and device scratch.
+ * Mirrors the reference's threading model: search_file is called concurrently from rayon workers
+ * (main.rs:153-161) — each worker uses its own context; a context is not thread-safe.
+ * ------------------------------------------------------------------------------------------- */
+int pcq_init(int device, pcq_ctx **out_ctx);
+int pcq_shutdown(pcq_ctx *ctx);
+const char *pcq_last_error(void);
+int pcq_abi_version(void);
+
+typedef struct pcq_device_info {
+    char name[128];
+    char gcn_arch[64];
+    int compute_units;
+    int wavefront_size;
+    uint64_t hbm_bytes;
+    uint64_t lds_bytes_per_block;
+    int clock_khz;
+} pcq_device_info;
+int pcq_get_device_info(pcq_ctx *ctx, pcq_device_info *out);
+/* The context's stream (hipStream_t as void*). */
+void *pcq_ctx_stream(pcq_ctx *ctx);
+int pcq_ctx_synchronize(pcq_ctx *ctx);
+
+/* ---------------------------------------------------------------------------------------------
+ * Column view of one file's point data (or of a chunk of it).
+ * LAST (readers/src/last_reader.rs:83-144): xyz_stride 12, cls_stride 1, rgb_stride 6.
+ * LAS  (las.rs:102-135): all three strides = point_data_record_length, pointers offset into the
+ * record (xyz +0, cls +15/+16, rgb +20/+28).
+ * scale/offset are the header's (last.rs:156-160); `first_index` is the file-order index of the
+ * first point of this view (used to keep "first seen wins" across chunks and files).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pcq_columns {
+    const void *xyz;            /* n records of {i32 x, i32 y, i32 z}, little endian            */
+    const void *cls;            /* n classification bytes; may be NULL for count-only bounds scan */
+    const void *rgb;            /* n records of {u16 r, u16 g, u16 b}; NULL = no colour (0,0,0)  */
+    uint64_t xyz_stride;
+    uint64_t cls_stride;
+    uint64_t rgb_stride;
+    uint64_t n;
+    uint64_t first_index;
+    double scale[3];
+    double offset[3];
+} pcq_columns;
+
+typedef enum pcq_predicate_kind { PCQ_PRED_BOUNDS = 0, PCQ_PRED_CLASS = 1 } pcq_predicate_kind;
+
+/* The predicate in the file's local integer space.
+ * BOUNDS: lmin <= (x,y,z) <= lmax, inclusive, compared as i64 (last.rs:122-135).  lmin/lmax are
+ *         what pcq_box_to_local produced; values outside the i32 range are legal.
+ * CLASS:  classification byte == cls, whole byte (last.rs:259-262). */
+typedef struct pcq_predicate {
+    int32_t kind;               /* pcq_predicate_kind */
+    uint8_t cls;
+    uint8_t _pad[3];
+    int64_t lmin[3];
+    int64_t lmax[3];
+} pcq_predicate;
+
+/* last.rs:98-109 / las.rs:88-99 — f64 query box -> local integer box, bug-for-bug (all three min
+ * components divide by scale[0]; `as i64` truncation/saturation).  PCQ_ERR_PANIC if min > max. */
+int pcq_box_to_local(const double bmin[3], const double bmax[3], const double scale[3],
+                     const double offset[3], int64_t lmin[3], int64_t lmax[3]);
+
+/* ---------------------------------------------------------------------------------------------
+ * Collectors — device-resident counterparts of query/src/collect_points.rs.
+ *   count  : CountCollector        (:72-98)   a u64 counter in HBM
+ *   buffer : BufferCollector       (:14-44)   matches appended in file order (stable compaction)
+ *   grid   : GridSampledCollector  (:100-127) SparseGrid (grid_sampling.rs:9-114) as an HBM hash
+ *            table; per cell the point closest to the cell centre, first seen wins ties.
+ * A collector may be fed by several scans (sequential mode feeds all files into one collector,
+ * main.rs:129-133); scans into one collector must be issued in file order.
+ * ------------------------------------------------------------------------------------------- */
+int pcq_collector_new_count(pcq_ctx *ctx, pcq_collector **out);
+/* Count collector whose counter lives in caller-owned device memory (8 bytes, zeroed by the
+ * caller) — lets the caller all-reduce it in place with RCCL (main.rs:164-180). */
+int pcq_collector_new_count_at(pcq_ctx *ctx, uint64_t *device_counter, pcq_collector **out);
+int pcq_collector_new_buffer(pcq_ctx *ctx, pcq_collector **out);
+int pcq_collector_new_grid(pcq_ctx *ctx, const double bmin[3], const double bmax[3],
+                           double cell_size, pcq_collector **out);
+int pcq_collector_free(pcq_collector *c);
+/* ResultCollector::point_count (synchronises the collector's stream). */
+int pcq_collector_point_count(pcq_collector *c, uint64_t *out);
+/* 1 when points()/points_ref() is Some (buffer, grid), 0 for the count collector. */
+int pcq_collector_has_points(const pcq_collector *c);
+/* ResultCollector::points: copies up to cap points to host memory, *out_n = number available
+ * (PCQ_ERR_CAPACITY when cap is too small; call with out=NULL, cap=0 to size).
+ * buffer: file order.  grid: hash-table slot order (the reference's HashMap order is unspecified);
+ * pcq_collector_grid_cells returns the cell keys in the same order. */
+int pcq_collector_points(pcq_collector *c, pcq_point *out, uint64_t cap, uint64_t *out_n);
+int pcq_collector_grid_cells(pcq_collector *c, uint64_t *out, uint64_t cap, uint64_t *out_n);
+/* SparseGrid::new results (grid_sampling.rs:24-44). */
+int pcq_collector_grid_params(const pcq_collector *c, uint64_t dims[3], uint64_t bits[3]);
+/* Resets the collector to its freshly constructed state (keeps allocations). */
+int pcq_collector_reset(pcq_collector *c);
+
+/* ---------------------------------------------------------------------------------------------
+ * The scan: evaluates `pred` over `cols` and pushes every match into `c`
+ * (the loop at last.rs:117-164 / :253-291 / las.rs:101-146 / :221-259).
+ *   pcq_scan_dev : column pointers are DEVICE memory; kernels are enqueued on `stream`
+ *                  (asynchronous: results are complete after the stream is synchronised or a
+ *                  collector accessor is called).
+ *   pcq_scan_host: column pointers are HOST memory (e.g. the mmapped file); the library streams
+ *                  them through pinned double buffers with hipMemcpyAsync overlapped with the
+ *                  kernels, in chunks; returns when the scan is complete.
+ * ------------------------------------------------------------------------------------------- */
+int pcq_scan_dev(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c,
+                 void *stream);
+int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred,
+                  pcq_collector *c);
+
+/* Count-only scan of many device-resident LAST files in ONE launch (files = independent units,
+ * main.rs:153-161): segment i is scanned with preds[i]; the total is ADDED to *device_total. */
+int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *preds,
+                             size_t nsegments, uint64_t *device_total, void *stream);
+
+/* Device memory helpers for callers that keep column blocks resident in HBM. */
+int pcq_device_alloc(pcq_ctx *ctx, uint64_t bytes, void **out);
+int pcq_device_free(pcq_ctx *ctx, void *p);
+int pcq_copy_to_device(pcq_ctx *ctx, void *dst_device, const void *src_host, uint64_t bytes);
+int pcq_copy_to_host(pcq_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
+int pcq_device_memset(pcq_ctx *ctx, void *dst_device, int value, uint64_t bytes, void *stream);
+
+/* Tuning knob for experiments: selects the bounds-count kernel variant (0 = default). */
+int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCQ_H */
