@@ -327,17 +327,55 @@ __global__ __launch_bounds__(BLOCK) void k_grid_rehash(DevGridTable src, DevGrid
     }
 }
 
-// Drain: compact used slots (slot order) into packed 31-byte points + keys.
-__global__ __launch_bounds__(BLOCK) void k_grid_drain(DevGridTable t, uint8_t *__restrict__ out31, uint64_t *__restrict__ keys_out,
-                                                      uint64_t *__restrict__ cursor) {
-    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t h = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; h < t.cap; h += nthreads) {
-        if (t.keys[h] == PCQ_EMPTY_KEY || !(t.flags[h] & F_HAS_POINT)) continue;
-        const uint64_t pos = atomicAdd((unsigned long long *)cursor, 1ull);
-        const uint8_t *s = t.pts + h * 32;
-        uint8_t *d = out31 + pos * 31;
-        for (int k = 0; k < 31; k++) d[k] = s[k];
-        keys_out[pos] = t.keys[h];
+// Drain: deterministic slot-order compaction of the used slots into packed 31-byte points + keys
+// (tile counts -> exclusive scan -> emit; same ballot-rank scheme as the buffer collector).
+__global__ __launch_bounds__(BLOCK) void k_drain_tile_counts(DevGridTable t, uint64_t *__restrict__ counts) {
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    uint32_t cnt = 0;
+    for (int j = 0; j < ITEMS; j++) {
+        const uint64_t h = base + (uint64_t)j * BLOCK + threadIdx.x;
+        const bool used = h < t.cap && t.keys[h] != PCQ_EMPTY_KEY && (t.flags[h] & F_HAS_POINT);
+        cnt += (uint32_t)__popcll(__ballot(used));
+    }
+    __shared__ uint32_t s_w[WAVES];
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tt = 0;
+        for (int i = 0; i < WAVES; i++) tt += s_w[i];
+        counts[blockIdx.x] = tt;
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_drain_emit(DevGridTable t, const uint64_t *__restrict__ offsets,
+                                                      uint8_t *__restrict__ out31, uint64_t *__restrict__ keys_out) {
+    __shared__ uint32_t s_w[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t base = (uint64_t)blockIdx.x * TILE;
+    uint64_t run = offsets[blockIdx.x];
+    for (int j = 0; j < ITEMS; j++) {
+        const uint64_t h = base + (uint64_t)j * BLOCK + threadIdx.x;
+        const bool used = h < t.cap && t.keys[h] != PCQ_EMPTY_KEY && (t.flags[h] & F_HAS_POINT);
+        const uint64_t mask = __ballot(used);
+        if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+        for (int w = 0; w < WAVES; w++) {
+            const uint32_t v = s_w[w];
+            before += w < wave ? v : 0;
+            all += v;
+        }
+        if (used) {
+            const uint64_t pos = run + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (out31) {
+                const uint8_t *sp = t.pts + h * 32;
+                uint8_t *dp = out31 + pos * 31;
+                for (int k = 0; k < 31; k++) dp[k] = sp[k];
+            }
+            if (keys_out) keys_out[pos] = t.keys[h];
+        }
+        run += all;
+        __syncthreads();
     }
 }
 
@@ -474,17 +512,20 @@ int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_
                                  (unsigned long long)cap);
     uint8_t *d_out = nullptr;
     uint64_t *d_keys = nullptr;
-    PCQ_HIP(hipMalloc((void **)&d_out, n * 31));
-    PCQ_HIP(hipMalloc((void **)&d_keys, n * 8));
-    PCQ_HIP(hipMemsetAsync(ctx->d_scalars, 0, 8, s));
-    hipLaunchKernelGGL(k_grid_drain, dim3(grid_blocks(ctx, c->table.cap)), dim3(BLOCK), 0, s, c->table, d_out, d_keys,
-                       ctx->d_scalars);
+    const uint64_t nblocks = (c->table.cap + TILE - 1) / TILE;
+    int rc = pcq_ensure_partials(ctx, (size_t)nblocks);
+    if (rc) return rc;
+    if (out) PCQ_HIP(hipMalloc((void **)&d_out, n * 31));
+    if (keys_out) PCQ_HIP(hipMalloc((void **)&d_keys, n * 8));
+    hipLaunchKernelGGL(k_drain_tile_counts, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, c->table, ctx->d_partials);
+    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, ctx->d_partials, nblocks, ctx->d_scalars);
+    hipLaunchKernelGGL(k_drain_emit, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, c->table, ctx->d_partials, d_out, d_keys);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && out) e = hipMemcpyAsync(out, d_out, n * 31, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && keys_out) e = hipMemcpyAsync(keys_out, d_keys, n * 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    (void)hipFree(d_out);
-    (void)hipFree(d_keys);
+    if (d_out) (void)hipFree(d_out);
+    if (d_keys) (void)hipFree(d_keys);
     if (e != hipSuccess) return pcq_fail(PCQ_ERR_HIP, "grid drain failed: %s", hipGetErrorString(e));
     return PCQ_OK;
 }

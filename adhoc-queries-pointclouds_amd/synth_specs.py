@@ -112,3 +112,28 @@ def dataset(name: str, points_per_file: Optional[int] = None, files: Optional[in
     if name == "ca13":
         return synth_ca13(points_per_file, files or 16)
     raise KeyError(name)
+
+
+def header_fields(spec: SynthSpec) -> dict:
+    """The LAS header fields the query path reads (number of points, scale, offset, min/max bounds)
+    for a synthetic file, computed exactly as the generator writes them: extreme integer
+    coordinates mapped with `(i as f64 * scale) + offset` (last.rs:156-160).  Python floats are IEEE
+    doubles, so these equal the bytes in the generated header (tests/test_synth.py)."""
+    mn, mx = [], []
+    for a in range(3):
+        lo = spec.lo[a]
+        hi = spec.lo[a] + spec.span[a] - 1
+        if a == 2 and spec.zo_prob16 > 0:
+            lo = min(lo, spec.zo_lo)
+            hi = max(hi, spec.zo_lo + spec.zo_span - 1)
+        a0 = (float(lo) * spec.scale[a]) + spec.offset[a]
+        a1 = (float(hi) * spec.scale[a]) + spec.offset[a]
+        mn.append(min(a0, a1))
+        mx.append(max(a0, a1))
+    return {"n": int(spec.n), "format": int(spec.format), "scale": list(spec.scale), "offset": list(spec.offset),
+            "min": mn, "max": mx}
+
+
+def aabb_intersects(amin, amax, bmin, bmax) -> bool:
+    """pasture AABB::intersects (inclusive) — the file-level early-out of last.rs:92-94."""
+    return all(amin[a] <= bmax[a] and amax[a] >= bmin[a] for a in range(3))

@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""bench.py — the north-star measurement: ca13 XL bounds query (count), 1/2/4/8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (config.workload): synthetic ca13 — 16 LAST files x 163,000,000 points (2,608 Mpoints,
+31.3 GB of positions), SURVEY.md §8(d) — query `--bounds` ca13-XL (run_query_experiments.rs:141-144),
+count only.  The positions blocks are generated directly in HBM by pcq_synth_fill_dev (bit-identical
+to the host generator) and are resident before the timed region starts.
+
+A step = one query over the whole dataset: per file the header early-out (last.rs:92-94) and the
+f64 -> local integer box (last.rs:98-109) on the host, one batched bounds_count launch over this
+rank's files, the global sum of the match counts (main.rs:164-180; an RCCL all-reduce when N > 1) and
+the 8-byte result read back to the host.  Files are the independent units (main.rs:153-161): with N
+ranks, file i belongs to rank i % N; the dataset is fixed, so this is strong scaling.
+
+One JSON line is printed by rank 0 (see the contract in the task statement).  `roofline` is computed
+from HIP events recorded around every launch of the dominant kernel inside the timed region, on the
+stream the kernel runs on; `cpu_baseline` times the oracle (the C restatement of the reference's
+`--optimized --parallel` loop; "port": the reference itself is Rust and cannot be built here) on a
+bounded sample of the same synthetic files on the host cores.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (device memory, streams, torch.distributed — plumbing only)
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+BYTES_PER_POINT = 12   # bounds count reads N x {i32 x,y,z}
+
+
+def cpu_baseline(specs_mod, bmin, bmax, sample_points_per_file, nfiles):
+    """Oracle on the host cores: one thread per file (rayon par_iter, main.rs:153-161)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle  # the checker / CPU baseline, never the product path
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "liboracle.so"], check=True, capture_output=True)
+    oracle = _oracle.Oracle()
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    threads = min(nfiles, cores)
+    sample = specs_mod.synth_ca13(points_per_file=sample_points_per_file, files=nfiles)
+    images = [oracle.synth_image(s, transposed=True, threads=cores) for s in sample]
+    total_pts = sum(int(s.n) for s in sample)
+    times, count = [], None
+    for _ in range(5):  # run_query_experiments.rs:412 — 5 runs, median
+        t0 = time.perf_counter()
+        count = oracle.count_files_parallel(images, 0, bmin, bmax, 0, threads)
+        times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": total_pts / med / 1e6, "unit": "Mpoints/s", "cores": threads, "kind": "port",
+            "sample": f"oracle (C restatement of last.rs:46-166 + CountCollector), {nfiles} synthetic ca13 LAST files x "
+                      f"{sample_points_per_file} points in host memory, warm, one thread per file, median of 5; "
+                      f"matches {count}/{total_pts}; host has {cores} cores"}, images, sample, count
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--points-per-file", type=int, default=163_000_000)
+    ap.add_argument("--files", type=int, default=16)
+    ap.add_argument("--query", type=str, default="ca13_XL")
+    ap.add_argument("--cpu-sample-points", type=int, default=20_000_000, help="points per file of the CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-file-launch", action="store_true", help="one launch per file instead of one batched launch")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+        args.gpus = world
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = importlib.import_module("adhoc-queries-pointclouds_amd")
+    binding = importlib.import_module("adhoc-queries-pointclouds_amd.binding")
+    specs_mod = importlib.import_module("adhoc-queries-pointclouds_amd.synth_specs")
+
+    all_specs = specs_mod.synth_ca13(points_per_file=args.points_per_file, files=args.files)
+    mine = [i for i in range(len(all_specs)) if i % world == rank]  # file i -> rank i % N
+    bmin, bmax = specs_mod.box(args.query)
+
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    ctx = pkg.Context(local_rank)
+    info = ctx.device_info()
+
+    # ---- dataset: positions blocks resident in HBM (torch owns the memory) -----------------------
+    blocks, headers = [], []
+    for i in mine:
+        s = all_specs[i]
+        t = torch.empty(int(s.n) * BYTES_PER_POINT, dtype=torch.uint8, device=dev)
+        ctx.synth_fill(s, 0, int(s.n), t.data_ptr(), None, stream)
+        blocks.append(t)
+        headers.append(specs_mod.header_fields(s))
+    torch.cuda.synchronize()
+
+    total = torch.zeros(2, dtype=torch.int64, device=dev)  # [0] = match count of the query
+    local_points = sum(h["n"] for h in headers)
+    global_points = sum(int(s.n) for s in all_specs)
+
+    def query_step(record=None):
+        """One `--bounds XL --optimized --parallel` count query over the dataset."""
+        total.zero_()
+        cols, preds, scanned = [], [], 0
+        for t, h in zip(blocks, headers):
+            if not specs_mod.aabb_intersects(h["min"], h["max"], bmin, bmax):  # last.rs:92-94
+                continue
+            lmin, lmax = pkg.box_to_local(bmin, bmax, h["scale"], h["offset"])  # last.rs:98-109
+            cols.append(binding.make_columns(xyz=t.data_ptr(), n=h["n"], scale=h["scale"], offset=h["offset"]))
+            preds.append(pkg.Predicate.bounds(lmin, lmax))
+            scanned += h["n"]
+        if cols:
+            if args.per_file_launch:
+                cc = ctx.count_collector(device_counter=total.data_ptr())
+                for c, p in zip(cols, preds):
+                    if record is not None:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(tstream)
+                    ctx.scan_dev(c, p, cc, stream)
+                    if record is not None:
+                        e1.record(tstream)
+                        record.append((e0, e1, c.n))
+                cc.free()
+            else:
+                if record is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(tstream)
+                ctx.scan_dev_count_batch(cols, preds, total.data_ptr(), stream)
+                if record is not None:
+                    e1.record(tstream)
+                    record.append((e0, e1, scanned))
+        if world > 1:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)  # main.rs:164-180 across GPUs: one RCCL all-reduce
+        return int(total[0].item()), scanned  # the query's answer reaches the host every step
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        matches, _ = query_step()
+    barrier()
+    events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        matches, scanned_local = query_step(events)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te.item())
+        sc = torch.tensor([scanned_local], dtype=torch.int64, device=dev)
+        dist.all_reduce(sc, op=dist.ReduceOp.SUM)
+        scanned_global = int(sc.item())
+    else:
+        scanned_global = scanned_local
+
+    # kernel-only roofline (this rank's launches; HIP events on the launch stream)
+    launch_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
+    launch_pts = [n for _, _, n in events]
+    avg_ms = sum(launch_ms) / max(1, len(launch_ms))
+    alg_bytes = BYTES_PER_POINT * (sum(launch_pts) / max(1, len(launch_pts)))
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+
+    result = None
+    if rank == 0:
+        traffic = None
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc_path):
+            try:
+                pmc = json.load(open(pmc_path))
+                if pmc.get("points_per_launch") == (sum(launch_pts) // max(1, len(launch_pts))):
+                    traffic = pmc.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "Mpoints/s filtered + achieved HBM GB/s, ca13 XL bounds query, 1/2/4/8 GPUs",
+            "value": scanned_global * args.steps / elapsed / 1e6,
+            "unit": "Mpoints/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "i32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"synth-ca13: {args.files} LAST files x {args.points_per_file} points "
+                            f"({global_points / 1e6:.0f} Mpoints), query --bounds {args.query} count-only, positions resident in HBM",
+                "files": args.files,
+                "points": global_points,
+                "query": args.query,
+                "sharding": "file i -> rank i % N, one RCCL all-reduce(sum, u64) per query" if world > 1 else "single GPU",
+                "launch": "per-file" if args.per_file_launch else "one batched launch per query",
+                "device": info["name"] + " " + info["gcn_arch"],
+            },
+            "matches": matches,
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic,
+                "kernel": "k_bounds_count_xyz12" if args.per_file_launch else "k_bounds_count_batch",
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": avg_ms,
+                "launches_timed": len(launch_ms),
+            },
+        }
+
+    # CPU baseline: rank 0 at N=1 only, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        base, images, sample, cpu_count = cpu_baseline(specs_mod, bmin, bmax, args.cpu_sample_points, args.files)
+        result["cpu_baseline"] = base
+        # the same sample through the GPU path must give the same count (bit-exact parity on the bench inputs)
+        gpu_total = 0
+        for s, im in zip(sample, images):
+            h = specs_mod.header_fields(s)
+            if not specs_mod.aabb_intersects(h["min"], h["max"], bmin, bmax):
+                continue
+            lmin, lmax = pkg.box_to_local(bmin, bmax, h["scale"], h["offset"])
+            cols = binding.make_columns(xyz=im.ctypes.data + 227, n=h["n"], scale=h["scale"], offset=h["offset"])
+            cc = ctx.count_collector()
+            ctx.scan_host(cols, pkg.Predicate.bounds(lmin, lmax), cc)
+            gpu_total += cc.point_count()
+            cc.free()
+        result["cpu_baseline"]["gpu_count_on_sample"] = gpu_total
+        result["cpu_baseline"]["parity_on_sample"] = bool(gpu_total == cpu_count)
+        if gpu_total != cpu_count:
+            raise SystemExit(f"PARITY FAILURE on the CPU-baseline sample: gpu {gpu_total} != oracle {cpu_count}")
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

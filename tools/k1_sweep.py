@@ -29,7 +29,10 @@ def main():
     n = args.points
     dev = torch.device("cuda:0")
     torch.cuda.set_device(dev)
-    stream = torch.cuda.current_stream().cuda_stream
+    tstream = torch.cuda.Stream()  # a real (non-null) stream: handle 0 would mean "the context's stream"
+    torch.cuda.set_stream(tstream)
+    stream = tstream.cuda_stream
+    assert stream != 0
     with pkg.Context(0) as ctx:
         print(json.dumps(ctx.device_info()))
         spec = specs.synth_ca13(points_per_file=n, files=1)[0]
