@@ -75,7 +75,7 @@ class DeviceInfo(C.Structure):
 
 
 class SynthSpec(C.Structure):
-    """Layout shared by include/pcq_synth.h (pcq_synth_spec) and oracle/pcq_oracle.h (pcqo_synth_spec)."""
+    """include/pcq_synth.h: pcq_synth_spec (the test-side host generator uses the same layout)."""
     _fields_ = [("seed", C.c_uint64), ("n", C.c_uint64), ("format", C.c_uint32), ("n_classes", C.c_uint32),
                 ("scale", C.c_double * 3), ("offset", C.c_double * 3), ("lo", C.c_int32 * 3), ("span", C.c_uint32 * 3),
                 ("zo_prob16", C.c_uint32), ("zo_lo", C.c_int32), ("zo_span", C.c_uint32), ("cls_cum16", C.c_uint32 * 8),

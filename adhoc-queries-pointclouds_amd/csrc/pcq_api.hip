@@ -7,6 +7,7 @@
 #include "pcq_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <new>
 
 // ---------------------------------------------------------------------------------------------
@@ -68,6 +69,15 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
     if (rc) {
         pcq_shutdown(ctx);
         return rc;
+    }
+    // tuning / test knobs (same meaning as pcq_set_option)
+    if (const char *e = getenv("PCQ_CHUNK_POINTS")) {
+        const long long v = atoll(e);
+        if (v >= 4) ctx->chunk_points = (uint64_t)v;
+    }
+    if (const char *e = getenv("PCQ_K1_VARIANT")) {
+        const int v = atoi(e);
+        if (v >= 0 && v <= 3) ctx->k1_variant = v;
     }
     *out_ctx = ctx;
     return PCQ_OK;
@@ -142,7 +152,7 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
         if (value < 1 || value > 16) return pcq_fail(PCQ_ERR_ARG, "blocks_per_cu must be 1..16");
         ctx->grid_blocks_per_cu = (int)value;
     } else if (!strcmp(key, "chunk_points")) {
-        if (value < 1024) return pcq_fail(PCQ_ERR_ARG, "chunk_points must be >= 1024");
+        if (value < 4) return pcq_fail(PCQ_ERR_ARG, "chunk_points must be >= 4");
         ctx->chunk_points = (uint64_t)value;
     } else {
         return pcq_fail(PCQ_ERR_ARG, "unknown option '%s'", key);

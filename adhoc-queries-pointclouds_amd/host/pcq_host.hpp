@@ -1,0 +1,221 @@
+// pcq_host.hpp — C++ host layer above the C ABI of include/pcq.h.
+//
+// The reference's host code is Rust; no Rust toolchain exists in the build image, so the host side
+// is written in C++ and mirrors the reference's operator interface for this path — same names,
+// argument meaning and error behaviour — so that tests read like tests of the reference:
+//
+//   readers::Point                                   readers/src/lib.rs:10-19
+//   trait ResultCollector + Count/Buffer/GridSampled query/src/collect_points.rs:7-127
+//   trait Searcher, BoundsSearcher, ClassSearcher,
+//   enum SearchImplementation                        query/src/search/searcher.rs:19-152
+//   search_{last,las}_file_by_{bounds,classification}_optimized
+//                                                    query/src/search/last.rs:46-166, 213-293
+//                                                    query/src/search/las.rs:52-148, 192-261
+//   trait PointDumper, IgnoreDumper, FileDumper      query/src/dump_points.rs:13-121
+//   get_all_input_files, parse_aabb, get_total_bounds, run_search_sequential,
+//   run_search_parallel, is_valid_file               query/src/main.rs:29-189
+//
+// Everything that touches point data goes through libpcq.so (pcq_scan_host & co.); this layer only
+// opens/mmaps files, parses LAS headers, converts the query box and drains collectors.  There is no
+// CPU implementation of the scans here.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <optional>
+#include <string>
+#include <vector>
+
+#include "pcq.h"
+
+namespace pcq {
+
+// anyhow::Result<()> stand-in.  `panic` marks conditions where the reference panics (exit 101).
+struct Status {
+    int code = PCQ_OK;
+    std::string message;
+    bool panic = false;
+    bool ok() const { return code == PCQ_OK; }
+    static Status Ok() { return {}; }
+    static Status Err(int code, std::string msg) { return {code, std::move(msg), false}; }
+    static Status Panic(std::string msg) { return {PCQ_ERR_PANIC, std::move(msg), true}; }
+    static Status FromLib(int code);  // picks up pcq_last_error()
+};
+
+using Point = pcq_point;  // readers::Point, 31 bytes packed
+
+// pasture_core::math::AABB<f64>
+struct AABB {
+    double min[3];
+    double max[3];
+    // AABB::from_min_max panics when min > max on an axis [recalled, pasture-core 0.1.0]
+    static Status from_min_max(const double mn[3], const double mx[3], AABB *out);
+    static AABB from_min_max_unchecked(const double mn[3], const double mx[3]);
+    bool intersects(const AABB &o) const;           // inclusive
+    static AABB union_of(const AABB &a, const AABB &b);
+};
+
+// las::raw::Header fields consumed by the path (layout: query/src/las.rs:7-40).
+struct LasHeader {
+    uint8_t version_major = 0, version_minor = 0;
+    uint16_t header_size = 0;
+    uint32_t offset_to_point_data = 0;
+    uint8_t point_data_record_format = 0;  // after optional masking
+    uint16_t point_data_record_length = 0;
+    uint64_t number_of_points = 0;         // Header::number_of_points()
+    double scale[3] = {0, 0, 0}, offset[3] = {0, 0, 0};
+    AABB bounds{};                          // Header::bounds()
+};
+// raw::Header::read_from + Header::from_raw; mask_format applies `&= 0b1111` first (last.rs:222).
+Status parse_las_header(const uint8_t *data, size_t len, bool mask_format, LasHeader *out);
+
+// Read-only mmap of a whole file (last.rs:27-34).
+class MappedFile {
+public:
+    MappedFile() = default;
+    ~MappedFile();
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+    Status open(const std::string &path);
+    const uint8_t *data() const { return data_; }
+    size_t size() const { return size_; }
+
+private:
+    const uint8_t *data_ = nullptr;
+    size_t size_ = 0;
+};
+
+// One GPU context per (thread, device); created on first use, destroyed with the thread.
+Status thread_context(int device, pcq_ctx **out);
+
+// ---- collect_points.rs ------------------------------------------------------------------------
+// The per-match `collect_one(Point)` callback of the reference does not exist here: matches are
+// pushed into the device-resident collector by the scan kernels (a per-match callback across the
+// boundary is the CPU bottleneck this path removes).  The drain side is identical.
+class ResultCollector {
+public:
+    virtual ~ResultCollector();
+    // ResultCollector::points  (None for the count collector)
+    virtual std::optional<std::vector<Point>> points();
+    // ResultCollector::points_ref (Some only for the buffer collector)
+    virtual const std::vector<Point> *points_ref();
+    virtual Status point_count(size_t *out);
+    pcq_collector *handle() const { return handle_; }
+    pcq_ctx *context() const { return ctx_; }
+    uint64_t next_index = 0;  // file-order index of the next scanned point (first-seen-wins bookkeeping)
+
+protected:
+    pcq_ctx *ctx_ = nullptr;
+    pcq_collector *handle_ = nullptr;
+    std::vector<Point> cache_;
+    bool cached_ = false;
+    Status fetch();
+};
+
+class CountCollector : public ResultCollector {  // collect_points.rs:72-98
+public:
+    static Status create(pcq_ctx *ctx, std::unique_ptr<ResultCollector> *out);
+};
+class BufferCollector : public ResultCollector {  // collect_points.rs:14-44
+public:
+    static Status create(pcq_ctx *ctx, std::unique_ptr<ResultCollector> *out);
+    std::optional<std::vector<Point>> points() override;
+    const std::vector<Point> *points_ref() override;
+};
+class GridSampledCollector : public ResultCollector {  // collect_points.rs:100-127
+public:
+    static Status create(pcq_ctx *ctx, const AABB &bounds, double cell_size, std::unique_ptr<ResultCollector> *out);
+    std::optional<std::vector<Point>> points() override;
+};
+
+// ---- search/last.rs, search/las.rs ---------------------------------------------------------------
+struct SearchLog {  // side output the reference prints from inside the scans
+    int las_record_size = -1;  // las.rs:73 `println!("Point record size: {}")`
+};
+Status search_last_file_by_bounds_optimized(const std::string &path, const AABB &bounds, ResultCollector &rc);
+Status search_last_file_by_classification_optimized(const std::string &path, uint8_t cls, ResultCollector &rc);
+Status search_las_file_by_bounds_optimized(const std::string &path, const AABB &bounds, ResultCollector &rc, SearchLog *log);
+Status search_las_file_by_classification_optimized(const std::string &path, uint8_t cls, ResultCollector &rc);
+
+// ---- search/searcher.rs ----------------------------------------------------------------------------
+enum class SearchImplementation { Regular, Optimized };
+
+class Searcher {
+public:
+    virtual ~Searcher() = default;
+    virtual Status search_file(const std::string &path, SearchImplementation impl, ResultCollector &collector,
+                               SearchLog *log = nullptr) const = 0;
+};
+class BoundsSearcher : public Searcher {
+public:
+    explicit BoundsSearcher(const AABB &bounds) : bounds_(bounds) {}
+    Status search_file(const std::string &path, SearchImplementation impl, ResultCollector &collector,
+                       SearchLog *log = nullptr) const override;
+
+private:
+    AABB bounds_;
+};
+class ClassSearcher : public Searcher {
+public:
+    explicit ClassSearcher(uint8_t cls) : class_(cls) {}
+    Status search_file(const std::string &path, SearchImplementation impl, ResultCollector &collector,
+                       SearchLog *log = nullptr) const override;
+
+private:
+    uint8_t class_;
+};
+
+// ---- dump_points.rs ----------------------------------------------------------------------------------
+class PointDumper {
+public:
+    virtual ~PointDumper() = default;
+    virtual Status dump_points(const Point *points, size_t n) = 0;
+    virtual size_t num_dumped_points() const = 0;
+};
+class IgnoreDumper : public PointDumper {
+public:
+    Status dump_points(const Point *, size_t n) override {
+        dumped_ += n;
+        return Status::Ok();
+    }
+    size_t num_dumped_points() const override { return dumped_; }
+
+private:
+    size_t dumped_ = 0;
+};
+class FileDumper : public PointDumper {
+public:
+    static Status create(const std::string &root_dir, std::unique_ptr<PointDumper> *out);
+    Status dump_points(const Point *points, size_t n) override;
+    size_t num_dumped_points() const override { return dumped_; }
+
+private:
+    std::string root_;
+    size_t file_index_ = 0, dumped_ = 0;
+};
+
+// ---- main.rs -----------------------------------------------------------------------------------------
+Status get_all_input_files(const std::string &input, std::vector<std::string> *out);
+bool is_valid_file(const std::string &path);
+Status parse_aabb(const std::string &s, AABB *out);
+Status get_total_bounds(const std::vector<std::string> &files, AABB *out);
+
+// Creates the collector for one worker: Result<Box<dyn ResultCollector>> of main.rs:24.
+using CollectorFactoryFn = std::function<Status(pcq_ctx *, std::unique_ptr<ResultCollector> *)>;
+
+struct RunOptions {
+    std::vector<int> devices = {0};  // GPUs to use; files are the independent units (main.rs:153-161)
+    int threads_per_device = 2;      // host threads feeding each GPU in --parallel mode
+};
+// stdout lines go through `print` (so tests can capture them).
+using PrintFn = std::function<void(const std::string &)>;
+Status run_search_sequential(const std::vector<std::string> &files, const Searcher &searcher, SearchImplementation impl,
+                             const CollectorFactoryFn &factory, PointDumper &dumper, const RunOptions &opt, const PrintFn &print);
+Status run_search_parallel(const std::vector<std::string> &files, const Searcher &searcher, SearchImplementation impl,
+                           const CollectorFactoryFn &factory, PointDumper &dumper, const RunOptions &opt, const PrintFn &print);
+
+// The whole CLI (main.rs:191-319): returns the process exit code; stdout/stderr text via callbacks.
+int query_main(int argc, const char *const *argv, const PrintFn &out, const PrintFn &err);
+
+}  // namespace pcq

@@ -101,9 +101,10 @@ def main():
     pkg = importlib.import_module("adhoc-queries-pointclouds_amd")
     binding = importlib.import_module("adhoc-queries-pointclouds_amd.binding")
     specs_mod = importlib.import_module("adhoc-queries-pointclouds_amd.synth_specs")
+    sharding = importlib.import_module("adhoc-queries-pointclouds_amd.sharding")
 
     all_specs = specs_mod.synth_ca13(points_per_file=args.points_per_file, files=args.files)
-    mine = [i for i in range(len(all_specs)) if i % world == rank]  # file i -> rank i % N
+    mine = sharding.assign_files(len(all_specs), world, rank)  # file i -> rank i % N
     bmin, bmax = specs_mod.box(args.query)
 
     tstream = torch.cuda.Stream(device=dev)
@@ -157,8 +158,7 @@ def main():
                 if record is not None:
                     e1.record(tstream)
                     record.append((e0, e1, scanned))
-        if world > 1:
-            dist.all_reduce(total, op=dist.ReduceOp.SUM)  # main.rs:164-180 across GPUs: one RCCL all-reduce
+        sharding.global_count(total, world)  # main.rs:164-180 across GPUs: one RCCL all-reduce when N > 1
         return int(total[0].item()), scanned  # the query's answer reaches the host every step
 
     def barrier():

@@ -1,0 +1,72 @@
+/*
+ * pcq_query.h — C view of the C++ host layer (libpcq_query.so), so that tests and other languages
+ * can call the file-level operators of the reference by name:
+ *
+ *   Searcher::search_file for BoundsSearcher / ClassSearcher     query/src/search/searcher.rs:24-152
+ *   CountCollector / BufferCollector / GridSampledCollector      query/src/collect_points.rs:14-127
+ *   parse_aabb, get_all_input_files, is_valid_file, get_total_bounds   query/src/main.rs:29-120, 185-189
+ *
+ * libpcq_query.so contains NO scan code: every function below that touches point data calls the
+ * HIP library through include/pcq.h (pcq_scan_host).  Functions return 0 or a negative pcq_status;
+ * pcq_query_last_error() returns the message of the last failure on the calling thread and
+ * pcq_query_last_was_panic() tells whether the reference would have panicked (exit code 101).
+ */
+#ifndef PCQ_QUERY_H
+#define PCQ_QUERY_H
+
+#include "pcq.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pcq_host_collector pcq_host_collector;
+
+const char *pcq_query_last_error(void);
+int pcq_query_last_was_panic(void);
+
+/* raw::Header::read_from + Header::from_raw on a memory image (no GPU needed). */
+typedef struct pcq_las_header_info {
+    uint8_t version_major, version_minor;
+    uint8_t point_data_record_format;
+    uint8_t _pad;
+    uint16_t header_size;
+    uint16_t point_data_record_length;
+    uint32_t offset_to_point_data;
+    uint32_t _pad2;
+    uint64_t number_of_points;
+    double scale[3], offset[3], min[3], max[3];
+} pcq_las_header_info;
+int pcq_query_parse_las_header(const uint8_t *data, size_t len, int mask_format, pcq_las_header_info *out);
+
+/* main.rs:59-92 (PCQ_ERR_PANIC when min > max), :185-189, :94-120 — no GPU needed. */
+int pcq_query_parse_aabb(const char *s, double bmin[3], double bmax[3]);
+int pcq_query_is_valid_file(const char *path);
+int pcq_query_get_total_bounds(const char *const *files, size_t nfiles, double bmin[3], double bmax[3]);
+
+/* Collectors on the calling thread's context for `device`. */
+int pcq_query_collector_new_count(int device, pcq_host_collector **out);
+int pcq_query_collector_new_buffer(int device, pcq_host_collector **out);
+int pcq_query_collector_new_grid(int device, const double bmin[3], const double bmax[3], double cell_size,
+                                 pcq_host_collector **out);
+int pcq_query_collector_free(pcq_host_collector *c);
+int pcq_query_collector_point_count(pcq_host_collector *c, uint64_t *out);
+/* 0: points() is None; 1: Some.  Copies up to cap points (buffer: file order). */
+int pcq_query_collector_has_points(pcq_host_collector *c);
+int pcq_query_collector_points(pcq_host_collector *c, pcq_point *out, uint64_t cap, uint64_t *out_n);
+int pcq_query_collector_grid_cells(pcq_host_collector *c, uint64_t *out, uint64_t cap, uint64_t *out_n);
+
+/* BoundsSearcher::search_file / ClassSearcher::search_file with SearchImplementation
+ * (0 = Regular, 1 = Optimized).  *las_record_size receives the value the reference prints with
+ * `Point record size: {}` (las.rs:73) or is left at -1. */
+int pcq_query_search_file_bounds(const char *path, const double bmin[3], const double bmax[3], int optimized,
+                                 pcq_host_collector *c, int *las_record_size);
+int pcq_query_search_file_class(const char *path, uint8_t cls, int optimized, pcq_host_collector *c);
+
+/* The whole CLI in-process (main.rs:191-319); returns the exit code. */
+int pcq_query_main(int argc, const char *const *argv);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

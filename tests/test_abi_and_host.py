@@ -1,0 +1,205 @@
+"""CPU-only checks of the product side: the C-ABI libraries load and export every symbol the headers
+declare, the host logic (header parse, box conversion, argument handling) matches the oracle and the
+golden vectors, and — without a GPU — the product fails loudly instead of falling back to a CPU path.
+No compute call is made here.
+"""
+import ctypes as C
+import importlib
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+PKG = os.path.join(ROOT, "adhoc-queries-pointclouds_amd")
+G = json.load(open(os.path.join(HERE, "golden", "expected.json")))
+
+pkg = importlib.import_module("adhoc-queries-pointclouds_amd")
+
+
+def fhex(s):
+    return float("nan") if s == "nan" else float.fromhex(s)
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def test_libpcq_exports_every_declared_symbol():
+    declared = pkg.declared_symbols(["pcq.h", "pcq_synth.h"])
+    assert len(declared) >= 29
+    exported = pkg.exported_symbols(pkg.lib_path())
+    assert [s for s in declared if s not in exported] == []
+    lib = pkg.load_library()  # dlopen resolves libamdhip64 etc.
+    assert lib.pcq_abi_version() == 1
+
+
+def test_libpcq_query_exports_every_declared_symbol():
+    declared = pkg.declared_symbols(["pcq_query.h"])
+    declared = [s for s in declared if s.startswith("pcq_query")]
+    assert len(declared) >= 15
+    path = os.path.join(PKG, "libpcq_query.so")
+    exported = pkg.exported_symbols(path)
+    assert [s for s in declared if s not in exported] == []
+    C.CDLL(path)
+
+
+def test_no_oracle_in_the_product_binaries():
+    """The product must not link, load or embed the oracle."""
+    for name in ("libpcq.so", "libpcq_query.so", os.path.join("host", "query")):
+        path = os.path.join(PKG, name)
+        needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+        assert "liboracle" not in needed
+        syms = subprocess.run(["nm", "-D", path], capture_output=True, text=True).stdout
+        assert "pcqo_" not in syms
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".cpp", ".hip", ".h", ".hpp", ".py")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "pcq_oracle.h" not in text and "liboracle" not in text, f
+
+
+def test_box_to_local_matches_golden_and_oracle(oracle):
+    for c in G["box_to_local"]:
+        args = ([fhex(v) for v in c["bmin"]], [fhex(v) for v in c["bmax"]], [fhex(v) for v in c["scale"]],
+                [fhex(v) for v in c["offset"]])
+        if c["panic"]:
+            with pytest.raises(pkg.PcqError) as e:
+                pkg.box_to_local(*args)
+            assert e.value.code == -7  # PCQ_ERR_PANIC
+        else:
+            assert pkg.box_to_local(*args) == (c["lmin"], c["lmax"])
+    rng = np.random.default_rng(7)
+    for _ in range(2000):
+        lo = rng.uniform(-1e6, 1e6, 3)
+        hi = lo + rng.uniform(0, 1e5, 3)
+        sc = 10.0 ** rng.integers(-4, 1, 3)
+        off = rng.uniform(-1e5, 1e5, 3)
+        try:
+            want = oracle.box_to_local(lo, hi, sc, off)
+        except Exception:
+            with pytest.raises(pkg.PcqError):
+                pkg.box_to_local(lo, hi, sc, off)
+            continue
+        assert pkg.box_to_local(lo, hi, sc, off) == want
+
+
+class HeaderInfo(C.Structure):
+    _fields_ = [("version_major", C.c_uint8), ("version_minor", C.c_uint8), ("point_data_record_format", C.c_uint8),
+                ("_pad", C.c_uint8), ("header_size", C.c_uint16), ("point_data_record_length", C.c_uint16),
+                ("offset_to_point_data", C.c_uint32), ("_pad2", C.c_uint32), ("number_of_points", C.c_uint64),
+                ("scale", C.c_double * 3), ("offset", C.c_double * 3), ("min", C.c_double * 3), ("max", C.c_double * 3)]
+
+
+@pytest.fixture(scope="module")
+def qlib():
+    lib = C.CDLL(os.path.join(PKG, "libpcq_query.so"))
+    lib.pcq_query_last_error.restype = C.c_char_p
+    lib.pcq_query_parse_las_header.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(HeaderInfo)]
+    lib.pcq_query_parse_aabb.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.pcq_query_is_valid_file.argtypes = [C.c_char_p]
+    lib.pcq_query_collector_new_count.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    return lib
+
+
+def _mutations(image: np.ndarray):
+    yield "ok", image
+    yield "short", image[:100]
+    yield "sig", np.concatenate([np.frombuffer(b"XASF", dtype=np.uint8), image[4:]])
+    for fmt in (0x82, 11, 15, 6, 0x12):
+        m = image.copy()
+        m[104] = fmt
+        yield f"fmt{fmt}", m
+    m = image.copy()
+    m[105:107] = np.frombuffer(np.uint16(10).tobytes(), dtype=np.uint8)  # record length < format length
+    yield "reclen", m
+    m = image.copy()
+    m[25] = 4  # LAS 1.4 header is longer than the 227 bytes + data available? (tail fields read)
+    yield "v14", m
+    m = image.copy()
+    m[25] = 4
+    m[104] = 6
+    m[105:107] = np.frombuffer(np.uint16(30).tobytes(), dtype=np.uint8)
+    m[107:111] = 0  # legacy count 0 -> large count from the 1.4 tail
+    yield "v14_fmt6", m
+
+
+def test_host_header_parse_matches_oracle(oracle, qlib):
+    import _oracle
+    last = np.fromfile(os.path.join(HERE, "golden", "tiny_fmt2.last"), dtype=np.uint8)
+    for name, img in _mutations(last):
+        img = np.ascontiguousarray(img)
+        for mask in (0, 1):
+            h = HeaderInfo()
+            rc = qlib.pcq_query_parse_las_header(img.ctypes.data_as(C.c_void_p), img.size, mask, C.byref(h))
+            try:
+                oh = oracle.parse_header(img.tobytes(), bool(mask))
+                orc = 0
+            except _oracle.OracleError as e:
+                orc, oh = e.code, None
+            assert rc == orc, (name, mask, qlib.pcq_query_last_error())
+            if rc == 0:
+                assert (h.number_of_points, h.point_data_record_format, h.point_data_record_length, h.offset_to_point_data) == \
+                       (oh.number_of_points, oh.point_data_record_format, oh.point_data_record_length, oh.offset_to_point_data), name
+                assert list(h.scale) == list(oh.scale) and list(h.offset) == list(oh.offset)
+                assert list(h.min) == list(oh.min) and list(h.max) == list(oh.max)
+
+
+def test_parse_aabb_and_is_valid_file(qlib):
+    mn, mx = (C.c_double * 3)(), (C.c_double * 3)()
+    assert qlib.pcq_query_parse_aabb(b"665000;3910000;0;705000;3950000;480", mn, mx) == 0
+    assert list(mn) == [665000.0, 3910000.0, 0.0] and list(mx) == [705000.0, 3950000.0, 480.0]
+    assert qlib.pcq_query_parse_aabb(b"-23.108;-21.261;-10.029;28.588;27.123;5.959", mn, mx) == 0
+    assert list(mn) == [-23.108, -21.261, -10.029]
+    assert qlib.pcq_query_parse_aabb(b"1;2;3;4;5", mn, mx) == -8          # main.rs:61-63
+    assert qlib.pcq_query_parse_aabb(b"1;2;3;4;5;x", mn, mx) == -8        # main.rs:65-78
+    assert qlib.pcq_query_parse_aabb(b"1;2;3;4;5; 6", mn, mx) == -8       # Rust's parse rejects whitespace
+    assert qlib.pcq_query_parse_aabb(b"5;0;0;1;1;1", mn, mx) == -7        # from_min_max panics (min > max)
+    for name, ok in (("a.las", 1), ("a.laz", 1), ("b.last", 1), ("c.lazer", 1), ("d.LAS", 0), ("e.txt", 0), ("las", 0),
+                     (".las", 0), ("dir.las/x", 0), ("x.laser", 0)):
+        assert qlib.pcq_query_is_valid_file(name.encode()) == ok, name  # main.rs:185-189
+
+
+@pytest.mark.skipif(_has_gpu(), reason="checks the behaviour on a machine WITHOUT a GPU")
+def test_product_fails_loudly_without_a_gpu(qlib):
+    with pytest.raises(pkg.PcqError) as e:
+        pkg.Context(0)
+    assert e.value.code == -9 and "no CPU path" in e.value.message  # PCQ_ERR_HIP
+    h = C.c_void_p()
+    assert qlib.pcq_query_collector_new_count(0, C.byref(h)) == -9
+
+
+def _run(exe, args):
+    r = subprocess.run([exe] + args, capture_output=True, text=True)
+    return r.returncode, r.stdout, r.stderr
+
+
+@pytest.mark.parametrize("args", [
+    [],                                                                    # missing --input
+    ["-i", "/nonexistent/path", "--bounds", "0;0;0;1;1;1"],                # main.rs:30-35
+    ["-i", "DIR", "--bounds", "0;0;0;1;1;1", "--class", "6"],              # main.rs:238-240
+    ["-i", "DIR"],                                                         # main.rs:242-244
+    ["-i", "DIR", "--bounds", "nonsense"],                                 # expect() panic, exit 101
+    ["-i", "DIR", "--bounds", "2;0;0;1;1;1"],                              # from_min_max panic
+    ["-i", "DIR", "--class", "256"],                                       # u8 parse panic
+    ["-i", "DIR", "--class", "-1"],
+    ["-i", "DIR", "--bounds", "0;0;0;1;1;1", "--density", "abc"],
+    ["-i", "DIR", "--bounds", "0;0;0;1;1;1", "-o", "/nonexistent/out"],    # FileDumper::new
+    ["-i", "DIR", "--frobnicate"],
+])
+def test_cli_argument_errors_match_oracle_cli(oracle, tmp_path, args):
+    """Argument handling happens before any GPU work: same exit status as the oracle CLI."""
+    d = tmp_path / "data"
+    d.mkdir()
+    args = [str(d) if a == "DIR" else a for a in args]
+    rc_p, out_p, err_p = _run(os.path.join(PKG, "host", "query"), args)
+    rc_o, out_o, err_o = _run(os.path.join(ROOT, "oracle", "query_oracle"), args)
+    assert rc_p == rc_o and rc_p != 0, (args, rc_p, rc_o, err_p, err_o)
+    assert out_p == out_o == ""
