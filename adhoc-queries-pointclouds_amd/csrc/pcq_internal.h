@@ -110,7 +110,7 @@ struct pcq_ctx {
     size_t segments_cap = 0;
     // options
     int k1_variant = 0;
-    int grid_blocks_per_cu = 8;
+    int grid_blocks_per_cu = 4;   // persistent blocks per CU for the streaming count kernels (measured best 3-4, profiles/)
     uint64_t chunk_points = 8ull << 20;
 };
 

@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--cpu-sample-points", type=int, default=20_000_000, help="points per file of the CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-file-launch", action="store_true", help="one launch per file instead of one batched launch")
+    ap.add_argument("--blocks-per-cu", type=int, default=0, help="tuning: persistent blocks per CU (0 = library default)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,6 +113,8 @@ def main():
     stream = tstream.cuda_stream
     ctx = pkg.Context(local_rank)
     info = ctx.device_info()
+    if args.blocks_per_cu:
+        ctx.set_option("blocks_per_cu", args.blocks_per_cu)
 
     # ---- dataset: positions blocks resident in HBM (torch owns the memory) -----------------------
     blocks, headers = [], []
