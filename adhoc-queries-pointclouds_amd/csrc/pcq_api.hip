@@ -77,7 +77,7 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
     }
     if (const char *e = getenv("PCQ_K1_VARIANT")) {
         const int v = atoi(e);
-        if (v >= 0 && v <= 3) ctx->k1_variant = v;
+        if (v >= 0 && v <= 5) ctx->k1_variant = v;
     }
     *out_ctx = ctx;
     return PCQ_OK;
@@ -146,11 +146,12 @@ extern "C" int pcq_ctx_synchronize(pcq_ctx *ctx) {
 extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return pcq_fail(PCQ_ERR_ARG, "pcq_set_option: null argument");
     if (!strcmp(key, "k1_variant")) {
-        if (value < 0 || value > 3) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..3");
+        if (value < 0 || value > 5) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..5");
         ctx->k1_variant = (int)value;
     } else if (!strcmp(key, "blocks_per_cu")) {
         if (value < 1 || value > 16) return pcq_fail(PCQ_ERR_ARG, "blocks_per_cu must be 1..16");
         ctx->grid_blocks_per_cu = (int)value;
+        ctx->batch_blocks_per_cu = (int)value;
     } else if (!strcmp(key, "chunk_points")) {
         if (value < 4) return pcq_fail(PCQ_ERR_ARG, "chunk_points must be >= 4");
         ctx->chunk_points = (uint64_t)value;

@@ -110,7 +110,8 @@ struct pcq_ctx {
     size_t segments_cap = 0;
     // options
     int k1_variant = 0;
-    int grid_blocks_per_cu = 4;   // persistent blocks per CU for the streaming count kernels (measured best 3-4, profiles/)
+    int grid_blocks_per_cu = 2;   // persistent blocks per CU of the streaming count kernels: 8 waves x 3 KiB in flight per CU measured best (profiles/r01_k1_variant_sweep_interleaved.log)
+    int batch_blocks_per_cu = 3;  // the batched K1 measured best at 3 (same log)
     uint64_t chunk_points = 8ull << 20;
 };
 

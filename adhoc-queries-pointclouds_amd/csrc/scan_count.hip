@@ -58,11 +58,24 @@ __device__ __forceinline__ LaneBox rotate_box(const int32_t (&lo)[3], const uint
 }
 
 // Count of matching points in one 768-dword wave tile, mask-algebra form (wave-uniform result).
+__device__ __forceinline__ uint32_t tile_count_regs(const v4i (&v)[3], const LaneBox &b);
+
+template <bool NT = true>
 __device__ __forceinline__ uint32_t tile_count_masks(const v4i *tile, int lane, const LaneBox &b) {
     v4i v[3];
-    v[0] = ld_nt(tile + lane);
-    v[1] = ld_nt(tile + 64 + lane);
-    v[2] = ld_nt(tile + 128 + lane);
+    if (NT) {
+        v[0] = ld_nt(tile + lane);
+        v[1] = ld_nt(tile + 64 + lane);
+        v[2] = ld_nt(tile + 128 + lane);
+    } else {
+        v[0] = tile[lane];
+        v[1] = tile[64 + lane];
+        v[2] = tile[128 + lane];
+    }
+    return tile_count_regs(v, b);
+}
+
+__device__ __forceinline__ uint32_t tile_count_regs(const v4i (&v)[3], const LaneBox &b) {
     uint64_t m[3][4];
 #pragma unroll
     for (int k = 0; k < 3; k++)
@@ -143,7 +156,8 @@ __device__ __forceinline__ void block_store_partial(uint64_t wave_total, uint64_
 }
 
 // K1.  VARIANT 0: mask algebra (default) · 1: dwordx3 per lane · 2: 48-byte lane stride
-//      · 3: mask algebra, two tiles in flight per wave.
+//      · 3: mask algebra, two tiles in flight per wave · 4: mask algebra, plain (temporal) loads
+//      · 5: mask algebra, each wave owns two ADJACENT tiles (6 KiB contiguous), six loads in flight.
 template <int VARIANT>
 __global__ __launch_bounds__(BLOCK) void k_bounds_count_xyz12(const v4i *__restrict__ base, uint64_t n,
                                                               DevPred pred, uint64_t *__restrict__ partials) {
@@ -160,10 +174,24 @@ __global__ __launch_bounds__(BLOCK) void k_bounds_count_xyz12(const v4i *__restr
             total += tile_count_masks(base + (t + stride) * 192, lane, lb);
         }
         if (t < tiles) total += tile_count_masks(base + t * 192, lane, lb);
+    } else if (VARIANT == 5) {
+        const uint64_t pairs = tiles / 2;
+        for (uint64_t t = wave_id; t < pairs; t += stride) {
+            const v4i *tile = base + t * 384;
+            v4i a[3], b[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) a[k] = ld_nt(tile + 64 * k + lane);
+#pragma unroll
+            for (int k = 0; k < 3; k++) b[k] = ld_nt(tile + 192 + 64 * k + lane);
+            total += tile_count_regs(a, lb);
+            total += tile_count_regs(b, lb);
+        }
+        if ((tiles & 1) && wave_id == 0) total += tile_count_masks(base + (tiles - 1) * 192, lane, lb);
     } else {
         for (uint64_t t = wave_id; t < tiles; t += stride) {
             const v4i *tile = base + t * 192;  // 192 x 16 B = 3 KiB
             if (VARIANT == 0) total += tile_count_masks(tile, lane, lb);
+            else if (VARIANT == 4) total += tile_count_masks<false>(tile, lane, lb);
             else if (VARIANT == 1) total += tile_count_x3(tile, lane, pred.lo, pred.width);
             else total += tile_count_lane48(tile, lane, pred.lo, pred.width);
         }
@@ -287,9 +315,9 @@ __global__ __launch_bounds__(BLOCK) void k_finish_count(const uint64_t *__restri
 
 }  // namespace
 
-static int grid_for(pcq_ctx *ctx, uint64_t work_items_per_block_min, uint64_t items) {
+static int grid_for(pcq_ctx *ctx, uint64_t work_items_per_block_min, uint64_t items, int blocks_per_cu = 0) {
     uint64_t want = (items + work_items_per_block_min - 1) / work_items_per_block_min;
-    uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->grid_blocks_per_cu;
+    uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)(blocks_per_cu ? blocks_per_cu : ctx->grid_blocks_per_cu);
     if (want < 1) want = 1;
     return (int)(want < cap ? want : cap);
 }
@@ -306,6 +334,8 @@ int pcq_launch_bounds_count_xyz12(pcq_ctx *ctx, const void *d_xyz, uint64_t n, c
     case 1: hipLaunchKernelGGL(k_bounds_count_xyz12<1>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     case 2: hipLaunchKernelGGL(k_bounds_count_xyz12<2>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     case 3: hipLaunchKernelGGL(k_bounds_count_xyz12<3>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
+    case 4: hipLaunchKernelGGL(k_bounds_count_xyz12<4>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
+    case 5: hipLaunchKernelGGL(k_bounds_count_xyz12<5>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     default: hipLaunchKernelGGL(k_bounds_count_xyz12<0>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     }
     hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, grid, d_count);
@@ -368,7 +398,7 @@ extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, c
         points += cols[i].n;
     }
     PCQ_HIP(hipMemcpyAsync(ctx->d_segments, ctx->h_segments, nsegments * sizeof(DevSegment), hipMemcpyHostToDevice, s));
-    const int grid = grid_for(ctx, (uint64_t)WAVES * TILE_POINTS, points ? points : 1);
+    const int grid = grid_for(ctx, (uint64_t)WAVES * TILE_POINTS, points ? points : 1, ctx->batch_blocks_per_cu);
     int rc = pcq_ensure_partials(ctx, (size_t)grid);
     if (rc) return rc;
     hipLaunchKernelGGL(k_bounds_count_batch, dim3(grid), dim3(BLOCK), 0, s, ctx->d_segments, (int)nsegments, tiles,

@@ -1,8 +1,12 @@
 """Kernel-variant sweep for the count kernels on a real MI355X (developer tool, not the bench).
 
-Times each K1 (bounds count) variant and K2 (class count) on a device-resident synthetic LAST file
-with HIP events (torch.cuda.Event on the stream the kernels are launched on), interleaved rounds in
-one process, and prints achieved algorithmic GB/s (12 B/point, 1 B/point).
+Times each K1 (bounds count) variant, the batched K1 and K2 (class count) with HIP events
+(torch.cuda.Event on the stream the kernels are launched on), interleaved rounds in one process, and
+prints achieved algorithmic GB/s (12 B/point, 1 B/point).
+
+The working set rotates over `--files` device-resident synthetic files (default 8 x 163 M points =
+15.6 GB) so that no launch re-reads data the 256 MiB Infinity Cache could still hold: a sweep that
+re-reads ONE 2 GB file reports ~10 % more than the HBM stream really delivers.
 """
 import argparse
 import importlib
@@ -23,8 +27,10 @@ specs = importlib.import_module("adhoc-queries-pointclouds_amd.synth_specs")
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=163_000_000)
-    ap.add_argument("--rounds", type=int, default=10)
-    ap.add_argument("--blocks", type=str, default="4,8,16")
+    ap.add_argument("--files", type=int, default=8)
+    ap.add_argument("--rounds", type=int, default=16)
+    ap.add_argument("--blocks", type=str, default="2,3,4,6,8")
+    ap.add_argument("--variants", type=str, default="0,3,5,1")
     args = ap.parse_args()
     n = args.points
     dev = torch.device("cuda:0")
@@ -35,38 +41,51 @@ def main():
     assert stream != 0
     with pkg.Context(0) as ctx:
         print(json.dumps(ctx.device_info()))
-        spec = specs.synth_ca13(points_per_file=n, files=1)[0]
-        xyz = torch.empty(n * 12, dtype=torch.uint8, device=dev)
-        cls = torch.empty(n, dtype=torch.uint8, device=dev)
-        ctx.synth_fill(spec, 0, n, xyz.data_ptr(), cls.data_ptr(), stream)
+        ss = specs.synth_ca13(points_per_file=n, files=args.files)
+        xyz, cls, cols = [], [], []
+        bmin, bmax = specs.box("ca13_XL")
+        preds = []
+        for s in ss:
+            x = torch.empty(n * 12, dtype=torch.uint8, device=dev)
+            c = torch.empty(n, dtype=torch.uint8, device=dev)
+            ctx.synth_fill(s, 0, n, x.data_ptr(), c.data_ptr(), stream)
+            xyz.append(x)
+            cls.append(c)
+            cols.append(binding.make_columns(xyz=x.data_ptr(), cls=c.data_ptr(), n=n, scale=list(s.scale), offset=list(s.offset)))
+            lmin, lmax = pkg.box_to_local(bmin, bmax, list(s.scale), list(s.offset))
+            preds.append(pkg.Predicate.bounds(lmin, lmax))
         torch.cuda.synchronize()
         counter = torch.zeros(2, dtype=torch.int64, device=dev)
         cc = ctx.count_collector(device_counter=counter.data_ptr())
-        bmin, bmax = specs.box("ca13_XL")
-        lmin, lmax = pkg.box_to_local(bmin, bmax, list(spec.scale), list(spec.offset))
-        cols = binding.make_columns(xyz=xyz.data_ptr(), cls=cls.data_ptr(), n=n, scale=list(spec.scale), offset=list(spec.offset))
-        pb, pc = pkg.Predicate.bounds(lmin, lmax), pkg.Predicate.classification(6)
-        results = {}
-        for bpc in [int(b) for b in args.blocks.split(",")]:
-            ctx.set_option("blocks_per_cu", bpc)
-            for variant in (0, 1, 2, 3, "class"):
-                if variant != "class":
-                    ctx.set_option("k1_variant", variant)
-                times = []
-                for r in range(args.rounds + 2):
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        pc = pkg.Predicate.classification(6)
+        variants = [int(v) for v in args.variants.split(",")]
+        configs = [(bpc, v) for bpc in [int(b) for b in args.blocks.split(",")] for v in variants + ["batch", "class"]]
+        times = {c: [] for c in configs}
+        k = 0
+        for r in range(args.rounds + 2):  # interleaved rounds in one process (cdna guide rule 24)
+            for bpc, variant in configs:
+                ctx.set_option("blocks_per_cu", bpc)
+                ctx.set_option("k1_variant", variant if isinstance(variant, int) else 0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if variant == "batch":
                     e0.record()
-                    ctx.scan_dev(cols, pc if variant == "class" else pb, cc, stream)
+                    ctx.scan_dev_count_batch(cols, preds, counter.data_ptr(), stream)
                     e1.record()
-                    e1.synchronize()
-                    if r >= 2:
-                        times.append(e0.elapsed_time(e1))
-                times.sort()
-                med = times[len(times) // 2]
-                bpp = 1 if variant == "class" else 12
-                results[(bpc, variant)] = med
-                print(f"blocks/cu={bpc:2d} variant={variant!s:6} median {med:8.4f} ms  min {times[0]:8.4f} ms  "
-                      f"{n * bpp / med / 1e6:9.1f} GB/s (min: {n * bpp / times[0] / 1e6:9.1f})", flush=True)
+                else:
+                    f = k % args.files
+                    k += 1
+                    e0.record()
+                    ctx.scan_dev(cols[f], pc if variant == "class" else preds[f], cc, stream)
+                    e1.record()
+                e1.synchronize()
+                if r >= 2:
+                    times[(bpc, variant)].append(e0.elapsed_time(e1))
+        for (bpc, variant), t in times.items():
+            t.sort()
+            med = t[len(t) // 2]
+            nbytes = n * (1 if variant == "class" else 12) * (args.files if variant == "batch" else 1)
+            print(f"blocks/cu={bpc:2d} variant={variant!s:6} median {med:8.4f} ms  min {t[0]:8.4f} ms  "
+                  f"{nbytes / med / 1e6:9.1f} GB/s (min-time: {nbytes / t[0] / 1e6:9.1f})", flush=True)
         ctx.set_option("k1_variant", 0)
         print("count check:", int(counter[0].item()))
         cc.free()
