@@ -381,8 +381,7 @@ __global__ __launch_bounds__(BLOCK) void k_drain_emit(DevGridTable t, const uint
 
 }  // namespace
 
-void pcq_grid_release(pcq_collector *c) {
-    DevGridTable &t = c->table;
+static void table_free(DevGridTable &t) {
     if (t.keys) (void)hipFree(t.keys);
     if (t.dist) (void)hipFree(t.dist);
     if (t.widx) (void)hipFree(t.widx);
@@ -392,22 +391,42 @@ void pcq_grid_release(pcq_collector *c) {
     t = DevGridTable{};
 }
 
+void pcq_grid_cache_clear(pcq_ctx *ctx) { table_free(ctx->grid_cache); }
+
+// Retires the collector's table: the largest retired table stays cached in the context.
+void pcq_grid_release(pcq_collector *c) {
+    DevGridTable &t = c->table;
+    pcq_ctx *ctx = c->ctx;
+    if (t.keys && ctx && t.cap > ctx->grid_cache.cap) {
+        table_free(ctx->grid_cache);
+        ctx->grid_cache = t;
+        t = DevGridTable{};
+        return;
+    }
+    table_free(t);
+}
+
 static int table_alloc(pcq_ctx *ctx, DevGridTable *t, uint64_t cap, hipStream_t s) {
     *t = DevGridTable{};
-    t->cap = cap;
-    PCQ_HIP(hipMalloc((void **)&t->keys, cap * 8));
-    PCQ_HIP(hipMalloc((void **)&t->dist, cap * 8));
-    PCQ_HIP(hipMalloc((void **)&t->widx, cap * 8));
-    PCQ_HIP(hipMalloc((void **)&t->pts, cap * 32));
-    PCQ_HIP(hipMalloc((void **)&t->flags, cap));
-    PCQ_HIP(hipMalloc((void **)&t->occupied, 16));
-    t->n_alias = t->occupied + 1;
+    if (ctx->grid_cache.keys && ctx->grid_cache.cap >= cap && ctx->grid_cache.cap <= 4 * cap) {
+        *t = ctx->grid_cache;  // reuse (a larger table only lowers the load factor)
+        ctx->grid_cache = DevGridTable{};
+        cap = t->cap;
+    } else {
+        t->cap = cap;
+        PCQ_HIP(hipMalloc((void **)&t->keys, cap * 8));
+        PCQ_HIP(hipMalloc((void **)&t->dist, cap * 8));
+        PCQ_HIP(hipMalloc((void **)&t->widx, cap * 8));
+        PCQ_HIP(hipMalloc((void **)&t->pts, cap * 32));
+        PCQ_HIP(hipMalloc((void **)&t->flags, cap));
+        PCQ_HIP(hipMalloc((void **)&t->occupied, 16));
+        t->n_alias = t->occupied + 1;
+    }
     PCQ_HIP(hipMemsetAsync(t->keys, 0xff, cap * 8, s));
     PCQ_HIP(hipMemsetAsync(t->dist, 0xff, cap * 8, s));
     PCQ_HIP(hipMemsetAsync(t->widx, 0xff, cap * 8, s));
     PCQ_HIP(hipMemsetAsync(t->flags, 0, cap, s));
     PCQ_HIP(hipMemsetAsync(t->occupied, 0, 16, s));
-    (void)ctx;
     return PCQ_OK;
 }
 

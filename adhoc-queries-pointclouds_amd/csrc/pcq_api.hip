@@ -94,6 +94,7 @@ extern "C" int pcq_shutdown(pcq_ctx *ctx) {
         if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
         if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
     }
+    pcq_grid_cache_clear(ctx);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);

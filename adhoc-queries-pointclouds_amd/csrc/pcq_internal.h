@@ -108,6 +108,10 @@ struct pcq_ctx {
     DevSegment *d_segments = nullptr;
     DevSegment *h_segments = nullptr;
     size_t segments_cap = 0;
+    // one retired grid hash table kept for reuse: per-file grids (main.rs:156) would otherwise
+    // hipMalloc/hipFree tens of GB per file, and a fresh 30 GB allocation right after a free was
+    // measured to stall for seconds (profiles/r01_grid_timeline.txt)
+    DevGridTable grid_cache = {};
     // options
     int k1_variant = 0;
     int grid_blocks_per_cu = 2;   // persistent blocks per CU of the streaming count kernels: 8 waves x 3 KiB in flight per CU measured best (profiles/r01_k1_variant_sweep_interleaved.log)
@@ -158,4 +162,5 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const Dev
                   uint64_t matches_upper_bound, hipStream_t s);
 int pcq_grid_alloc(pcq_ctx *ctx, pcq_collector *c, uint64_t cap);
 void pcq_grid_release(pcq_collector *c);
+void pcq_grid_cache_clear(pcq_ctx *ctx);
 int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_t cap, uint64_t *out_n);

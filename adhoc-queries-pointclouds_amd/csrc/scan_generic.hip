@@ -102,37 +102,66 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(uint64_t *__restrict__ 
 }
 
 // Pass 3: write each match of tile b at out[(out_base + offsets[b] + rank) * 31].
+// 31-byte records at a 31-byte pitch are hostile to per-lane stores (31 byte-stores per match, 16
+// cache lines touched per wave-instruction).  The block instead assembles the records of 1024 input
+// points in LDS, laid out congruent (mod 16) to their final global position, and then streams the
+// contiguous byte range out with 16-byte stores; only the two ragged ends use byte stores, so
+// neighbouring blocks never write the same 16-byte chunk.
+constexpr int FLUSH_ITEMS = 4;                                  // input rows of 256 points per LDS flush
+constexpr int STAGE_BYTES = FLUSH_ITEMS * BLOCK * 31 + 16;      // 31,760 B: five blocks per CU fit in LDS
+
 __global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, const uint64_t *__restrict__ offsets,
                                                        uint8_t *__restrict__ out31, uint64_t out_base) {
     __shared__ uint32_t s_w[WAVES];
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[STAGE_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t base = (uint64_t)blockIdx.x * TILE;
-    uint64_t run = out_base + offsets[blockIdx.x];
+    uint64_t run = out_base + offsets[blockIdx.x];  // record index of the block's next match
 #pragma unroll 1
-    for (int j = 0; j < ITEMS; j++) {
-        const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
-        RawPoint rp;
-        bool have = false;
-        const bool pass = i < c.n && eval_pred(c, pr, i, rp, have);
-        const uint64_t mask = __ballot(pass);
-        if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
-        __syncthreads();
-        uint32_t before = 0, all = 0;
+    for (int h = 0; h < ITEMS / FLUSH_ITEMS; h++) {
+        const uint64_t gbyte0 = run * 31ull;
+        const uint32_t pad = (uint32_t)(gbyte0 & 15);
+        uint32_t seg = 0;  // matches staged so far (block-uniform)
+#pragma unroll 1
+        for (int jj = 0; jj < FLUSH_ITEMS; jj++) {
+            const int j = h * FLUSH_ITEMS + jj;
+            const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
+            RawPoint rp;
+            bool have = false;
+            const bool pass = i < c.n && eval_pred(c, pr, i, rp, have);
+            const uint64_t mask = __ballot(pass);
+            if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
+            __syncthreads();
+            uint32_t before = 0, all = 0;
 #pragma unroll
-        for (int w = 0; w < WAVES; w++) {
-            const uint32_t v = s_w[w];
-            before += w < wave ? v : 0;
-            all += v;
+            for (int w = 0; w < WAVES; w++) {
+                const uint32_t v = s_w[w];
+                before += w < wave ? v : 0;
+                all += v;
+            }
+            if (pass) {
+                const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                if (!have) rp = ld_xyz(c, i);
+                pcq_point pt;
+                make_point(c, i, rp, pt);
+                store_point31(s_stage + pad + 31u * (seg + before + rank), pt);
+            }
+            seg += all;
+            __syncthreads();
         }
-        if (pass) {
-            const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            if (!have) rp = ld_xyz(c, i);
-            pcq_point pt;
-            make_point(c, i, rp, pt);
-            store_point31(out31 + (run + before + rank) * 31ull, pt);
+        const uint32_t total = pad + seg * 31u;  // staged image is [pad, total)
+        uint8_t *gdst = out31 + (gbyte0 - pad);   // 16-byte aligned (out31 comes from hipMalloc)
+        for (uint32_t b0 = threadIdx.x * 16u; b0 < total; b0 += BLOCK * 16u) {
+            const uint32_t b1 = b0 + 16u;
+            if (b0 >= pad && b1 <= total) {
+                *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(s_stage + b0);
+            } else {
+                const uint32_t lo = b0 > pad ? b0 : pad, hi = b1 < total ? b1 : total;
+                for (uint32_t k = lo; k < hi; k++) gdst[k] = s_stage[k];
+            }
         }
-        run += all;
-        __syncthreads();
+        run += seg;
+        __syncthreads();  // the stage is reused by the next half
     }
 }
 

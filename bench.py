@@ -83,6 +83,12 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="tuning: persistent blocks per CU (0 = library default)")
     args = ap.parse_args()
 
+    # stdout carries exactly ONE JSON line: native libraries (the RCCL banner, rocprof) write to fd 1,
+    # so everything else is routed to stderr and the result is written to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,8 +101,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path is exercised even at N=1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module("adhoc-queries-pointclouds_amd")
@@ -161,12 +169,12 @@ def main():
                 if record is not None:
                     e1.record(tstream)
                     record.append((e0, e1, scanned))
-        sharding.global_count(total, world)  # main.rs:164-180 across GPUs: one RCCL all-reduce when N > 1
+        sharding.global_count(total, world if not use_dist else max(world, 2))  # main.rs:164-180: one RCCL all-reduce
         return int(total[0].item()), scanned  # the query's answer reaches the host every step
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -179,7 +187,7 @@ def main():
         matches, scanned_local = query_step(events)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -269,9 +277,10 @@ def main():
         result["cpu_baseline"] = None
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(result) + "\n").encode())
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,28 @@
+"""Developer probe: one grid-collector scan (for rocprofv3 --kernel-trace)."""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+pkg = importlib.import_module("adhoc-queries-pointclouds_amd")
+binding = importlib.import_module("adhoc-queries-pointclouds_amd.binding")
+specs = importlib.import_module("adhoc-queries-pointclouds_amd.synth_specs")
+q, cell, n = sys.argv[1], float(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 163_000_000
+with pkg.Context(0) as ctx:
+    spec = specs.synth_ca13(points_per_file=n)[5]
+    xyz, cls = ctx.alloc(12 * n), ctx.alloc(n)
+    ctx.synth_fill(spec, 0, n, xyz, cls)
+    ctx.synchronize()
+    cols = binding.make_columns(xyz=xyz, cls=cls, n=n, scale=list(spec.scale), offset=list(spec.offset))
+    bmin, bmax = specs.box(q)
+    lmin, lmax = pkg.box_to_local(bmin, bmax, list(spec.scale), list(spec.offset))
+    for _ in range(2):
+        t0 = time.perf_counter()
+        g = ctx.grid_collector(bmin, bmax, cell)
+        t1 = time.perf_counter()
+        ctx.scan_dev(cols, pkg.Predicate.bounds(lmin, lmax), g)
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        k = g.point_count()
+        t3 = time.perf_counter()
+        g.free()
+        t4 = time.perf_counter()
+        print(q, cell, "cells", k, "new %.1f scan %.1f count %.1f free %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3), flush=True)
