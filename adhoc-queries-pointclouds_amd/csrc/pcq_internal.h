@@ -108,6 +108,7 @@ struct pcq_ctx {
     DevSegment *d_segments = nullptr;
     DevSegment *h_segments = nullptr;
     size_t segments_cap = 0;
+    size_t segments_uploaded = 0;       // number of segments of the table currently in d_segments (0 = none)
     // one retired grid hash table kept for reuse: per-file grids (main.rs:156) would otherwise
     // hipMalloc/hipFree tens of GB per file, and a fresh 30 GB allocation right after a free was
     // measured to stall for seconds (profiles/r01_grid_timeline.txt)

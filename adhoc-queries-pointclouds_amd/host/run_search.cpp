@@ -242,6 +242,7 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
     std::vector<std::unique_ptr<ResultCollector>> collectors(nfiles);
     std::vector<Status> results(nfiles);
     std::vector<SearchLog> logs(nfiles);
+    std::vector<int> file_device(nfiles, 0);
     std::atomic<size_t> next{0};
     std::vector<int> devices = opt.devices.empty() ? std::vector<int>{0} : opt.devices;
     const int tpd = opt.threads_per_device < 1 ? 1 : opt.threads_per_device;
@@ -266,6 +267,7 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
                     results[i] = cst;
                     continue;
                 }
+                file_device[i] = device;
                 Status st = factory(ctx, &collectors[i]);  // :156
                 if (st.ok()) st = searcher.search_file(files[i], impl, *collectors[i], &logs[i]);  // :158
                 results[i] = st;
@@ -290,8 +292,36 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         if (!results[i].ok()) final_status = results[i];  // :161-163 first Err aborts
     std::optional<size_t> matches;
     if (final_status.ok()) {
-        for (size_t i = 0; i < nfiles && final_status.ok(); i++)  // :165-176, input-file order
-            final_status = drain(*collectors[i], dumper, &matches);
+        std::vector<uint64_t> partial(devices.size(), 0);  // per-GPU partial match counts
+        for (size_t i = 0; i < nfiles && final_status.ok(); i++) {  // :165-176, input-file order
+            std::optional<size_t> one;
+            final_status = drain(*collectors[i], dumper, &one);
+            if (one) {
+                matches = matches.value_or(0) + *one;
+                for (size_t d = 0; d < devices.size(); d++)
+                    if (devices[d] == file_device[i]) partial[d] += *one;
+            }
+        }
+        // With several GPUs the global count is the all-reduce of the per-GPU partial counts
+        // (main.rs:171-179 across devices): one RCCL all-reduce(sum, u64) over xGMI.
+        if (final_status.ok() && matches && devices.size() > 1) {
+            std::vector<pcq_ctx *> ctxs(devices.size(), nullptr);
+            std::vector<uint64_t *> counters(devices.size(), nullptr);
+            for (size_t d = 0; d < devices.size() && final_status.ok(); d++) {
+                final_status = thread_context(devices[d], &ctxs[d]);
+                void *p = nullptr;
+                if (final_status.ok()) final_status = Status::FromLib(pcq_device_alloc(ctxs[d], 16, &p));
+                counters[d] = (uint64_t *)p;
+                if (final_status.ok()) final_status = Status::FromLib(pcq_copy_to_device(ctxs[d], p, &partial[d], 8));
+            }
+            if (final_status.ok())
+                final_status = Status::FromLib(pcq_allreduce_sum_u64(ctxs.data(), counters.data(), (int)devices.size()));
+            uint64_t total = 0;
+            if (final_status.ok()) final_status = Status::FromLib(pcq_copy_to_host(ctxs[0], &total, counters[0], 8));
+            for (size_t d = 0; d < devices.size(); d++)
+                if (counters[d]) pcq_device_free(ctxs[d], counters[d]);
+            if (final_status.ok()) matches = (size_t)total;
+        }
     }
     {
         std::unique_lock<std::mutex> lk(mu);

@@ -178,6 +178,12 @@ int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pr
 int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *preds,
                              size_t nsegments, uint64_t *device_total, void *stream);
 
+/* The one collective of the path (main.rs:164-180) for callers that drive n GPUs from ONE process:
+ * device_counters[i] (8 bytes in ctxs[i]'s HBM, e.g. of pcq_collector_new_count_at) all become the sum
+ * over i — a single RCCL all-reduce(sum, u64, count = 1) over an intra-node communicator (xGMI).
+ * Synchronous.  n == 1 is a no-op.  RCCL is bound at run time; failure to find it is an error. */
+int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, uint64_t *const *device_counters, int n);
+
 /* Device memory helpers for callers that keep column blocks resident in HBM. */
 int pcq_device_alloc(pcq_ctx *ctx, uint64_t bytes, void **out);
 int pcq_device_free(pcq_ctx *ctx, void *p);

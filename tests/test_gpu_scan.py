@@ -233,3 +233,16 @@ def test_synth_device_generator_is_bit_identical(oracle, gpu_ctx):
         gpu_ctx.free(dc)
         assert np.array_equal(gx, xyz_h)
         assert np.array_equal(gc, cls_h)
+
+
+def test_allreduce_entry_point_single_rank(gpu_ctx):
+    """pcq_allreduce_sum_u64 with one rank is the identity (the n > 1 RCCL path needs several GPUs)."""
+    d = gpu_ctx.alloc(16)
+    gpu_ctx.to_device(d, np.array([12345678901234567], dtype=np.uint64))
+    ctxs = (C.c_void_p * 1)(gpu_ctx.handle.value)
+    ptrs = (C.c_void_p * 1)(d)
+    assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, ptrs, 1) == 0
+    out = np.zeros(1, dtype=np.uint64)
+    gpu_ctx.to_host(out, d)
+    gpu_ctx.free(d)
+    assert int(out[0]) == 12345678901234567
