@@ -123,6 +123,7 @@ def load_library() -> C.CDLL:
         "pcq_collector_reset": (C.c_int, [vp]),
         "pcq_scan_dev": (C.c_int, [vp, P(Columns), P(Predicate), vp, vp]),
         "pcq_scan_host": (C.c_int, [vp, P(Columns), P(Predicate), vp]),
+        "pcq_scan_fd": (C.c_int, [vp, C.c_int, P(Columns), P(Predicate), vp]),
         "pcq_scan_dev_count_batch": (C.c_int, [vp, P(Columns), P(Predicate), C.c_size_t, vp, vp]),
         "pcq_allreduce_sum_u64": (C.c_int, [P(vp), P(vp), C.c_int]),
         "pcq_device_alloc": (C.c_int, [vp, u64, P(vp)]),

@@ -6,6 +6,9 @@
 // usable, pcq_init fails and nothing else can be called.
 #include "pcq_internal.h"
 
+#include <unistd.h>
+
+#include <cerrno>
 #include <cmath>
 #include <cstdlib>
 #include <new>
@@ -557,7 +560,31 @@ struct StagePlan {
 
 static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
-extern "C" int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
+
+// Copies `bytes` from the host source into pinned memory: memcpy from caller memory, or — when the
+// columns are given as offsets into an open file (pcq_scan_fd) — pread straight from the page cache
+// (no mmap page-table work: measured ~2x the rate of memcpy from a freshly mmapped file).
+static int fetch(int fd, uint8_t *dst, const uint8_t *src, size_t bytes) {
+    if (fd < 0) {
+        memcpy(dst, src, bytes);
+        return PCQ_OK;
+    }
+    off_t off = (off_t)(uintptr_t)src;
+    while (bytes) {
+        const ssize_t r = pread(fd, dst, bytes, off);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            return pcq_fail(PCQ_ERR_IO, "pread failed: %s", strerror(errno));
+        }
+        if (r == 0) return pcq_fail(PCQ_ERR_EOF, "failed to fill whole buffer");
+        dst += r;
+        off += r;
+        bytes -= (size_t)r;
+    }
+    return PCQ_OK;
+}
+
+static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
     if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_host: null context");
     int rc = validate_scan(cols, pred, c);
     if (rc) return rc;
@@ -628,11 +655,14 @@ extern "C" int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_pr
         if (pl.aos) {
             // up to the last needed byte of the last record (never past the caller's mapping)
             bytes = (size_t)((cnt - 1) * pl.stride + pl.span);
-            memcpy(h, pl.aos_base + first * pl.stride, bytes);
+            int frc = fetch(fd, h, pl.aos_base + first * pl.stride, bytes);
+            if (frc) return frc;
         } else {
-            if (pl.need_xyz) memcpy(h + off_xyz, hx + first * 12, (size_t)cnt * 12);
-            if (pl.need_cls) memcpy(h + off_cls, hc + first, (size_t)cnt);
-            if (pl.need_rgb) memcpy(h + off_rgb, hr + first * 6, (size_t)cnt * 6);
+            int frc = PCQ_OK;
+            if (pl.need_xyz) frc = fetch(fd, h + off_xyz, hx + first * 12, (size_t)cnt * 12);
+            if (!frc && pl.need_cls) frc = fetch(fd, h + off_cls, hc + first, (size_t)cnt);
+            if (!frc && pl.need_rgb) frc = fetch(fd, h + off_rgb, hr + first * 6, (size_t)cnt * 6);
+            if (frc) return frc;
             bytes = off_rgb + (pl.need_rgb ? (size_t)cnt * 6 : 0);
             if (!pl.need_rgb) bytes = off_cls + (pl.need_cls ? (size_t)cnt : 0);
             if (!pl.need_cls && !pl.need_rgb) bytes = (size_t)cnt * 12;
@@ -672,4 +702,13 @@ extern "C" int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_pr
     }
     PCQ_HIP(hipStreamSynchronize(s));
     return PCQ_OK;
+}
+
+extern "C" int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
+    return scan_host_impl(ctx, -1, cols, pred, c);
+}
+
+extern "C" int pcq_scan_fd(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
+    if (fd < 0) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_fd: bad file descriptor");
+    return scan_host_impl(ctx, fd, cols, pred, c);
 }

@@ -117,7 +117,7 @@ struct pcq_ctx {
     int k1_variant = 0;
     int grid_blocks_per_cu = 2;   // persistent blocks per CU of the streaming count kernels: 8 waves x 3 KiB in flight per CU measured best (profiles/r01_k1_variant_sweep_interleaved.log)
     int batch_blocks_per_cu = 3;  // the batched K1 measured best at 3 (same log)
-    uint64_t chunk_points = 8ull << 20;
+    uint64_t chunk_points = 2ull << 20;    // 24 MB of positions per staging chunk (profiles/r01_host_path_rate.json: 1-8 Mi equal)
 };
 
 enum { COLL_COUNT = 0, COLL_BUFFER = 1, COLL_GRID = 2 };

@@ -130,6 +130,7 @@ Status parse_las_header(const uint8_t *data, size_t len, bool mask_format, LasHe
 // ---- mmap ---------------------------------------------------------------------------------------------
 MappedFile::~MappedFile() {
     if (data_) munmap(const_cast<uint8_t *>(data_), size_);
+    if (fd_ >= 0) close(fd_);
 }
 
 Status MappedFile::open(const std::string &path) {
@@ -151,9 +152,8 @@ Status MappedFile::open(const std::string &path) {
             return Status::Err(PCQ_ERR_IO, path + ": mmap: " + strerror(e));
         }
         data_ = (const uint8_t *)p;
-        madvise(p, size_, MADV_SEQUENTIAL);
     }
-    close(fd);
+    fd_ = fd;
     return Status::Ok();
 }
 

@@ -80,10 +80,12 @@ public:
     Status open(const std::string &path);
     const uint8_t *data() const { return data_; }
     size_t size() const { return size_; }
+    int fd() const { return fd_; }  // kept open: column blocks are streamed with pread (pcq_scan_fd)
 
 private:
     const uint8_t *data_ = nullptr;
     size_t size_ = 0;
+    int fd_ = -1;
 };
 
 // One GPU context per (thread, device); created on first use, destroyed with the thread.

@@ -9,6 +9,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <ctime>
 #include <limits>
@@ -259,7 +260,11 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         const int device = devices[t % devices.size()];
         pool.emplace_back([&, device]() {
             pcq_ctx *ctx = nullptr;
+            const auto t_a = std::chrono::steady_clock::now();
             Status cst = thread_context(device, &ctx);
+            if (getenv("PCQ_TIMING"))
+                fprintf(stderr, "[pcq] context on device %d ready after %.1f ms\n", device,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count());
             for (;;) {
                 const size_t i = next.fetch_add(1);
                 if (i >= nfiles) break;
@@ -268,9 +273,13 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
                     continue;
                 }
                 file_device[i] = device;
+                const auto t_f = std::chrono::steady_clock::now();
                 Status st = factory(ctx, &collectors[i]);  // :156
                 if (st.ok()) st = searcher.search_file(files[i], impl, *collectors[i], &logs[i]);  // :158
                 results[i] = st;
+                if (getenv("PCQ_TIMING"))
+                    fprintf(stderr, "[pcq] file %zu searched in %.1f ms\n", i,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f).count());
             }
             std::unique_lock<std::mutex> lk(mu);
             finished++;
@@ -504,6 +513,9 @@ int query_main(int argc, const char *const *argv, const PrintFn &out, const Prin
         return 1;
     }
 
+    if (getenv("PCQ_TIMING"))
+        fprintf(stderr, "[pcq] total in-process %.1f ms\n",
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count());
     const double elapsed = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();  // :309
     const double throughput_mibs = ((double)total_file_size / elapsed) / 1048576.0;
     char line[256];

@@ -96,9 +96,19 @@ Status eof() { return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer"); }
 // validated up front ("deviations").
 bool block_ok(const MappedFile &f, uint64_t off, uint64_t bytes) { return off <= f.size() && bytes <= f.size() - off; }
 
-Status run_scan(ResultCollector &rc, pcq_columns &cols, const pcq_predicate &pred) {
+// The column blocks were located in the mapped file (header parse, offsets: exactly as the reference
+// does); the bytes themselves are streamed by the library with pread from the same file, so `cols`
+// carries file offsets instead of addresses inside the mapping.
+Status run_scan(const MappedFile &file, ResultCollector &rc, pcq_columns &cols, const pcq_predicate &pred) {
     cols.first_index = rc.next_index;
-    const int r = pcq_scan_host(rc.context(), &cols, &pred, rc.handle());
+    auto to_offset = [&](const void *p) -> const void * {
+        return p ? (const void *)(uintptr_t)((const uint8_t *)p - file.data()) : nullptr;
+    };
+    // a NULL column must stay NULL, and offset 0 never is a column (the header lives there)
+    cols.xyz = to_offset(cols.xyz);
+    cols.cls = to_offset(cols.cls);
+    cols.rgb = to_offset(cols.rgb);
+    const int r = pcq_scan_fd(rc.context(), file.fd(), &cols, &pred, rc.handle());
     rc.next_index += cols.n;
     return Status::FromLib(r);
 }
@@ -143,7 +153,7 @@ Status search_last_file_by_bounds_optimized(const std::string &path, const AABB 
     cols.rgb_stride = 6;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :156-160
-    return run_scan(rc, cols, pred);
+    return run_scan(file, rc, cols, pred);
 }
 
 // ---- last.rs:213-293 -------------------------------------------------------------------------------------
@@ -180,7 +190,7 @@ Status search_last_file_by_classification_optimized(const std::string &path, uin
     cols.rgb_stride = 6;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :283-287
-    return run_scan(rc, cols, pred);
+    return run_scan(file, rc, cols, pred);
 }
 
 // ---- las.rs:52-148 ---------------------------------------------------------------------------------------
@@ -212,7 +222,7 @@ Status search_las_file_by_bounds_optimized(const std::string &path, const AABB &
     cols.xyz_stride = cols.cls_stride = cols.rgb_stride = rl;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :138-142
-    return run_scan(rc, cols, pred);
+    return run_scan(file, rc, cols, pred);
 }
 
 // ---- las.rs:192-261 --------------------------------------------------------------------------------------
@@ -243,7 +253,7 @@ Status search_las_file_by_classification_optimized(const std::string &path, uint
     cols.xyz_stride = cols.cls_stride = cols.rgb_stride = rl;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :251-255
-    return run_scan(rc, cols, pred);
+    return run_scan(file, rc, cols, pred);
 }
 
 // ---- searcher.rs ---------------------------------------------------------------------------------------------

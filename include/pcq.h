@@ -172,6 +172,11 @@ int pcq_scan_dev(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pre
                  void *stream);
 int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred,
                   pcq_collector *c);
+/* Same as pcq_scan_host, but the column "pointers" of `cols` are BYTE OFFSETS into the open file
+ * `fd` (e.g. offset_to_point_data for xyz): chunks are pread() straight into the pinned staging
+ * buffers, which avoids the page-table work of reading through a fresh mmap (last.rs:27-34). */
+int pcq_scan_fd(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predicate *pred,
+                pcq_collector *c);
 
 /* Count-only scan of many device-resident LAST files in ONE launch (files = independent units,
  * main.rs:153-161): segment i is scanned with preds[i]; the total is ADDED to *device_total. */

@@ -1,0 +1,70 @@
+"""End-to-end wall clock of the `query` CLI (files on disk, page cache warm) next to the oracle CLI
+(the C restatement of the reference's `query --optimized --parallel`, one thread... the oracle CLI is
+single-threaded; the multi-threaded oracle number is bench.py's cpu_baseline).  Developer tool: the
+numbers go to DESIGN.md, not to the bench line.
+"""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _oracle  # noqa: E402  (file generator)
+
+specs = importlib.import_module("adhoc-queries-pointclouds_amd.synth_specs")
+QUERY = os.path.join(ROOT, "adhoc-queries-pointclouds_amd", "host", "query")
+ORACLE = os.path.join(ROOT, "oracle", "query_oracle")
+
+
+def run(exe, args, repeat=3):
+    best, out = None, None
+    for _ in range(repeat):
+        t0 = time.perf_counter()
+        r = subprocess.run([exe] + args, capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            raise SystemExit(f"{exe} failed: {r.stderr}")
+        best = dt if best is None or dt < best else best
+        out = [l for l in r.stdout.splitlines() if not l.startswith("Searched")]
+    return best, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--files", type=int, default=16)
+    ap.add_argument("--points", type=int, default=20_000_000)
+    ap.add_argument("--threads-per-gpu", type=int, default=4)
+    args = ap.parse_args()
+    o = _oracle.Oracle()
+    d = tempfile.mkdtemp(prefix="pcq_e2e_", dir="/tmp")
+    ss = specs.synth_ca13(points_per_file=args.points, files=args.files)
+    for i, s in enumerate(ss):
+        o.synth_write(s, os.path.join(d, f"tile{i:02d}.last"), threads=32)
+    total_pts = args.files * args.points
+    res = {"files": args.files, "points": total_pts, "bytes": sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))}
+    xl = "643431.76;3883547.565;-46194.145;736910.93;3977026.735;47285.025"
+    for name, q in (("bounds_XL", ["--bounds", xl]), ("bounds_S", ["--bounds", "665000;3910000;0;705000;3950000;480"]),
+                    ("class_6", ["--class", "6"]), ("bounds_XL_density_100", ["--bounds", xl, "--density", "100"])):
+        base = ["-i", d, "--optimized", "--parallel"] + q
+        t_gpu, out_gpu = run(QUERY, base + ["--threads-per-gpu", str(args.threads_per_gpu)])
+        t_gpu2, _ = run(QUERY, base + ["--threads-per-gpu", "2"])
+        t_gpu8, _ = run(QUERY, base + ["--threads-per-gpu", "8"])
+        t_cpu, out_cpu = run(ORACLE, base, repeat=1)
+        assert sorted(out_gpu) == sorted(out_cpu), (out_gpu, out_cpu)
+        res[name] = {"gpu_cli_s": t_gpu, "gpu_cli_s_2thr": t_gpu2, "gpu_cli_s_8thr": t_gpu8, "oracle_cli_s": t_cpu, "gpu_Mpts_per_s": total_pts / t_gpu / 1e6,
+                     "oracle_cli_Mpts_per_s": total_pts / t_cpu / 1e6, "stdout": out_gpu[-1] if out_gpu else ""}
+        print(name, json.dumps(res[name]), flush=True)
+    for f in os.listdir(d):
+        os.remove(os.path.join(d, f))
+    os.rmdir(d)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,20 @@
+#!/bin/bash
+# developer probe: where the CLI's wall time goes (PCQ_TIMING=1) on 16 x 20 M-point LAST files
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+D=$(mktemp -d /tmp/pcq_probe_XXXX)
+python3 - "$D" <<PY
+import sys, importlib, os
+sys.path.insert(0, "$ROOT"); sys.path.insert(0, "$ROOT/tests")
+import _oracle
+specs = importlib.import_module("adhoc-queries-pointclouds_amd.synth_specs")
+o = _oracle.Oracle()
+for i, s in enumerate(specs.synth_ca13(points_per_file=20_000_000, files=16)):
+    o.synth_write(s, os.path.join(sys.argv[1], f"tile{i:02d}.last"), threads=32)
+PY
+XL="643431.76;3883547.565;-46194.145;736910.93;3977026.735;47285.025"
+for T in 2 4; do
+  echo "== threads-per-gpu $T"
+  time env PCQ_TIMING=1 "$ROOT/adhoc-queries-pointclouds_amd/host/query" -i "$D" --bounds "$XL" --optimized --parallel --threads-per-gpu $T 2>&1 | tail -30
+done
+rm -rf "$D"
