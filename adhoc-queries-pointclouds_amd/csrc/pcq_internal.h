@@ -60,6 +60,17 @@ struct DevSegment {
     int32_t _pad;
 };
 
+// One segment of a batched class-count launch: a LAST classification block of any alignment.
+struct DevClassSegment {
+    const uint8_t *cls;
+    uint64_t n;            // bytes (= points)
+    uint64_t head;         // bytes in front of the first 16-byte aligned byte
+    uint64_t nvec;         // 16-byte vectors in the aligned body
+    uint64_t tile_begin;   // first global wave-tile (256 vectors = 4 KiB) of this segment
+    uint32_t pat;          // class byte replicated x4
+    uint32_t _pad;
+};
+
 // SparseGrid parameters (grid_sampling.rs:9-47) in device form.
 struct DevGrid {
     double bmin[3], bmax[3];
@@ -109,6 +120,7 @@ struct pcq_ctx {
     DevSegment *h_segments = nullptr;
     size_t segments_cap = 0;
     size_t segments_uploaded = 0;       // number of segments of the table currently in d_segments (0 = none)
+    int segments_kind = -1;             // predicate kind of the uploaded table
     // one retired grid hash table kept for reuse: per-file grids (main.rs:156) would otherwise
     // hipMalloc/hipFree tens of GB per file, and a fresh 30 GB allocation right after a free was
     // measured to stall for seconds (profiles/r01_grid_timeline.txt)

@@ -301,6 +301,65 @@ __global__ __launch_bounds__(BLOCK) void k_class_count_u8(const uint8_t *__restr
     block_store_partial(w, partials);
 }
 
+// Batched K2: the classification blocks of many files in one launch.  A wave-tile is 256 aligned
+// 16-byte vectors (4 KiB, four loads in flight per lane); leftovers (< 256 vectors, head and tail
+// bytes) of segment i are handled by block i % gridDim.x.
+// The class segments live in the same device table as the bounds segments, at DevSegment pitch.
+__device__ __forceinline__ const DevClassSegment &cseg(const DevSegment *raw, int i) {
+    return *reinterpret_cast<const DevClassSegment *>(raw + i);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_class_count_batch(const DevSegment *__restrict__ raw, int nseg,
+                                                             uint64_t total_tiles, uint64_t *__restrict__ partials) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_id = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const uint64_t stride = (uint64_t)gridDim.x * WAVES;
+    uint32_t cnt = 0;
+    int s = 0;
+    uint64_t seg_begin = 0, seg_end = 0;
+    const v4i *body = nullptr;
+    uint32_t pat = 0;
+    for (uint64_t t = wave_id; t < total_tiles; t += stride) {
+        if (t >= seg_end) {
+            while (s + 1 < nseg && t >= cseg(raw, s + 1).tile_begin) s++;
+            seg_begin = cseg(raw, s).tile_begin;
+            seg_end = seg_begin + cseg(raw, s).nvec / 256;
+            body = reinterpret_cast<const v4i *>(cseg(raw, s).cls + cseg(raw, s).head);
+            pat = cseg(raw, s).pat;
+        }
+        const v4i *tile = body + (t - seg_begin) * 256;
+        const v4i a = ld_nt(tile + lane), b = ld_nt(tile + 64 + lane), c = ld_nt(tile + 128 + lane), d = ld_nt(tile + 192 + lane);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            cnt += __popc(zero_bytes((uint32_t)a[j] ^ pat));
+            cnt += __popc(zero_bytes((uint32_t)b[j] ^ pat));
+            cnt += __popc(zero_bytes((uint32_t)c[j] ^ pat));
+            cnt += __popc(zero_bytes((uint32_t)d[j] ^ pat));
+        }
+    }
+    for (int i = blockIdx.x; i < nseg; i += gridDim.x) {
+        const DevClassSegment g = cseg(raw, i);
+        const uint8_t c8 = (uint8_t)(g.pat & 0xff);
+        const v4i *bd = reinterpret_cast<const v4i *>(g.cls + g.head);
+        for (uint64_t v = (g.nvec / 256) * 256 + threadIdx.x; v < g.nvec; v += BLOCK) {  // < 256 leftover vectors
+            const v4i a = bd[v];
+#pragma unroll
+            for (int j = 0; j < 4; j++) cnt += __popc(zero_bytes((uint32_t)a[j] ^ g.pat));
+        }
+        if (threadIdx.x < 16) {
+            const uint64_t p = threadIdx.x;
+            if (p < g.head && g.cls[p] == c8) cnt++;
+        } else if (threadIdx.x < 32) {
+            const uint64_t p = g.head + 16 * g.nvec + (threadIdx.x - 16);
+            if (p < g.n && g.cls[p] == c8) cnt++;
+        }
+    }
+    uint64_t w = cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down((unsigned long long)w, off, 64);
+    block_store_partial(w, partials);
+}
+
 __global__ __launch_bounds__(BLOCK) void k_finish_count(const uint64_t *__restrict__ partials, int nblocks,
                                                         uint64_t *__restrict__ d_count) {
     __shared__ uint64_t s[BLOCK];
@@ -380,19 +439,39 @@ extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, c
         PCQ_HIP(hipHostMalloc((void **)&ctx->h_segments, cap * sizeof(DevSegment), hipHostMallocDefault));
         ctx->segments_cap = cap;
     }
+    static_assert(sizeof(DevClassSegment) <= sizeof(DevSegment), "the two segment tables share one buffer");
+    const int kind = preds[0].kind;
     // Build the segment table; it is uploaded only when it differs from the one already in HBM
     // (a repeated query re-launches without touching the pinned buffer, so no host-side wait).
     std::vector<DevSegment> table(nsegments);
+    memset(table.data(), 0, nsegments * sizeof(DevSegment));
     uint64_t tiles = 0, points = 0;
     for (size_t i = 0; i < nsegments; i++) {
-        if (preds[i].kind != PCQ_PRED_BOUNDS) return pcq_fail(PCQ_ERR_ARG, "count_batch: only bounds predicates");
+        if (preds[i].kind != kind) return pcq_fail(PCQ_ERR_ARG, "count_batch: mixed predicate kinds");
+        if (kind == PCQ_PRED_CLASS) {
+            if (cols[i].cls_stride != 1 || (!cols[i].cls && cols[i].n))
+                return pcq_fail(PCQ_ERR_ARG, "count_batch: LAST classification blocks only (stride 1)");
+            DevClassSegment g;
+            memset(&g, 0, sizeof g);
+            g.cls = (const uint8_t *)cols[i].cls;
+            g.n = cols[i].n;
+            g.head = (uint64_t)((16 - ((uintptr_t)g.cls & 15)) & 15);
+            if (g.head > g.n) g.head = g.n;
+            g.nvec = (g.n - g.head) / 16;
+            g.tile_begin = tiles;
+            g.pat = 0x01010101u * (uint32_t)preds[i].cls;
+            memcpy(&table[i], &g, sizeof g);
+            tiles += g.nvec / 256;
+            points += g.n;
+            continue;
+        }
+        if (kind != PCQ_PRED_BOUNDS) return pcq_fail(PCQ_ERR_ARG, "count_batch: bad predicate kind %d", kind);
         if (cols[i].xyz_stride != 12) return pcq_fail(PCQ_ERR_ARG, "count_batch: LAST positions blocks only (stride 12)");
         if (((uintptr_t)cols[i].xyz & 15) != 0) return pcq_fail(PCQ_ERR_ARG, "count_batch: positions block %zu not 16-byte aligned", i);
         DevPred dp;
         int rc = pcq_make_dev_pred(&preds[i], &dp);
         if (rc) return rc;
         DevSegment &g = table[i];
-        memset(&g, 0, sizeof g);
         g.xyz = reinterpret_cast<const int4 *>(cols[i].xyz);
         g.n = cols[i].n;
         g.tile_begin = tiles;
@@ -401,11 +480,24 @@ extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, c
         tiles += cols[i].n / TILE_POINTS;
         points += cols[i].n;
     }
-    if (ctx->segments_uploaded != nsegments || memcmp(ctx->h_segments, table.data(), nsegments * sizeof(DevSegment)) != 0) {
+    if (ctx->segments_uploaded != nsegments || ctx->segments_kind != kind ||
+        memcmp(ctx->h_segments, table.data(), nsegments * sizeof(DevSegment)) != 0) {
         PCQ_HIP(hipStreamSynchronize(s));  // the previous upload from the pinned table must have been consumed
         memcpy(ctx->h_segments, table.data(), nsegments * sizeof(DevSegment));
         PCQ_HIP(hipMemcpyAsync(ctx->d_segments, ctx->h_segments, nsegments * sizeof(DevSegment), hipMemcpyHostToDevice, s));
         ctx->segments_uploaded = nsegments;
+        ctx->segments_kind = kind;
+    }
+    if (kind == PCQ_PRED_CLASS) {
+        // one 4 KiB tile per wave per iteration; the class stream wants more waves in flight than K1
+        const int cgrid = grid_for(ctx, (uint64_t)WAVES * 4096, points ? points : 1, ctx->batch_blocks_per_cu + 1);
+        int crc = pcq_ensure_partials(ctx, (size_t)cgrid);
+        if (crc) return crc;
+        hipLaunchKernelGGL(k_class_count_batch, dim3(cgrid), dim3(BLOCK), 0, s, ctx->d_segments, (int)nsegments, tiles,
+                           ctx->d_partials);
+        hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, cgrid, device_total);
+        PCQ_HIP(hipGetLastError());
+        return PCQ_OK;
     }
     const int grid = grid_for(ctx, (uint64_t)WAVES * TILE_POINTS, points ? points : 1, ctx->batch_blocks_per_cu);
     int rc = pcq_ensure_partials(ctx, (size_t)grid);

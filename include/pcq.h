@@ -179,7 +179,9 @@ int pcq_scan_fd(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predica
                 pcq_collector *c);
 
 /* Count-only scan of many device-resident LAST files in ONE launch (files = independent units,
- * main.rs:153-161): segment i is scanned with preds[i]; the total is ADDED to *device_total. */
+ * main.rs:153-161): segment i is scanned with preds[i] (all bounds, over 16-byte aligned positions
+ * blocks — or all class, over classification blocks of any alignment); the total is ADDED to
+ * *device_total. */
 int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *preds,
                              size_t nsegments, uint64_t *device_total, void *stream);
 

@@ -246,3 +246,35 @@ def test_allreduce_entry_point_single_rank(gpu_ctx):
     gpu_ctx.to_host(out, d)
     gpu_ctx.free(d)
     assert int(out[0]) == 12345678901234567
+
+
+def test_class_count_batch_matches_sum_of_files(oracle, gpu_ctx):
+    files, cols, preds, expect = [], [], [], 0
+    try:
+        for i, (n, pad) in enumerate([(100_003, 0), (0, 3), (15, 7), (4096 + 17, 1), (70_001, 13), (1_000_003, 5)]):
+            spec = small_spec(700 + i, n, fmt=1)
+            image = oracle.synth_image(spec, transposed=True)
+            hdr = oracle.parse_header(image[:400].tobytes())
+            f = DevFile(gpu_ctx, image, hdr, pad=pad)
+            files.append(f)
+            cls = 6 if i % 2 == 0 else 2
+            oc = oracle.count_collector()
+            assert oracle.search_last_class(image, cls, oc) == 0
+            expect += oc.point_count()
+            oc.free()
+            cols.append(f.columns(True))
+            preds.append(pkg.Predicate.classification(cls))
+        total = gpu_ctx.alloc(16)
+        gpu_ctx.memset(total, 0, 16)
+        gpu_ctx.scan_dev_count_batch(cols, preds, total)
+        gpu_ctx.scan_dev_count_batch(cols, preds, total)
+        host = np.zeros(1, dtype=np.uint64)
+        gpu_ctx.to_host(host, total)
+        assert int(host[0]) == 2 * expect
+        # mixing kinds in one batch is rejected
+        with pytest.raises(pkg.PcqError):
+            gpu_ctx.scan_dev_count_batch(cols[:2], [preds[0], pkg.Predicate.bounds([0, 0, 0], [1, 1, 1])], total)
+        gpu_ctx.free(total)
+    finally:
+        for f in files:
+            f.free()

@@ -58,8 +58,9 @@ def main():
         counter = torch.zeros(2, dtype=torch.int64, device=dev)
         cc = ctx.count_collector(device_counter=counter.data_ptr())
         pc = pkg.Predicate.classification(6)
+        cpreds = [pc] * args.files
         variants = [int(v) for v in args.variants.split(",")]
-        configs = [(bpc, v) for bpc in [int(b) for b in args.blocks.split(",")] for v in variants + ["batch", "class"]]
+        configs = [(bpc, v) for bpc in [int(b) for b in args.blocks.split(",")] for v in variants + ["batch", "class", "cbatch"]]
         times = {c: [] for c in configs}
         k = 0
         for r in range(args.rounds + 2):  # interleaved rounds in one process (cdna guide rule 24)
@@ -70,6 +71,10 @@ def main():
                 if variant == "batch":
                     e0.record()
                     ctx.scan_dev_count_batch(cols, preds, counter.data_ptr(), stream)
+                    e1.record()
+                elif variant == "cbatch":
+                    e0.record()
+                    ctx.scan_dev_count_batch(cols, cpreds, counter.data_ptr(), stream)
                     e1.record()
                 else:
                     f = k % args.files
@@ -83,7 +88,7 @@ def main():
         for (bpc, variant), t in times.items():
             t.sort()
             med = t[len(t) // 2]
-            nbytes = n * (1 if variant == "class" else 12) * (args.files if variant == "batch" else 1)
+            nbytes = n * (1 if variant in ("class", "cbatch") else 12) * (args.files if variant in ("batch", "cbatch") else 1)
             print(f"blocks/cu={bpc:2d} variant={variant!s:6} median {med:8.4f} ms  min {t[0]:8.4f} ms  "
                   f"{nbytes / med / 1e6:9.1f} GB/s (min-time: {nbytes / t[0] / 1e6:9.1f})", flush=True)
         ctx.set_option("k1_variant", 0)
