@@ -430,10 +430,6 @@ static int table_alloc(pcq_ctx *ctx, DevGridTable *t, uint64_t cap, hipStream_t 
     return PCQ_OK;
 }
 
-int pcq_grid_alloc(pcq_ctx *ctx, pcq_collector *c, uint64_t cap) {
-    return table_alloc(ctx, &c->table, cap, ctx->stream);
-}
-
 static uint64_t next_pow2(uint64_t v) {
     uint64_t p = 1024;
     while (p < v) p <<= 1;
@@ -521,6 +517,7 @@ int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_
     pcq_ctx *ctx = c->ctx;
     hipStream_t s = ctx->stream;
     *out_n = 0;
+    if (c->last_stream && c->last_stream != s) PCQ_HIP(hipStreamSynchronize(c->last_stream));
     if (!c->table.keys) return PCQ_OK;
     PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->table.occupied, 8, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipStreamSynchronize(s));

@@ -111,9 +111,9 @@ extern "C" int pcq_shutdown(pcq_ctx *ctx) {
 
 int pcq_ensure_partials(pcq_ctx *ctx, size_t n) {
     if (n <= ctx->partials_cap) return PCQ_OK;
-    // The old buffer may still be referenced by enqueued kernels.
+    // The old buffer may still be referenced by kernels enqueued on the context's or a caller's stream.
     if (ctx->d_partials) {
-        PCQ_HIP(hipStreamSynchronize(ctx->stream));
+        PCQ_HIP(hipDeviceSynchronize());
         PCQ_HIP(hipFree(ctx->d_partials));
         ctx->d_partials = nullptr;
         ctx->partials_cap = 0;
@@ -274,6 +274,7 @@ extern "C" int pcq_collector_new_count(pcq_ctx *ctx, pcq_collector **out) {
     pcq_collector *c = *out;
     hipError_t e = hipMalloc((void **)&c->d_count, 16);
     if (e == hipSuccess) e = hipMemsetAsync(c->d_count, 0, 16, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // scans may be enqueued on a caller's stream
     if (e != hipSuccess) {
         delete c;
         *out = nullptr;
@@ -372,6 +373,7 @@ extern "C" int pcq_collector_has_points(const pcq_collector *c) { return c && c-
 extern "C" int pcq_collector_point_count(pcq_collector *c, uint64_t *out) {
     if (!c || !out) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_point_count: null argument");
     pcq_ctx *ctx = c->ctx;
+    if (c->last_stream && c->last_stream != ctx->stream) PCQ_HIP(hipStreamSynchronize(c->last_stream));
     switch (c->kind) {
     case COLL_COUNT:
         PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -392,6 +394,7 @@ extern "C" int pcq_collector_points(pcq_collector *c, pcq_point *out, uint64_t c
     pcq_ctx *ctx = c->ctx;
     *out_n = 0;
     if (c->kind == COLL_COUNT) return PCQ_OK;  // points() is None (collect_points.rs:87-93)
+    if (c->last_stream && c->last_stream != ctx->stream) PCQ_HIP(hipStreamSynchronize(c->last_stream));
     if (c->kind == COLL_BUFFER) {
         PCQ_HIP(hipStreamSynchronize(ctx->stream));
         *out_n = c->n_points;
@@ -491,6 +494,7 @@ static int scan_dev_impl(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predic
     rc = pcq_make_dev_pred(pred, &dp);
     if (rc) return rc;
     DevCols dc = to_dev_cols(cols);
+    c->last_stream = s;
     switch (c->kind) {
     case COLL_COUNT:
         return count_into(ctx, dc, dp, c->d_count, s);

@@ -151,6 +151,7 @@ struct pcq_collector {
     uint64_t table_used_bound = 0;      // host-side count of occupied slots after the last scan
     bool grid_has_alias = false;        // sticky: some key has seen an aliased cell (grid.hip pass R)
     uint64_t next_index = 0;            // file-order index the next scan starts at
+    hipStream_t last_stream = nullptr;  // stream of the most recent scan: accessors wait on it
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -173,7 +174,6 @@ int pcq_emit_prepare(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uin
 // grid.hip
 int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const DevPred &pred,
                   uint64_t matches_upper_bound, hipStream_t s);
-int pcq_grid_alloc(pcq_ctx *ctx, pcq_collector *c, uint64_t cap);
 void pcq_grid_release(pcq_collector *c);
 void pcq_grid_cache_clear(pcq_ctx *ctx);
 int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_t cap, uint64_t *out_n);
