@@ -196,3 +196,47 @@ def test_count_files_parallel_sums_per_file_counts(oracle):
         per_file.append(c.point_count())
     for threads in (1, 2, 8):
         assert oracle.count_files_parallel(images, 0, bmin, bmax, 0, threads) == sum(per_file)
+
+
+def test_oracle_matches_python_restatement_on_random_inputs(oracle):
+    """The independent Python restatement that derived the golden vectors (tests/golden/make_golden.py),
+    run live against the oracle on random inputs: SparseGrid folds (including power-of-two dims, points
+    on / beyond the max face, ties) and the box conversion."""
+    import importlib.util
+    import _oracle
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    rng = np.random.default_rng(2024)
+    for trial in range(300):
+        dims_target = int(rng.choice([1, 2, 3, 4, 7, 8, 10, 16, 33]))
+        cell = float(rng.choice([0.5, 1.0, 2.5]))
+        bmin = [float(v) for v in rng.choice([-5.0, 0.0, 100.25], size=3)]
+        bmax = [bmin[a] + dims_target * cell * float(rng.choice([1.0, 1.0, 0.93])) for a in range(3)]
+        g_py = mg.Grid(list(bmin), list(bmax), cell)
+        g_or = oracle.grid_collector(bmin, bmax, cell)
+        assert g_or.grid_params() == (g_py.dims, g_py.bits)
+        npts = int(rng.integers(1, 60))
+        lattice = rng.random() < 0.5  # lattice points produce exact ties and exact max-face hits
+        for i in range(npts):
+            if lattice:
+                p = [bmin[a] + float(rng.integers(-2, 2 * dims_target + 3)) * cell / 2 for a in range(3)]
+            else:
+                p = [float(rng.uniform(bmin[a] - cell, bmax[a] + cell)) for a in range(3)]
+            g_py.insert((p[0], p[1], p[2], i))
+            g_or.collect_one(p[0], p[1], p[2], cls=i % 256, r=i)
+        cells = sorted(g_py.cells.items())
+        assert list(g_or.grid_cells()) == [k for k, _ in cells], trial
+        assert [int(p["r"]) for p in g_or.points()] == [v[3] for _, v in cells], trial
+        g_or.free()
+    for trial in range(2000):
+        bmin = rng.uniform(-1e7, 1e7, 3)
+        bmax = bmin + rng.uniform(0, 1e6, 3) * rng.choice([0.0, 1.0, 1.0], 3)
+        sc = rng.choice([0.001, 0.01, 0.1, 0.25, 1.0, 3.0], 3)
+        off = rng.choice([0.0, 12345.678, -5e5], 3)
+        lmin, lmax, panic = mg.box_to_local(list(bmin), list(bmax), list(sc), list(off))
+        if panic:
+            with pytest.raises(_oracle.OracleError):
+                oracle.box_to_local(bmin, bmax, sc, off)
+        else:
+            assert oracle.box_to_local(bmin, bmax, sc, off) == (lmin, lmax)
