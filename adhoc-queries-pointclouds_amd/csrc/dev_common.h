@@ -81,6 +81,20 @@ __device__ __forceinline__ void store_point31(uint8_t *dst, const pcq_point &p) 
     for (int k = 0; k < 31; k++) dst[k] = s[k];
 }
 
+// The same record into a 32-byte aligned 32-byte slot as two 16-byte stores (byte 31 = 0).
+__device__ __forceinline__ void store_point_slot32(uint8_t *dst32, const pcq_point &p) {
+    const uint64_t bx = (uint64_t)__double_as_longlong(p.x), by = (uint64_t)__double_as_longlong(p.y),
+                   bz = (uint64_t)__double_as_longlong(p.z);
+    uint4 a, b;
+    a.x = (uint32_t)bx, a.y = (uint32_t)(bx >> 32), a.z = (uint32_t)by, a.w = (uint32_t)(by >> 32);
+    b.x = (uint32_t)bz, b.y = (uint32_t)(bz >> 32);
+    b.z = (uint32_t)p.r | ((uint32_t)p.g << 16);
+    b.w = (uint32_t)p.b | ((uint32_t)p.classification << 16);
+    uint4 *d = reinterpret_cast<uint4 *>(dst32);
+    d[0] = a;
+    d[1] = b;
+}
+
 __device__ __forceinline__ uint64_t hash64(uint64_t k) {
     k ^= k >> 33;
     k *= 0xff51afd7ed558ccdull;

@@ -7,6 +7,7 @@
 // cell (always, except the mask-aliasing case below) that fold is the lexicographic arg-min of
 // (squared distance, file-order index), computed here in three order-independent passes over the
 // matched points against an open-addressing hash table in HBM:
+// (one 32-byte slot per cell: key, distance, winner index, flags — one random access per probe):
 //   A  insert key; atomicMin of the f64 distance bits (monotone for d >= 0); a slot whose minimum
 //      was lowered in this scan has its winner index reset;
 //   B  points whose distance equals the slot minimum: atomicMin of the file-order index;
@@ -27,6 +28,12 @@ using namespace pcqdev;
 int pcq_emit_prepare(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint64_t *matches, hipStream_t s);
 
 namespace {
+
+// The count of occupied slots is kept in OCC_SHARDS counters on separate 128-byte lines (one
+// same-address atomic per inserting wave would serialise at ~88 atomics/us: 122 M new cells = 2 M waves).
+constexpr int OCC_SHARDS = 256;
+constexpr int OCC_STRIDE = 16;  // u64 units between shards
+constexpr size_t OCC_WORDS = (size_t)OCC_SHARDS * OCC_STRIDE + 16;  // + n_alias and padding
 
 constexpr uint8_t F_HAS_POINT = 1;  // pts[slot] holds a materialised winner
 constexpr uint8_t F_ALIAS = 2;      // key has seen a point whose unmasked cell differs from the masked one
@@ -71,13 +78,13 @@ __device__ __forceinline__ uint64_t find_or_insert(const DevGridTable &t, uint64
     const uint64_t m = t.cap - 1;
     uint64_t h = hash64(key) & m;
     for (;;) {
-        uint64_t k = __hip_atomic_load(&t.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint64_t k = __hip_atomic_load(&t.slots[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == key) return h;
         if (k == PCQ_EMPTY_KEY) {
-            const uint64_t prev = atomicCAS((unsigned long long *)&t.keys[h], (unsigned long long)PCQ_EMPTY_KEY,
+            const uint64_t prev = atomicCAS((unsigned long long *)&t.slots[h].key, (unsigned long long)PCQ_EMPTY_KEY,
                                             (unsigned long long)key);
             if (prev == PCQ_EMPTY_KEY) {
-                atomicAdd((unsigned long long *)t.occupied, 1ull);
+                atomicAdd((unsigned long long *)&t.occupied[(blockIdx.x & (OCC_SHARDS - 1)) * OCC_STRIDE], 1ull);
                 return h;
             }
             if (prev == key) return h;
@@ -90,7 +97,7 @@ __device__ __forceinline__ uint64_t find_slot(const DevGridTable &t, uint64_t ke
     const uint64_t m = t.cap - 1;
     uint64_t h = hash64(key) & m;
     for (;;) {
-        const uint64_t k = t.keys[h];
+        const uint64_t k = t.slots[h].key;
         if (k == key) return h;
         if (k == PCQ_EMPTY_KEY) return PCQ_NO_INDEX;  // cannot happen after pass A
         h = (h + 1) & m;
@@ -125,10 +132,10 @@ __global__ __launch_bounds__(BLOCK) void k_grid_pass_a(DevCols c, DevPred pr, De
         const uint64_t h = find_or_insert(t, ci.key);
         const double d = centre_dist(g, ci.cell, m.px, m.py, m.pz);
         const uint64_t db = (uint64_t)__double_as_longlong(d);
-        const uint64_t old = atomicMin((unsigned long long *)&t.dist[h], (unsigned long long)db);
-        if (db < old) t.widx[h] = PCQ_NO_INDEX;
+        const uint64_t old = atomicMin((unsigned long long *)&t.slots[h].dist, (unsigned long long)db);
+        if (db < old) t.slots[h].widx = PCQ_NO_INDEX;
         if (ci.alias) {
-            t.flags[h] |= F_ALIAS;  // racing writers all set the same bit; bit0 is not written in pass A
+            t.slots[h].nflags &= ~F_ALIAS;  // racing writers all clear the same bit; bit0 is not written in pass A
             atomicAdd((unsigned long long *)t.n_alias, 1ull);
         }
     }
@@ -143,8 +150,8 @@ __global__ __launch_bounds__(BLOCK) void k_grid_pass_b(DevCols c, DevPred pr, De
         const uint64_t h = find_slot(t, ci.key);
         if (h == PCQ_NO_INDEX) continue;
         const double d = centre_dist(g, ci.cell, m.px, m.py, m.pz);
-        if ((uint64_t)__double_as_longlong(d) == t.dist[h])
-            atomicMin((unsigned long long *)&t.widx[h], (unsigned long long)(c.first_index + i));
+        if ((uint64_t)__double_as_longlong(d) == t.slots[h].dist)
+            atomicMin((unsigned long long *)&t.slots[h].widx, (unsigned long long)(c.first_index + i));
     }
 }
 
@@ -156,12 +163,12 @@ __global__ __launch_bounds__(BLOCK) void k_grid_pass_c(DevCols c, DevPred pr, De
         const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
         const uint64_t h = find_slot(t, ci.key);
         if (h == PCQ_NO_INDEX) continue;
-        if (t.flags[h] & F_ALIAS) continue;  // resolved by pass R
-        if (t.widx[h] == c.first_index + i) {
+        if (!(t.slots[h].nflags & F_ALIAS)) continue;  // aliased key: resolved by pass R
+        if (t.slots[h].widx == c.first_index + i) {
             pcq_point pt;
             make_point(c, i, m.rp, pt);
-            store_point31(t.pts + h * 32, pt);
-            t.flags[h] |= F_HAS_POINT;
+            store_point_slot32(t.pts + h * 32, pt);
+            t.slots[h].nflags &= ~F_HAS_POINT;
         }
     }
 }
@@ -180,7 +187,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_pass_r(DevCols c, DevGrid g, Dev
         if (lkeys[q] == key) return;  // an earlier entry owns this key
     const uint64_t h = find_slot(t, key);
     if (h == PCQ_NO_INDEX) return;
-    bool has = (t.flags[h] & F_HAS_POINT) != 0;
+    bool has = !(t.slots[h].nflags & F_HAS_POINT);
     pcq_point cur;
     if (has) {
         const uint8_t *s = t.pts + h * 32;
@@ -209,7 +216,7 @@ __global__ __launch_bounds__(BLOCK) void k_grid_pass_r(DevCols c, DevGrid g, Dev
     }
     if (has) {
         store_point31(t.pts + h * 32, cur);
-        t.flags[h] |= F_HAS_POINT;
+        t.slots[h].nflags &= ~F_HAS_POINT;
     }
 }
 
@@ -225,7 +232,7 @@ __global__ __launch_bounds__(BLOCK) void k_alias_tile_counts(DevCols c, DevPred 
         if (m.pass) {
             const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
             const uint64_t h = find_slot(t, ci.key);
-            sel = h != PCQ_NO_INDEX && (t.flags[h] & F_ALIAS);
+            sel = h != PCQ_NO_INDEX && !(t.slots[h].nflags & F_ALIAS);
         }
         cnt += (uint32_t)__popcll(__ballot(sel));
     }
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(BLOCK) void k_alias_emit(DevCols c, DevPred pr, Dev
         if (m.pass) {
             const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
             const uint64_t h = find_slot(t, ci.key);
-            sel = h != PCQ_NO_INDEX && (t.flags[h] & F_ALIAS);
+            sel = h != PCQ_NO_INDEX && !(t.slots[h].nflags & F_ALIAS);
             key = ci.key;
         }
         const uint64_t mask = __ballot(sel);
@@ -303,23 +310,40 @@ __global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *__restrict__ counts
     if (threadIdx.x == 0) *total_out = s_carry;
 }
 
+// out[0] = occupied slots (sum of the shards), out[1] = aliased points seen in the last scan.
+__global__ __launch_bounds__(OCC_SHARDS) void k_sum_occupied(const uint64_t *__restrict__ occ, const uint64_t *__restrict__ n_alias,
+                                                             uint64_t *__restrict__ out) {
+    __shared__ uint64_t s[OCC_SHARDS];
+    s[threadIdx.x] = occ[threadIdx.x * OCC_STRIDE];
+    __syncthreads();
+    for (int off = OCC_SHARDS / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = s[0];
+        out[1] = *n_alias;
+    }
+}
+
 // Re-insert every used slot of `src` into `dst` (table growth).
 __global__ __launch_bounds__(BLOCK) void k_grid_rehash(DevGridTable src, DevGridTable dst) {
     const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t h = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; h < src.cap; h += nthreads) {
-        const uint64_t key = src.keys[h];
+        const GridSlot sl = src.slots[h];
+        const uint64_t key = sl.key;
         if (key == PCQ_EMPTY_KEY) continue;
         const uint64_t m = dst.cap - 1;
         uint64_t d = hash64(key) & m;
         for (;;) {
-            const uint64_t prev = atomicCAS((unsigned long long *)&dst.keys[d], (unsigned long long)PCQ_EMPTY_KEY,
+            const uint64_t prev = atomicCAS((unsigned long long *)&dst.slots[d].key, (unsigned long long)PCQ_EMPTY_KEY,
                                             (unsigned long long)key);
             if (prev == PCQ_EMPTY_KEY) break;
             d = (d + 1) & m;
         }
-        dst.dist[d] = src.dist[h];
-        dst.widx[d] = src.widx[h];
-        dst.flags[d] = src.flags[h];
+        dst.slots[d].dist = sl.dist;
+        dst.slots[d].widx = sl.widx;
+        dst.slots[d].nflags = sl.nflags;
         const uint4 *sp = reinterpret_cast<const uint4 *>(src.pts + h * 32);
         uint4 *dp = reinterpret_cast<uint4 *>(dst.pts + d * 32);
         dp[0] = sp[0];
@@ -334,7 +358,7 @@ __global__ __launch_bounds__(BLOCK) void k_drain_tile_counts(DevGridTable t, uin
     uint32_t cnt = 0;
     for (int j = 0; j < ITEMS; j++) {
         const uint64_t h = base + (uint64_t)j * BLOCK + threadIdx.x;
-        const bool used = h < t.cap && t.keys[h] != PCQ_EMPTY_KEY && (t.flags[h] & F_HAS_POINT);
+        const bool used = h < t.cap && t.slots[h].key != PCQ_EMPTY_KEY && !(t.slots[h].nflags & F_HAS_POINT);
         cnt += (uint32_t)__popcll(__ballot(used));
     }
     __shared__ uint32_t s_w[WAVES];
@@ -355,7 +379,7 @@ __global__ __launch_bounds__(BLOCK) void k_drain_emit(DevGridTable t, const uint
     uint64_t run = offsets[blockIdx.x];
     for (int j = 0; j < ITEMS; j++) {
         const uint64_t h = base + (uint64_t)j * BLOCK + threadIdx.x;
-        const bool used = h < t.cap && t.keys[h] != PCQ_EMPTY_KEY && (t.flags[h] & F_HAS_POINT);
+        const bool used = h < t.cap && t.slots[h].key != PCQ_EMPTY_KEY && !(t.slots[h].nflags & F_HAS_POINT);
         const uint64_t mask = __ballot(used);
         if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
         __syncthreads();
@@ -372,7 +396,7 @@ __global__ __launch_bounds__(BLOCK) void k_drain_emit(DevGridTable t, const uint
                 uint8_t *dp = out31 + pos * 31;
                 for (int k = 0; k < 31; k++) dp[k] = sp[k];
             }
-            if (keys_out) keys_out[pos] = t.keys[h];
+            if (keys_out) keys_out[pos] = t.slots[h].key;
         }
         run += all;
         __syncthreads();
@@ -382,11 +406,8 @@ __global__ __launch_bounds__(BLOCK) void k_drain_emit(DevGridTable t, const uint
 }  // namespace
 
 static void table_free(DevGridTable &t) {
-    if (t.keys) (void)hipFree(t.keys);
-    if (t.dist) (void)hipFree(t.dist);
-    if (t.widx) (void)hipFree(t.widx);
+    if (t.slots) (void)hipFree(t.slots);
     if (t.pts) (void)hipFree(t.pts);
-    if (t.flags) (void)hipFree(t.flags);
     if (t.occupied) (void)hipFree(t.occupied);
     t = DevGridTable{};
 }
@@ -397,7 +418,7 @@ void pcq_grid_cache_clear(pcq_ctx *ctx) { table_free(ctx->grid_cache); }
 void pcq_grid_release(pcq_collector *c) {
     DevGridTable &t = c->table;
     pcq_ctx *ctx = c->ctx;
-    if (t.keys && ctx && t.cap > ctx->grid_cache.cap) {
+    if (t.slots && ctx && t.cap > ctx->grid_cache.cap) {
         table_free(ctx->grid_cache);
         ctx->grid_cache = t;
         t = DevGridTable{};
@@ -408,25 +429,19 @@ void pcq_grid_release(pcq_collector *c) {
 
 static int table_alloc(pcq_ctx *ctx, DevGridTable *t, uint64_t cap, hipStream_t s) {
     *t = DevGridTable{};
-    if (ctx->grid_cache.keys && ctx->grid_cache.cap >= cap && ctx->grid_cache.cap <= 4 * cap) {
+    if (ctx->grid_cache.slots && ctx->grid_cache.cap >= cap && ctx->grid_cache.cap <= 4 * cap) {
         *t = ctx->grid_cache;  // reuse (a larger table only lowers the load factor)
         ctx->grid_cache = DevGridTable{};
         cap = t->cap;
     } else {
         t->cap = cap;
-        PCQ_HIP(hipMalloc((void **)&t->keys, cap * 8));
-        PCQ_HIP(hipMalloc((void **)&t->dist, cap * 8));
-        PCQ_HIP(hipMalloc((void **)&t->widx, cap * 8));
+        PCQ_HIP(hipMalloc((void **)&t->slots, cap * sizeof(GridSlot)));
         PCQ_HIP(hipMalloc((void **)&t->pts, cap * 32));
-        PCQ_HIP(hipMalloc((void **)&t->flags, cap));
-        PCQ_HIP(hipMalloc((void **)&t->occupied, 16));
-        t->n_alias = t->occupied + 1;
+        PCQ_HIP(hipMalloc((void **)&t->occupied, OCC_WORDS * 8));
+        t->n_alias = t->occupied + (size_t)OCC_SHARDS * OCC_STRIDE;
     }
-    PCQ_HIP(hipMemsetAsync(t->keys, 0xff, cap * 8, s));
-    PCQ_HIP(hipMemsetAsync(t->dist, 0xff, cap * 8, s));
-    PCQ_HIP(hipMemsetAsync(t->widx, 0xff, cap * 8, s));
-    PCQ_HIP(hipMemsetAsync(t->flags, 0, cap, s));
-    PCQ_HIP(hipMemsetAsync(t->occupied, 0, 16, s));
+    PCQ_HIP(hipMemsetAsync(t->slots, 0xff, cap * sizeof(GridSlot), s));  // all-ones = empty (flags are inverted)
+    PCQ_HIP(hipMemsetAsync(t->occupied, 0, OCC_WORDS * 8, s));
     return PCQ_OK;
 }
 
@@ -446,13 +461,13 @@ static int grid_blocks(pcq_ctx *ctx, uint64_t n) {
 // Make room for `additional` new cells: load factor <= 1/2.
 static int grid_reserve(pcq_ctx *ctx, pcq_collector *c, uint64_t additional, hipStream_t s) {
     const uint64_t need = next_pow2(2 * (c->table_used_bound + additional) + 1);
-    if (c->table.keys && c->table.cap >= need) return PCQ_OK;
-    if (!c->table.keys) return table_alloc(ctx, &c->table, need, s);
+    if (c->table.slots && c->table.cap >= need) return PCQ_OK;
+    if (!c->table.slots) return table_alloc(ctx, &c->table, need, s);
     DevGridTable nt;
     int rc = table_alloc(ctx, &nt, need, s);
     if (rc) return rc;
     // carry the counters over, then re-insert
-    PCQ_HIP(hipMemcpyAsync(nt.occupied, c->table.occupied, 16, hipMemcpyDeviceToDevice, s));
+    PCQ_HIP(hipMemcpyAsync(nt.occupied, c->table.occupied, OCC_WORDS * 8, hipMemcpyDeviceToDevice, s));
     hipLaunchKernelGGL(k_grid_rehash, dim3(grid_blocks(ctx, c->table.cap)), dim3(BLOCK), 0, s, c->table, nt);
     PCQ_HIP(hipGetLastError());
     PCQ_HIP(hipStreamSynchronize(s));
@@ -482,7 +497,8 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const Dev
     hipLaunchKernelGGL(k_grid_pass_a, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
     hipLaunchKernelGGL(k_grid_pass_b, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
     PCQ_HIP(hipGetLastError());
-    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, t.occupied, 16, hipMemcpyDeviceToHost, s));
+    hipLaunchKernelGGL(k_sum_occupied, dim3(1), dim3(OCC_SHARDS), 0, s, t.occupied, t.n_alias, ctx->d_scalars + 16);
+    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars + 16, 16, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipStreamSynchronize(s));
     c->table_used_bound = ctx->h_scalars[0];
     if (ctx->h_scalars[1]) c->grid_has_alias = true;  // sticky: flagged keys stay flagged
@@ -518,8 +534,9 @@ int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_
     hipStream_t s = ctx->stream;
     *out_n = 0;
     if (c->last_stream && c->last_stream != s) PCQ_HIP(hipStreamSynchronize(c->last_stream));
-    if (!c->table.keys) return PCQ_OK;
-    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->table.occupied, 8, hipMemcpyDeviceToHost, s));
+    if (!c->table.slots) return PCQ_OK;
+    hipLaunchKernelGGL(k_sum_occupied, dim3(1), dim3(OCC_SHARDS), 0, s, c->table.occupied, c->table.n_alias, ctx->d_scalars + 16);
+    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars + 16, 8, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipStreamSynchronize(s));
     const uint64_t n = ctx->h_scalars[0];
     *out_n = n;

@@ -80,16 +80,24 @@ struct DevGrid {
     uint32_t shift[3];    // 0, bits_x, bits_x + bits_y  (already & 63)
 };
 
-// HBM hash table behind the grid collector.
+// HBM hash table behind the grid collector.  One 32-byte slot holds everything the three passes
+// touch for a cell (key, best distance, winner index, flags), so a probe costs ONE random memory
+// access; the winner's record lives in a parallel 32-byte array.  A fresh table is all-ones:
+// key = empty, dist = +max, widx = none, and the flag bits are therefore stored INVERTED
+// (bit cleared = set).
+struct GridSlot {
+    uint64_t key;     // PCQ_EMPTY_KEY = free
+    uint64_t dist;    // f64 bits of the winning squared distance (monotone for d >= 0)
+    uint64_t widx;    // file-order index of the winner
+    uint32_t nflags;  // inverted: bit0 clear = pts[slot] holds a materialised point, bit1 clear = aliased key
+    uint32_t _pad;
+};
 struct DevGridTable {
-    uint64_t *keys;       // PCQ_EMPTY_KEY = free
-    uint64_t *dist;       // f64 bits of the winning squared distance (monotone for d >= 0)
-    uint64_t *widx;       // file-order index of the winner
-    uint8_t *pts;         // 32-byte slots holding the winner's pcq_point (31 bytes used)
-    uint8_t *flags;       // bit0: slot holds a materialised point, bit1: key saw an aliased cell
+    GridSlot *slots;
+    uint8_t *pts;         // 32-byte records: the winner's pcq_point (31 bytes used)
     uint64_t cap;         // power of two
-    uint64_t *occupied;   // device counter of used slots
-    uint64_t *n_alias;    // device counter of aliased points seen
+    uint64_t *occupied;   // sharded device counters of used slots
+    uint64_t *n_alias;    // device counter of aliased points seen in the current scan
 };
 
 constexpr uint64_t PCQ_EMPTY_KEY = ~0ull;
