@@ -1,0 +1,56 @@
+"""bench.py and __graft_entry__.smoke() on a GPU: the printed JSON line follows the driver's contract
+(small sizes here; the real run uses the defaults)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _check(line, n_gpus):
+    d = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Mpoints/s" and d["n_gpus"] == n_gpus and d["higher_is_better"] is True
+    assert d["vs_baseline"] is None and d["data"] == "synthetic" and d["dtype"] == "i32"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
+    assert abs(d["value"] - d["config"]["points"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6) / d["value"] < 1e-9
+    assert d["matches"] == d["config"]["points"]  # XL contains every generated point
+    return d
+
+
+def test_bench_json_contract_single_process():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--files", "4",
+                        "--points-per-file", "300007", "--cpu-sample-points", "100003"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1  # exactly one JSON line on stdout
+    d = _check(lines[0], 1)
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mpoints/s" and c["cores"] >= 1 and c["parity_on_sample"] is True
+
+
+def test_bench_under_torch_distributed_run_exercises_rccl():
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+                        "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3",
+                        "--warmup", "1", "--files", "4", "--points-per-file", "300007", "--no-cpu-baseline"],
+                       capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = _check(lines[0], 1)
+    assert d["cpu_baseline"] is None
+
+
+def test_smoke_entry_point():
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "smoke ok" in r.stdout
