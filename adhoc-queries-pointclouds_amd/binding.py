@@ -74,6 +74,11 @@ class DeviceInfo(C.Structure):
                 ("clock_khz", C.c_int)]
 
 
+class IndexStats(C.Structure):
+    _fields_ = [("chunks", C.c_uint64), ("skipped", C.c_uint64), ("whole", C.c_uint64), ("scanned", C.c_uint64),
+                ("built", C.c_uint64)]
+
+
 class SynthSpec(C.Structure):
     """include/pcq_synth.h: pcq_synth_spec (the test-side host generator uses the same layout)."""
     _fields_ = [("seed", C.c_uint64), ("n", C.c_uint64), ("format", C.c_uint32), ("n_classes", C.c_uint32),
@@ -126,6 +131,10 @@ def load_library() -> C.CDLL:
         "pcq_scan_fd": (C.c_int, [vp, C.c_int, P(Columns), P(Predicate), vp]),
         "pcq_scan_dev_count_batch": (C.c_int, [vp, P(Columns), P(Predicate), C.c_size_t, vp, vp]),
         "pcq_allreduce_sum_u64": (C.c_int, [P(vp), P(vp), C.c_int]),
+        "pcq_index_new": (C.c_int, [vp, P(vp)]),
+        "pcq_index_free": (C.c_int, [vp]),
+        "pcq_index_get_stats": (C.c_int, [vp, P(IndexStats)]),
+        "pcq_scan_dev_indexed": (C.c_int, [vp, P(Columns), P(Predicate), vp, vp, vp]),
         "pcq_device_alloc": (C.c_int, [vp, u64, P(vp)]),
         "pcq_device_free": (C.c_int, [vp, vp]),
         "pcq_copy_to_device": (C.c_int, [vp, vp, vp, u64]),
@@ -310,6 +319,24 @@ class Context:
         ca = (Columns * n)(*cols)
         pa = (Predicate * n)(*preds)
         _check(self.lib.pcq_scan_dev_count_batch(self.handle, ca, pa, n, C.c_void_p(device_total), C.c_void_p(stream)))
+
+    # chunk index --------------------------------------------------------------------------------
+    def index_new(self) -> int:
+        h = C.c_void_p()
+        _check(self.lib.pcq_index_new(self.handle, C.byref(h)))
+        return h.value
+
+    def index_free(self, ix: int) -> None:
+        self.lib.pcq_index_free(C.c_void_p(ix))
+
+    def index_stats(self, ix: int) -> dict:
+        st = IndexStats()
+        _check(self.lib.pcq_index_get_stats(C.c_void_p(ix), C.byref(st)))
+        return {k: getattr(st, k) for k, _ in IndexStats._fields_}
+
+    def scan_dev_indexed(self, cols: Columns, pred: Predicate, ix: int, coll: Collector, stream: Optional[int] = None) -> None:
+        _check(self.lib.pcq_scan_dev_indexed(self.handle, C.byref(cols), C.byref(pred), C.c_void_p(ix), coll.handle,
+                                             C.c_void_p(stream)))
 
     def synth_fill(self, spec: SynthSpec, first: int, count: int, d_xyz: Optional[int], d_cls: Optional[int],
                    stream: Optional[int] = None) -> None:

@@ -1,0 +1,377 @@
+// chunk_index.hip — on-the-fly chunk index for device-resident LAST columns.
+//
+// The reference's authors list this as their own next step (improvements.md:3-10): "while scanning
+// first (without an index) we can create a chunk header for each chunk, but only for the queried
+// attribute(s): if we query by bounds, we compute an AABB for each chunk; if we query by object class,
+// a class histogram ... upon further scans, we first consult the index to find the matching chunks".
+//
+// Here the index is a side output of the count scans of a file that stays resident in HBM:
+//   * bounds: the first bounds scan also writes the integer AABB of every 4096-point chunk (24 B per
+//     48 KiB of positions).  Later bounds scans classify each chunk against the query box: disjoint ->
+//     skipped, contained -> counted without reading a byte, straddling -> scanned with the same
+//     mask-algebra tile kernel as K1 (scan_count.hip).
+//   * class: the first class scan writes a 256-bin histogram per 65536-point chunk; later class
+//     counts are sums of one bin per chunk and read no classification bytes at all.
+// Results are identical to the unindexed scans (tests/test_gpu_index.py).  The index never takes part
+// in bench.py: skipping work inside the timed region would invalidate the north-star measurement.
+#include <new>
+
+#include "pcq_internal.h"
+
+namespace {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = 4;
+constexpr int TILE_POINTS = 256;
+constexpr int CHUNK_TILES = 16;                           // 16 wave-tiles = 4096 points = 48 KiB
+constexpr uint64_t CHUNK_POINTS = (uint64_t)CHUNK_TILES * TILE_POINTS;
+constexpr uint64_t CLASS_CHUNK = 65536;
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+constexpr uint64_t R0 = 0x9249249249249249ull, R1 = 0x2492492492492492ull, R2 = 0x4924924924924924ull;
+__device__ __forceinline__ constexpr uint64_t start_lanes(int s) { return (s % 3) == 0 ? R0 : ((s % 3) == 1 ? R2 : R1); }
+__device__ __forceinline__ v4i ld_nt(const v4i *p) { return __builtin_nontemporal_load(p); }
+
+struct LaneBox {
+    int lo[3];
+    uint32_t w[3];
+};
+__device__ __forceinline__ LaneBox rotate_box(const int32_t (&lo)[3], const uint32_t (&w)[3], int lane) {
+    const int r = lane % 3;
+    LaneBox b;
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int c = (r + t) % 3;
+        b.lo[t] = c == 0 ? lo[0] : (c == 1 ? lo[1] : lo[2]);
+        b.w[t] = c == 0 ? w[0] : (c == 1 ? w[1] : w[2]);
+    }
+    return b;
+}
+
+// Same mask algebra as scan_count.hip::tile_count_regs (see there for the derivation).
+__device__ __forceinline__ uint32_t tile_count_regs(const v4i (&v)[3], const LaneBox &b) {
+    uint64_t m[3][4];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int t = (k + j) % 3;
+            m[k][j] = __ballot((uint32_t)(v[k][j] - b.lo[t]) <= b.w[t]);
+        }
+    uint32_t cnt = 0;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const uint64_t m0 = m[k][0], m1 = m[k][1], m2 = m[k][2], m3 = m[k][3];
+        const uint64_t c0 = k < 2 ? m[k < 2 ? k + 1 : k][0] : 0ull;
+        const uint64_t c1 = k < 2 ? m[k < 2 ? k + 1 : k][1] : 0ull;
+        const uint64_t n0 = (m0 >> 1) | (c0 << 63), n1 = (m1 >> 1) | (c1 << 63);
+        const uint64_t a = m1 & m2, t0 = m0 & a, t1 = a & m3, bb = m3 & n0, t2 = m2 & bb, t3 = bb & n1;
+        const uint64_t s012 = (t0 & start_lanes(k)) | (t1 & start_lanes(k + 1)) | (t2 & start_lanes(k + 2));
+        cnt += (uint32_t)__popcll(s012) + (uint32_t)__popcll(t3 & start_lanes(k + 3));
+    }
+    return cnt;
+}
+
+struct ChunkBox {  // integer AABB of one chunk
+    int32_t mn[3], mx[3];
+};
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// First bounds scan: count + per-chunk AABB in one pass.  One block per chunk iteration; each of the
+// four waves takes four of the chunk's sixteen tiles.
+__global__ __launch_bounds__(BLOCK) void k_index_build_bounds(const v4i *__restrict__ base, uint64_t nchunks, DevPred pred,
+                                                              ChunkBox *__restrict__ boxes, uint64_t *__restrict__ partials) {
+    __shared__ int s_mn[WAVES][3], s_mx[WAVES][3];
+    __shared__ uint64_t s_cnt[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const LaneBox lb = rotate_box(pred.lo, pred.width, lane);
+    const int r = lane % 3;
+    uint64_t total = 0;
+    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        int mn[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, mx[3] = {INT32_MIN, INT32_MIN, INT32_MIN};  // per ROTATED component
+#pragma unroll
+        for (int q = 0; q < CHUNK_TILES / WAVES; q++) {
+            const v4i *tile = base + (ch * CHUNK_TILES + (uint64_t)wave * (CHUNK_TILES / WAVES) + q) * 192;
+            v4i v[3];
+            v[0] = ld_nt(tile + lane);
+            v[1] = ld_nt(tile + 64 + lane);
+            v[2] = ld_nt(tile + 128 + lane);
+            if (!pred.empty) total += tile_count_regs(v, lb);
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int t = (k + j) % 3;  // dword (k, lane, j) is component (lane%3 + t) % 3
+                    mn[t] = min(mn[t], v[k][j]);
+                    mx[t] = max(mx[t], v[k][j]);
+                }
+        }
+        // un-rotate: actual component c lives in rotated slot (c - r + 3) % 3
+        int amn[3], amx[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int t = (c - r + 3) % 3;
+            amn[c] = t == 0 ? mn[0] : (t == 1 ? mn[1] : mn[2]);
+            amx[c] = t == 0 ? mx[0] : (t == 1 ? mx[1] : mx[2]);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int a = wave_min(amn[c]), b = wave_max(amx[c]);
+            if (lane == 0) s_mn[wave][c] = a, s_mx[wave][c] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int c = threadIdx.x;
+            int a = s_mn[0][c], b = s_mx[0][c];
+            for (int w = 1; w < WAVES; w++) a = min(a, s_mn[w][c]), b = max(b, s_mx[w][c]);
+            boxes[ch].mn[c] = a;
+            boxes[ch].mx[c] = b;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) s_cnt[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// Later bounds scans: classify each chunk, read only the straddling ones.  stats[0..2] += chunks
+// skipped / counted whole / scanned.
+__global__ __launch_bounds__(BLOCK) void k_index_count_bounds(const v4i *__restrict__ base, uint64_t nchunks, DevPred pred,
+                                                              const ChunkBox *__restrict__ boxes, uint64_t *__restrict__ partials,
+                                                              unsigned long long *__restrict__ stats) {
+    __shared__ uint64_t s_cnt[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const LaneBox lb = rotate_box(pred.lo, pred.width, lane);
+    int64_t hi[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) hi[a] = (int64_t)pred.lo[a] + (int64_t)pred.width[a];
+    uint64_t total = 0;
+    uint32_t n_skip = 0, n_full = 0, n_scan = 0;
+    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        const ChunkBox cb = boxes[ch];  // block-uniform
+        bool disjoint = pred.empty != 0, inside = !pred.empty;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            disjoint |= (int64_t)cb.mx[a] < (int64_t)pred.lo[a] || (int64_t)cb.mn[a] > hi[a];
+            inside &= (int64_t)cb.mn[a] >= (int64_t)pred.lo[a] && (int64_t)cb.mx[a] <= hi[a];
+        }
+        if (disjoint) {
+            n_skip++;
+            continue;
+        }
+        if (inside) {
+            if (threadIdx.x == 0) total += CHUNK_POINTS;
+            n_full++;
+            continue;
+        }
+        n_scan++;
+#pragma unroll
+        for (int q = 0; q < CHUNK_TILES / WAVES; q++) {
+            const v4i *tile = base + (ch * CHUNK_TILES + (uint64_t)wave * (CHUNK_TILES / WAVES) + q) * 192;
+            v4i v[3];
+            v[0] = ld_nt(tile + lane);
+            v[1] = ld_nt(tile + 64 + lane);
+            v[2] = ld_nt(tile + 128 + lane);
+            const uint32_t c = tile_count_regs(v, lb);
+            if (lane == 0) total += c;
+        }
+    }
+    // `total` was accumulated on lane 0 of each wave (thread 0 for whole chunks)
+    if (lane == 0) s_cnt[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        if (n_skip) atomicAdd(&stats[0], (unsigned long long)n_skip);
+        if (n_full) atomicAdd(&stats[1], (unsigned long long)n_full);
+        if (n_scan) atomicAdd(&stats[2], (unsigned long long)n_scan);
+    }
+}
+
+// First class scan: 256-bin histogram per 65536-point chunk (LDS atomics), one block per chunk.
+__global__ __launch_bounds__(BLOCK) void k_index_build_class(const uint8_t *__restrict__ cls, uint64_t n, uint64_t nchunks,
+                                                             uint32_t *__restrict__ hist) {
+    __shared__ uint32_t s_h[256];
+    for (uint64_t ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        s_h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t first = ch * CLASS_CHUNK;
+        const uint64_t cnt = n - first < CLASS_CHUNK ? n - first : CLASS_CHUNK;
+        for (uint64_t i = threadIdx.x; i < cnt; i += BLOCK) atomicAdd(&s_h[cls[first + i]], 1u);
+        __syncthreads();
+        hist[ch * 256 + threadIdx.x] = s_h[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(BLOCK) void k_index_count_class(const uint32_t *__restrict__ hist, uint64_t nchunks, uint32_t cls,
+                                                             uint64_t *__restrict__ d_count) {
+    __shared__ uint64_t s[BLOCK];
+    uint64_t t = 0;
+    for (uint64_t ch = threadIdx.x; ch < nchunks; ch += BLOCK) t += hist[ch * 256 + cls];
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd((unsigned long long *)d_count, (unsigned long long)s[0]);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_index_finish(const uint64_t *__restrict__ partials, int nblocks, uint64_t *__restrict__ d_count) {
+    __shared__ uint64_t s[BLOCK];
+    uint64_t t = 0;
+    for (int i = threadIdx.x; i < nblocks; i += BLOCK) t += partials[i];
+    s[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = BLOCK / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd((unsigned long long *)d_count, (unsigned long long)s[0]);
+}
+
+}  // namespace
+
+struct pcq_index {
+    pcq_ctx *ctx = nullptr;
+    // bounds part
+    const void *xyz = nullptr;
+    uint64_t n_xyz = 0, nchunks = 0;
+    ChunkBox *d_boxes = nullptr;
+    // class part
+    const void *cls = nullptr;
+    uint64_t n_cls = 0, ncchunks = 0;
+    uint32_t *d_hist = nullptr;
+    // statistics of the last indexed bounds scan
+    unsigned long long *d_stats = nullptr;
+    pcq_index_stats last = {};
+    hipStream_t stats_stream = nullptr;  // non-null: `last` must be completed from d_stats (fetched lazily)
+};
+
+extern "C" int pcq_index_new(pcq_ctx *ctx, pcq_index **out) {
+    if (!ctx || !out) return pcq_fail(PCQ_ERR_ARG, "pcq_index_new: null argument");
+    *out = nullptr;
+    pcq_index *ix = new (std::nothrow) pcq_index();
+    if (!ix) return pcq_fail(PCQ_ERR_NOMEM, "pcq_index_new: out of memory");
+    ix->ctx = ctx;
+    hipError_t e = hipMalloc((void **)&ix->d_stats, 4 * sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        delete ix;
+        return pcq_fail(PCQ_ERR_HIP, "pcq_index_new: %s", hipGetErrorString(e));
+    }
+    *out = ix;
+    return PCQ_OK;
+}
+
+extern "C" int pcq_index_free(pcq_index *ix) {
+    if (!ix) return PCQ_OK;
+    (void)hipDeviceSynchronize();
+    if (ix->d_boxes) (void)hipFree(ix->d_boxes);
+    if (ix->d_hist) (void)hipFree(ix->d_hist);
+    if (ix->d_stats) (void)hipFree(ix->d_stats);
+    delete ix;
+    return PCQ_OK;
+}
+
+extern "C" int pcq_index_get_stats(pcq_index *ix, pcq_index_stats *out) {
+    if (!ix || !out) return pcq_fail(PCQ_ERR_ARG, "pcq_index_get_stats: null argument");
+    if (ix->stats_stream) {  // the counters of the last indexed bounds scan are still on the device
+        unsigned long long h[3] = {0, 0, 0};
+        PCQ_HIP(hipStreamSynchronize(ix->stats_stream));
+        PCQ_HIP(hipMemcpy(h, ix->d_stats, sizeof h, hipMemcpyDeviceToHost));
+        ix->last.skipped = h[0];
+        ix->last.whole = h[1];
+        ix->last.scanned = h[2];
+        ix->stats_stream = nullptr;
+    }
+    *out = ix->last;
+    return PCQ_OK;
+}
+
+extern "C" int pcq_scan_dev_indexed(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_index *ix,
+                                    pcq_collector *c, void *stream) {
+    if (!ctx || !cols || !pred || !ix || !c) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_dev_indexed: null argument");
+    if (c->kind != COLL_COUNT) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_dev_indexed: count collectors only");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    c->last_stream = s;
+    DevPred dp;
+    int rc = pcq_make_dev_pred(pred, &dp);
+    if (rc) return rc;
+    const int max_blocks = ctx->num_cus * 8;
+    if (pred->kind == PCQ_PRED_BOUNDS) {
+        if (cols->xyz_stride != 12 || ((uintptr_t)cols->xyz & 15) != 0 || cols->n < CHUNK_POINTS)
+            return pcq_scan_dev(ctx, cols, pred, c, stream);  // layout the index does not cover: plain scan
+        const uint64_t nchunks = cols->n / CHUNK_POINTS;
+        const uint64_t rest_first = nchunks * CHUNK_POINTS;
+        const int grid = (int)(nchunks < (uint64_t)max_blocks ? nchunks : (uint64_t)max_blocks);
+        rc = pcq_ensure_partials(ctx, (size_t)grid);
+        if (rc) return rc;
+        const bool built = ix->d_boxes && ix->xyz == cols->xyz && ix->n_xyz == cols->n;
+        ix->last = pcq_index_stats{};
+        ix->last.chunks = nchunks;
+        if (!built) {
+            if (ix->d_boxes) PCQ_HIP(hipFree(ix->d_boxes));
+            ix->d_boxes = nullptr;
+            PCQ_HIP(hipMalloc((void **)&ix->d_boxes, nchunks * sizeof(ChunkBox)));
+            hipLaunchKernelGGL(k_index_build_bounds, dim3(grid), dim3(BLOCK), 0, s, reinterpret_cast<const v4i *>(cols->xyz), nchunks, dp,
+                               ix->d_boxes, ctx->d_partials);
+            ix->xyz = cols->xyz;
+            ix->n_xyz = cols->n;
+            ix->nchunks = nchunks;
+            ix->last.built = 1;
+            ix->last.scanned = nchunks;
+        } else {
+            PCQ_HIP(hipMemsetAsync(ix->d_stats, 0, 4 * sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(k_index_count_bounds, dim3(grid), dim3(BLOCK), 0, s, reinterpret_cast<const v4i *>(cols->xyz), nchunks, dp,
+                               ix->d_boxes, ctx->d_partials, ix->d_stats);
+        }
+        hipLaunchKernelGGL(k_index_finish, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, grid, c->d_count);
+        PCQ_HIP(hipGetLastError());
+        ix->stats_stream = built ? s : nullptr;  // fetched lazily by pcq_index_get_stats: no sync on the scan path
+        if (rest_first < cols->n) {  // the ragged end (< one chunk) is always scanned
+            pcq_columns tail = *cols;
+            tail.xyz = (const uint8_t *)cols->xyz + 12 * rest_first;
+            tail.cls = nullptr;
+            tail.rgb = nullptr;
+            tail.n = cols->n - rest_first;
+            return pcq_scan_dev(ctx, &tail, pred, c, stream);
+        }
+        return PCQ_OK;
+    }
+    // class
+    if (cols->cls_stride != 1 || !cols->cls) return pcq_scan_dev(ctx, cols, pred, c, stream);
+    const uint64_t ncc = (cols->n + CLASS_CHUNK - 1) / CLASS_CHUNK;
+    if (ncc == 0) return PCQ_OK;
+    const bool built = ix->d_hist && ix->cls == cols->cls && ix->n_cls == cols->n;
+    ix->stats_stream = nullptr;
+    ix->last = pcq_index_stats{};
+    ix->last.chunks = ncc;
+    if (!built) {
+        if (ix->d_hist) PCQ_HIP(hipFree(ix->d_hist));
+        ix->d_hist = nullptr;
+        PCQ_HIP(hipMalloc((void **)&ix->d_hist, ncc * 256 * sizeof(uint32_t)));
+        const int grid = (int)(ncc < (uint64_t)max_blocks ? ncc : (uint64_t)max_blocks);
+        hipLaunchKernelGGL(k_index_build_class, dim3(grid), dim3(BLOCK), 0, s, (const uint8_t *)cols->cls, cols->n, ncc, ix->d_hist);
+        ix->cls = cols->cls;
+        ix->n_cls = cols->n;
+        ix->ncchunks = ncc;
+        ix->last.built = 1;
+        ix->last.scanned = ncc;
+    } else {
+        ix->last.whole = ncc;  // answered from the histograms: no classification byte is read
+    }
+    hipLaunchKernelGGL(k_index_count_class, dim3(1), dim3(BLOCK), 0, s, ix->d_hist, ncc, (uint32_t)pred->cls, c->d_count);
+    PCQ_HIP(hipGetLastError());
+    return PCQ_OK;
+}

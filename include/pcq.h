@@ -185,6 +185,29 @@ int pcq_scan_fd(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predica
 int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *preds,
                              size_t nsegments, uint64_t *device_total, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * On-the-fly chunk index for device-resident LAST columns — the reference authors' own next step
+ * (improvements.md:3-10), SURVEY.md §8f-3.  The first bounds (class) count scan of a file through
+ * pcq_scan_dev_indexed also records the integer AABB of every 4096-point chunk (a 256-bin class
+ * histogram per 65536-point chunk); later scans of the SAME columns consult it: chunks disjoint from
+ * the box are skipped, chunks inside it are counted without being read, only straddling chunks are
+ * scanned (class counts are answered from the histograms alone).  Results are identical to
+ * pcq_scan_dev; count collectors only; layouts the index does not cover fall through to pcq_scan_dev.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct pcq_index pcq_index;
+typedef struct pcq_index_stats {
+    uint64_t chunks;   /* chunks covered by the last indexed scan                       */
+    uint64_t skipped;  /* ... disjoint from the query box: not read                     */
+    uint64_t whole;    /* ... inside the box / answered from the histogram: not read    */
+    uint64_t scanned;  /* ... read                                                      */
+    uint64_t built;    /* 1 when the last scan built the index (it read everything)     */
+} pcq_index_stats;
+int pcq_index_new(pcq_ctx *ctx, pcq_index **out);
+int pcq_index_free(pcq_index *ix);
+int pcq_index_get_stats(pcq_index *ix, pcq_index_stats *out);
+int pcq_scan_dev_indexed(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_index *ix,
+                         pcq_collector *c, void *stream);
+
 /* The one collective of the path (main.rs:164-180) for callers that drive n GPUs from ONE process:
  * device_counters[i] (8 bytes in ctxs[i]'s HBM, e.g. of pcq_collector_new_count_at) all become the sum
  * over i — a single RCCL all-reduce(sum, u64, count = 1) over an intra-node communicator (xGMI).
