@@ -1,7 +1,7 @@
 """End-to-end wall clock of the `query` CLI (files on disk, page cache warm) next to the oracle CLI
-(the C restatement of the reference's `query --optimized --parallel`, one thread... the oracle CLI is
-single-threaded; the multi-threaded oracle number is bench.py's cpu_baseline).  Developer tool: the
-numbers go to DESIGN.md, not to the bench line.
+(the C restatement of the reference's `query --optimized --parallel`; the oracle CLI is single-threaded,
+the multi-threaded oracle number is bench.py's cpu_baseline).  Manual check kept under tests/ because it
+uses the oracle; the numbers go to DESIGN.md, not to the bench line.
 """
 import argparse
 import importlib
@@ -12,7 +12,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _oracle  # noqa: E402  (file generator)

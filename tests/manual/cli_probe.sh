@@ -1,7 +1,7 @@
 #!/bin/bash
 # developer probe: where the CLI's wall time goes (PCQ_TIMING=1) on 16 x 20 M-point LAST files
 set -e
-ROOT=$(cd "$(dirname "$0")/.." && pwd)
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 D=$(mktemp -d /tmp/pcq_probe_XXXX)
 python3 - "$D" <<PY
 import sys, importlib, os
