@@ -1,6 +1,9 @@
 // scan_generic.hip — layout-generic scan kernels (any column strides: LAST column blocks or LAS
 // AoS records), used where the count-only fast paths of scan_count.hip do not apply:
 //   * strided count            — LAS bounds/class count (las.rs:101-119, :221-231), unaligned LAST
+//                                (one record per lane: 4.1-5.9 TB/s of record bytes; an LDS-tiled variant
+//                                with 16-byte coalesced loads was measured and was NOT faster,
+//                                profiles/r01_las_aos_count_rate.log)
 //   * order-preserving emit    — BufferCollector semantics (collect_points.rs:29-31): matches are
 //                                appended in file order, as 31-byte Point records built like
 //                                last.rs:137-163.
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, co
 int pcq_launch_generic_count(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint64_t *d_count,
                              hipStream_t s) {
     if (cols.n == 0) return PCQ_OK;
+    if (pred.kind == PCQ_PRED_BOUNDS && pred.empty) return PCQ_OK;
     uint64_t want = (cols.n + BLOCK * 4 - 1) / (BLOCK * 4);
     const uint64_t cap = (uint64_t)ctx->num_cus * (uint64_t)ctx->grid_blocks_per_cu;
     const int grid = (int)(want < cap ? want : cap);
