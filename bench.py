@@ -81,6 +81,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-file-launch", action="store_true", help="one launch per file instead of one batched launch")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="tuning: persistent blocks per CU (0 = library default)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank rehearsal on a single-GPU box: every rank uses device 0 and the gloo backend "
+                         "(RCCL refuses two ranks on one device); numbers from such a run are not a measurement")
     args = ap.parse_args()
 
     # stdout carries exactly ONE JSON line: native libraries (the RCCL banner, rocprof) write to fd 1,
@@ -99,13 +102,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or "RANK" in os.environ  # under torch.distributed.run the RCCL path is exercised even at N=1
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     pkg = importlib.import_module("adhoc-queries-pointclouds_amd")
     binding = importlib.import_module("adhoc-queries-pointclouds_amd.binding")
