@@ -1,0 +1,68 @@
+// membench.hip — read-only HBM streaming reference kernels (developer tool, include/pcq_synth.h).
+// They do nothing but load and XOR, with the SAME access shapes the scan kernels use, so that the
+// scan kernels' achieved GB/s can be compared with what the memory system delivers for a pure read
+// stream on the same device (a measured ceiling instead of an assumed one).
+#include "pcq_internal.h"
+#include "pcq_synth.h"
+
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// shape 0: K1's shape — a wave reads 3 KiB tiles (three 1 KiB wave-loads), tile-stride persistent loop
+// shape 1: one 16-byte load per lane per iteration, grid-stride
+// shape 2: four independent 16-byte loads per lane per iteration (4 KiB per wave in flight)
+// shape 3: eight loads per lane per iteration
+template <int SHAPE, bool NT>
+__global__ __launch_bounds__(256) void k_read_only(const v4i *__restrict__ p, uint64_t nvec, uint32_t *__restrict__ sink) {
+    const uint64_t tid = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * 256;
+    v4i acc = {0, 0, 0, 0};
+    auto ld = [&](uint64_t i) { return NT ? __builtin_nontemporal_load(p + i) : p[i]; };
+    if (SHAPE == 0) {
+        const int lane = threadIdx.x & 63;
+        const uint64_t wave = tid >> 6, nwaves = nthreads >> 6, tiles = nvec / 192;
+        for (uint64_t t = wave; t < tiles; t += nwaves) {
+            const uint64_t b = t * 192 + lane;
+            const v4i a = ld(b), c = ld(b + 64), d = ld(b + 128);
+            acc ^= a ^ c ^ d;
+        }
+    } else {
+        constexpr int U = SHAPE == 1 ? 1 : (SHAPE == 2 ? 4 : 8);
+        uint64_t i = tid;
+        for (; i + (U - 1) * nthreads < nvec; i += U * nthreads) {
+            v4i v[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) v[u] = ld(i + u * nthreads);
+#pragma unroll
+            for (int u = 0; u < U; u++) acc ^= v[u];
+        }
+    }
+    const uint32_t x = (uint32_t)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
+    if (x == 0x9e3779b9u) sink[0] = x;  // practically never true: keeps the loads alive
+}
+
+}  // namespace
+
+extern "C" int pcq_membench_read(pcq_ctx *ctx, const void *d_buf, uint64_t bytes, int shape, int nontemporal, int blocks_per_cu,
+                                 void *stream) {
+    if (!ctx || !d_buf || ((uintptr_t)d_buf & 15)) return pcq_fail(PCQ_ERR_ARG, "pcq_membench_read: bad buffer");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const uint64_t nvec = bytes / 16;
+    const int grid = ctx->num_cus * (blocks_per_cu > 0 ? blocks_per_cu : 4);
+    const v4i *p = reinterpret_cast<const v4i *>(d_buf);
+    uint32_t *sink = reinterpret_cast<uint32_t *>(ctx->d_scalars + 32);
+#define LAUNCH(SH)                                                                                         \
+    if (nontemporal) hipLaunchKernelGGL((k_read_only<SH, true>), dim3(grid), dim3(256), 0, s, p, nvec, sink); \
+    else hipLaunchKernelGGL((k_read_only<SH, false>), dim3(grid), dim3(256), 0, s, p, nvec, sink);
+    switch (shape) {
+    case 0: LAUNCH(0) break;
+    case 1: LAUNCH(1) break;
+    case 2: LAUNCH(2) break;
+    case 3: LAUNCH(3) break;
+    default: return pcq_fail(PCQ_ERR_ARG, "pcq_membench_read: shape 0..3");
+    }
+#undef LAUNCH
+    PCQ_HIP(hipGetLastError());
+    return PCQ_OK;
+}

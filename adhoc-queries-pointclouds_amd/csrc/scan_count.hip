@@ -159,7 +159,8 @@ __device__ __forceinline__ void block_store_partial(uint64_t wave_total, uint64_
 
 // K1.  VARIANT 0: mask algebra (default) · 1: dwordx3 per lane · 2: 48-byte lane stride
 //      · 3: mask algebra, two tiles in flight per wave · 4: mask algebra, plain (temporal) loads
-//      · 5: mask algebra, each wave owns two ADJACENT tiles (6 KiB contiguous), six loads in flight.
+//      · 5: mask algebra, each wave owns two ADJACENT tiles (6 KiB contiguous), six loads in flight
+//      · 6: mask algebra with software prefetch of the wave's next tile.
 template <int VARIANT>
 __global__ __launch_bounds__(BLOCK) void k_bounds_count_xyz12(const v4i *__restrict__ base, uint64_t n,
                                                               DevPred pred, uint64_t *__restrict__ partials) {
@@ -176,6 +177,25 @@ __global__ __launch_bounds__(BLOCK) void k_bounds_count_xyz12(const v4i *__restr
             total += tile_count_masks(base + (t + stride) * 192, lane, lb);
         }
         if (t < tiles) total += tile_count_masks(base + t * 192, lane, lb);
+    } else if (VARIANT == 6) {
+        // software prefetch: the loads of the wave's NEXT tile are issued before the current tile is
+        // evaluated, so a wave always has a tile in flight while its SALU/VALU work runs
+        uint64_t t = wave_id;
+        v4i cur[3], nxt[3];
+        if (t < tiles) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) cur[k] = ld_nt(base + t * 192 + 64 * k + lane);
+        }
+        for (; t < tiles; t += stride) {
+            const uint64_t tn = t + stride;
+            if (tn < tiles) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) nxt[k] = ld_nt(base + tn * 192 + 64 * k + lane);
+            }
+            total += tile_count_regs(cur, lb);
+#pragma unroll
+            for (int k = 0; k < 3; k++) cur[k] = nxt[k];
+        }
     } else if (VARIANT == 5) {
         const uint64_t pairs = tiles / 2;
         for (uint64_t t = wave_id; t < pairs; t += stride) {
@@ -397,6 +417,7 @@ int pcq_launch_bounds_count_xyz12(pcq_ctx *ctx, const void *d_xyz, uint64_t n, c
     case 3: hipLaunchKernelGGL(k_bounds_count_xyz12<3>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     case 4: hipLaunchKernelGGL(k_bounds_count_xyz12<4>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     case 5: hipLaunchKernelGGL(k_bounds_count_xyz12<5>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
+    case 6: hipLaunchKernelGGL(k_bounds_count_xyz12<6>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     default: hipLaunchKernelGGL(k_bounds_count_xyz12<0>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     }
     hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, grid, d_count);

@@ -39,6 +39,13 @@ typedef struct pcq_synth_spec {
 int pcq_synth_fill_dev(pcq_ctx *ctx, const pcq_synth_spec *spec, uint64_t first, uint64_t count,
                        void *d_xyz, void *d_cls, void *stream);
 
+/* Developer tool: a read-only streaming kernel over `bytes` of device memory (16-byte aligned) in one
+ * of the access shapes the scan kernels use (0 = K1's 3 KiB wave tiles, 1/2/3 = 1/4/8 independent
+ * 16-byte loads per lane, grid-stride), optionally non-temporal.  Asynchronous; time it with events.
+ * Gives the measured read-stream ceiling the scan kernels are compared with (tools/hbm_read_ceiling.py). */
+int pcq_membench_read(pcq_ctx *ctx, const void *d_buf, uint64_t bytes, int shape, int nontemporal,
+                      int blocks_per_cu, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
