@@ -166,7 +166,8 @@ __global__ __launch_bounds__(BLOCK) void k_bounds_count_xyz12(const v4i *__restr
                                                               DevPred pred, uint64_t *__restrict__ partials) {
     const int lane = threadIdx.x & 63;
     const uint64_t tiles = n / TILE_POINTS;
-    const uint64_t wave_id = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    // readfirstlane: the wave index is uniform, so the tile loop runs on the scalar unit
+    const uint64_t wave_id = (uint64_t)blockIdx.x * WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t stride = (uint64_t)gridDim.x * WAVES;
     uint64_t total = 0;  // wave-uniform
     const LaneBox lb = rotate_box(pred.lo, pred.width, lane);
@@ -237,7 +238,7 @@ __global__ __launch_bounds__(BLOCK) void k_bounds_count_xyz12(const v4i *__restr
 __global__ __launch_bounds__(BLOCK) void k_bounds_count_batch(const DevSegment *__restrict__ segs, int nseg,
                                                               uint64_t total_tiles, uint64_t *__restrict__ partials) {
     const int lane = threadIdx.x & 63;
-    const uint64_t wave_id = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const uint64_t wave_id = (uint64_t)blockIdx.x * WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t stride = (uint64_t)gridDim.x * WAVES;
     uint64_t total = 0;
     int s = 0;
@@ -332,7 +333,7 @@ __device__ __forceinline__ const DevClassSegment &cseg(const DevSegment *raw, in
 __global__ __launch_bounds__(BLOCK) void k_class_count_batch(const DevSegment *__restrict__ raw, int nseg,
                                                              uint64_t total_tiles, uint64_t *__restrict__ partials) {
     const int lane = threadIdx.x & 63;
-    const uint64_t wave_id = (uint64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+    const uint64_t wave_id = (uint64_t)blockIdx.x * WAVES + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t stride = (uint64_t)gridDim.x * WAVES;
     uint32_t cnt = 0;
     int s = 0;
