@@ -103,6 +103,7 @@ public:
     // ResultCollector::points_ref (Some only for the buffer collector)
     virtual const std::vector<Point> *points_ref();
     virtual Status point_count(size_t *out);
+    bool has_points() const { return pcq_collector_has_points(handle_) != 0; }
     pcq_collector *handle() const { return handle_; }
     pcq_ctx *context() const { return ctx_; }
     uint64_t next_index = 0;  // file-order index of the next scanned point (first-seen-wins bookkeeping)
@@ -174,9 +175,14 @@ public:
     virtual ~PointDumper() = default;
     virtual Status dump_points(const Point *points, size_t n) = 0;
     virtual size_t num_dumped_points() const = 0;
+    // false: only the NUMBER of points is used (IgnoreDumper, dump_points.rs:28-33) — the driver then
+    // asks the collector for its count instead of copying every record out of HBM
+    virtual bool wants_points() const { return true; }
+    // true when points()/points_ref() is Some for this collector kind (main.rs:135-141)
 };
 class IgnoreDumper : public PointDumper {
 public:
+    bool wants_points() const override { return false; }
     Status dump_points(const Point *, size_t n) override {
         dumped_ += n;
         return Status::Ok();

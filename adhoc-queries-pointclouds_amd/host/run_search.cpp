@@ -202,6 +202,12 @@ Status FileDumper::dump_points(const Point *points, size_t n) {
 
 // ---- drain shared by both drivers (main.rs:135-141 / :164-180) ---------------------------------------------
 static Status drain(ResultCollector &c, PointDumper &dumper, std::optional<size_t> *num_matches) {
+    if (c.has_points() && !dumper.wants_points()) {  // same observable behaviour, no device-to-host copy
+        size_t n = 0;
+        Status st = c.point_count(&n);
+        if (!st.ok()) return st;
+        return dumper.dump_points(nullptr, n);
+    }
     if (const std::vector<Point> *ref = c.points_ref()) return dumper.dump_points(ref->data(), ref->size());
     if (auto pts = c.points()) return dumper.dump_points(pts->data(), pts->size());
     size_t n = 0;
