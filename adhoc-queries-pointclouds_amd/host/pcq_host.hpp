@@ -212,9 +212,15 @@ Status get_total_bounds(const std::vector<std::string> &files, AABB *out);
 // Creates the collector for one worker: Result<Box<dyn ResultCollector>> of main.rs:24.
 using CollectorFactoryFn = std::function<Status(pcq_ctx *, std::unique_ptr<ResultCollector> *)>;
 
+struct FileStat {  // filled by the drivers when RunOptions::stats is set (extra flag --stats-json)
+    std::string path;
+    int device = 0;
+    double search_ms = 0;
+};
 struct RunOptions {
     std::vector<int> devices = {0};  // GPUs to use; files are the independent units (main.rs:153-161)
     int threads_per_device = 2;      // host threads feeding each GPU in --parallel mode
+    std::vector<FileStat> *stats = nullptr;
 };
 // stdout lines go through `print` (so tests can capture them).
 using PrintFn = std::function<void(const std::string &)>;

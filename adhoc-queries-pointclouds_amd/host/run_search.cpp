@@ -228,7 +228,11 @@ Status run_search_sequential(const std::vector<std::string> &files, const Search
     if (!st.ok()) return st;
     for (const auto &f : files) {  // :131-133
         SearchLog log;
+        const auto t_f = std::chrono::steady_clock::now();
         st = searcher.search_file(f, impl, *collector, &log);
+        if (opt.stats)
+            opt.stats->push_back({f, opt.devices.empty() ? 0 : opt.devices[0],
+                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f).count()});
         if (log.las_record_size >= 0) print("Point record size: " + std::to_string(log.las_record_size));  // las.rs:73
         if (!st.ok()) return st;
     }
@@ -250,6 +254,7 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
     std::vector<Status> results(nfiles);
     std::vector<SearchLog> logs(nfiles);
     std::vector<int> file_device(nfiles, 0);
+    std::vector<double> file_ms(nfiles, 0.0);
     std::atomic<size_t> next{0};
     std::vector<int> devices = opt.devices.empty() ? std::vector<int>{0} : opt.devices;
     const int tpd = opt.threads_per_device < 1 ? 1 : opt.threads_per_device;
@@ -283,6 +288,7 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
                 Status st = factory(ctx, &collectors[i]);  // :156
                 if (st.ok()) st = searcher.search_file(files[i], impl, *collectors[i], &logs[i]);  // :158
                 results[i] = st;
+                file_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f).count();
                 if (getenv("PCQ_TIMING"))
                     fprintf(stderr, "[pcq] file %zu searched in %.1f ms\n", i,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f).count());
@@ -344,6 +350,8 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         cv.notify_all();
     }
     for (auto &th : pool) th.join();
+    if (opt.stats)
+        for (size_t i = 0; i < nfiles; i++) opt.stats->push_back({files[i], file_device[i], file_ms[i]});
     if (!final_status.ok()) return final_status;
     if (matches) print("Found " + std::to_string(*matches) + " matching points");  // :178-180
     return Status::Ok();
@@ -352,7 +360,8 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
 // ---- main.rs:191-319 ---------------------------------------------------------------------------------------------
 int query_main(int argc, const char *const *argv, const PrintFn &out, const PrintFn &err) {
     const auto t_start = std::chrono::steady_clock::now();  // :192
-    std::optional<std::string> input, bounds_s, class_s, output, density_s;
+    std::optional<std::string> input, bounds_s, class_s, output, density_s, stats_json;
+    std::vector<FileStat> file_stats;
     bool parallel = false, optimized = false;
     RunOptions opt;
     opt.devices = {0};
@@ -367,6 +376,7 @@ int query_main(int argc, const char *const *argv, const PrintFn &out, const Prin
         else if (a == "--density") dst = &density_s;
         else if (a == "--parallel") { parallel = true; continue; }
         else if (a == "--optimized") { optimized = true; continue; }
+        else if (a == "--stats-json") dst = &stats_json;  // extra flag: machine-readable timing sidecar
         else if (a == "--gpus" || a == "--device" || a == "--threads-per-gpu") dst = &ext_val;  // extra flags (not in the reference)
         else if (a == "-h" || a == "--help") {
             out("I/O experiments 0.1\nLAS I/O experiments (MI355X-native predicate path)\n\nUSAGE:\n    query [FLAGS] [OPTIONS] --input <FILE>\n\n"
@@ -374,7 +384,8 @@ int query_main(int argc, const char *const *argv, const PrintFn &out, const Prin
                 "OPTIONS:\n        --bounds <BOUNDS>    \"minX;minY;minZ;maxX;maxY;maxZ\"\n        --class <CLASS>      object class (u8)\n"
                 "        --density <DENSITY>  maximum density (grid cell size)\n    -i, --input <FILE>       file or directory\n"
                 "    -o, --output <OUTPUT>    output directory\n        --gpus <N>           (extra) number of GPUs to shard files over\n"
-                "        --device <D>         (extra) first GPU to use\n        --threads-per-gpu <T> (extra) host threads feeding each GPU");
+                "        --device <D>         (extra) first GPU to use\n        --threads-per-gpu <T> (extra) host threads feeding each GPU\n"
+                "        --stats-json <PATH>  (extra) write per-file timings as JSON");
             return 0;
         } else {
             err("error: Found argument '" + a + "' which wasn't expected, or isn't valid in this context");
@@ -506,6 +517,7 @@ int query_main(int argc, const char *const *argv, const PrintFn &out, const Prin
     }
     const SearchImplementation impl = optimized ? SearchImplementation::Optimized : SearchImplementation::Regular;  // :283-287
 
+    if (stats_json) opt.stats = &file_stats;
     out("Searching " + std::to_string(input_files.size()) + " files...");  // :289
 
     st = parallel ? run_search_parallel(input_files, *searcher, impl, factory, *dumper, opt, out)
@@ -527,6 +539,23 @@ int query_main(int argc, const char *const *argv, const PrintFn &out, const Prin
     char line[256];
     snprintf(line, sizeof line, "Searched %.2f MiB in %.2fs (throughput: %.2fMiB/s)", total_file_size_mib, elapsed, throughput_mibs);  // :313-316
     out(line);
+    if (stats_json) {  // sidecar: never changes stdout
+        if (FILE *f = fopen(stats_json->c_str(), "w")) {
+            fprintf(f, "{\"files\": %zu, \"bytes\": %llu, \"seconds\": %.6f, \"parallel\": %s, \"gpus\": %zu, \"per_file\": [", input_files.size(),
+                    (unsigned long long)total_file_size, elapsed, parallel ? "true" : "false", opt.devices.size());
+            for (size_t i = 0; i < file_stats.size(); i++) {
+                std::string esc;
+                for (char ch : file_stats[i].path) {
+                    if (ch == '"' || ch == '\\') esc += '\\';
+                    esc += ch;
+                }
+                fprintf(f, "%s{\"path\": \"%s\", \"device\": %d, \"search_ms\": %.3f}", i ? ", " : "", esc.c_str(), file_stats[i].device,
+                        file_stats[i].search_ms);
+            }
+            fprintf(f, "]}\n");
+            fclose(f);
+        }
+    }
     return 0;
 }
 

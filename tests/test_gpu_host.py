@@ -350,6 +350,19 @@ def test_cli_density_with_output_dir_writes_one_file_per_grid(files, tmp_path):
         assert len(written) == len([l for l in body_p if l.startswith("Writing ")])
 
 
+def test_cli_extra_flags_do_not_change_stdout(files, tmp_path):
+    d = os.path.dirname(files[0])
+    base = ["-i", d, "--optimized", "--parallel", "--bounds", "0;-400;-100;200;0;100"]
+    rc0, body0, _, _ = _cli(QUERY, base)
+    sj = tmp_path / "stats.json"
+    rc1, body1, _, err = _cli(QUERY, base + ["--gpus", "1", "--threads-per-gpu", "3", "--stats-json", str(sj)])
+    assert rc0 == rc1 == 0, err
+    assert sorted(body0) == sorted(body1)
+    st = json.load(open(sj))
+    assert st["files"] == 8 and len(st["per_file"]) == 8 and st["gpus"] == 1 and st["parallel"] is True
+    assert sorted(e["path"] for e in st["per_file"]) == sorted(files)
+
+
 def test_cli_single_file_and_output_dir(oracle, files, tmp_path):
     path = [f for f in files if f.endswith("f2.last")][0]
     out = tmp_path / "out"
