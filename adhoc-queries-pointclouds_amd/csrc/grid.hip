@@ -10,8 +10,9 @@
 // (one 32-byte slot per cell: key, distance, winner index, flags — one random access per probe):
 //   A  insert key; atomicMin of the f64 distance bits (monotone for d >= 0); a slot whose minimum
 //      was lowered in this scan has its winner index reset;
-//   B  points whose distance equals the slot minimum: atomicMin of the file-order index;
-//   C  the unique winner materialises its 31-byte Point into the slot.
+//   B  points whose distance equals the slot minimum: atomicMin of the file-order index; the first
+//      such point of a cell materialises its 31-byte Point at once (it is almost always the only one);
+//   C  only when pass B saw an exact distance tie: the winners are re-derived from the final indices.
 // Scans into one collector are issued in file order with increasing `first_index`, which keeps
 // "first seen wins" across chunks and across files (sequential mode, main.rs:129-133).
 //
@@ -141,6 +142,10 @@ __global__ __launch_bounds__(BLOCK) void k_grid_pass_a(DevCols c, DevPred pr, De
     }
 }
 
+// Pass B also materialises: the FIRST candidate of a cell in this scan (atomicMin found "no index")
+// writes its record right away — for almost every cell it is the only point at the minimum distance.
+// A second candidate (an exact distance tie, or a tie with the winner of an earlier scan) only bumps
+// `ties`; pass C, which re-derives the winners from the final indices, then runs for that scan only.
 __global__ __launch_bounds__(BLOCK) void k_grid_pass_b(DevCols c, DevPred pr, DevGrid g, DevGridTable t) {
     const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < c.n; i += nthreads) {
@@ -150,8 +155,18 @@ __global__ __launch_bounds__(BLOCK) void k_grid_pass_b(DevCols c, DevPred pr, De
         const uint64_t h = find_slot(t, ci.key);
         if (h == PCQ_NO_INDEX) continue;
         const double d = centre_dist(g, ci.cell, m.px, m.py, m.pz);
-        if ((uint64_t)__double_as_longlong(d) == t.slots[h].dist)
-            atomicMin((unsigned long long *)&t.slots[h].widx, (unsigned long long)(c.first_index + i));
+        if ((uint64_t)__double_as_longlong(d) != t.slots[h].dist) continue;
+        const uint64_t prev = atomicMin((unsigned long long *)&t.slots[h].widx, (unsigned long long)(c.first_index + i));
+        if (prev == PCQ_NO_INDEX) {
+            if (t.slots[h].nflags & F_ALIAS) {  // inverted flag: set = NOT aliased (aliased keys belong to pass R)
+                pcq_point pt;
+                make_point(c, i, m.rp, pt);
+                store_point_slot32(t.pts + h * 32, pt);
+                t.slots[h].nflags &= ~F_HAS_POINT;
+            }
+        } else {
+            atomicAdd((unsigned long long *)(t.n_alias + 1), 1ull);
+        }
     }
 }
 
@@ -310,7 +325,7 @@ __global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *__restrict__ counts
     if (threadIdx.x == 0) *total_out = s_carry;
 }
 
-// out[0] = occupied slots (sum of the shards), out[1] = aliased points seen in the last scan.
+// out[0] = occupied slots (sum of the shards), out[1] = aliased points, out[2] = distance ties of the last scan.
 __global__ __launch_bounds__(OCC_SHARDS) void k_sum_occupied(const uint64_t *__restrict__ occ, const uint64_t *__restrict__ n_alias,
                                                              uint64_t *__restrict__ out) {
     __shared__ uint64_t s[OCC_SHARDS];
@@ -322,7 +337,8 @@ __global__ __launch_bounds__(OCC_SHARDS) void k_sum_occupied(const uint64_t *__r
     }
     if (threadIdx.x == 0) {
         out[0] = s[0];
-        out[1] = *n_alias;
+        out[1] = n_alias[0];
+        out[2] = n_alias[1];  // distance ties seen by pass B
     }
 }
 
@@ -493,14 +509,15 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const Dev
     const DevGrid &g = c->grid;
     DevGridTable &t = c->table;
     // alias counter is per scan
-    PCQ_HIP(hipMemsetAsync(t.n_alias, 0, 8, s));
+    PCQ_HIP(hipMemsetAsync(t.n_alias, 0, 16, s));  // aliased points, distance ties
     hipLaunchKernelGGL(k_grid_pass_a, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
     hipLaunchKernelGGL(k_grid_pass_b, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
     PCQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_sum_occupied, dim3(1), dim3(OCC_SHARDS), 0, s, t.occupied, t.n_alias, ctx->d_scalars + 16);
-    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars + 16, 16, hipMemcpyDeviceToHost, s));
+    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars + 16, 24, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipStreamSynchronize(s));
     c->table_used_bound = ctx->h_scalars[0];
+    const uint64_t n_ties = ctx->h_scalars[2];
     if (ctx->h_scalars[1]) c->grid_has_alias = true;  // sticky: flagged keys stay flagged
     if (c->grid_has_alias) {
         const uint64_t nblocks = (cols.n + TILE - 1) / TILE;
@@ -524,7 +541,7 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const Dev
             if (e != hipSuccess) return pcq_fail(PCQ_ERR_HIP, "grid pass R failed: %s", hipGetErrorString(e));
         }
     }
-    hipLaunchKernelGGL(k_grid_pass_c, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
+    if (n_ties) hipLaunchKernelGGL(k_grid_pass_c, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
     PCQ_HIP(hipGetLastError());
     return PCQ_OK;
 }
