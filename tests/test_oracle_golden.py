@@ -240,3 +240,37 @@ def test_oracle_matches_python_restatement_on_random_inputs(oracle):
                 oracle.box_to_local(bmin, bmax, sc, off)
         else:
             assert oracle.box_to_local(bmin, bmax, sc, off) == (lmin, lmax)
+
+
+def test_integer_path_agrees_with_f64_contains_away_from_the_box_faces(oracle):
+    """Semantic cross-check: with isotropic scales the optimized integer predicate
+    (last.rs:98-135) and the straightforward f64 `contains` on world coordinates (the non-optimized
+    path, last.rs:198-206) may only disagree for points within one scale unit of a box face — the
+    documented truncation effect — never elsewhere."""
+    import importlib
+    specs = importlib.import_module("adhoc-queries-pointclouds_amd.synth_specs")
+    rng = np.random.default_rng(99)
+    for trial in range(20):
+        scale = float(rng.choice([0.001, 0.01, 0.1, 0.5]))
+        offset = [float(v) for v in rng.choice([0.0, -1234.5, 250000.0], size=3)]
+        spec = specs._spec(7000 + trial, 40_000, 0, (scale,) * 3, offset, (-20000, -20000, -2000), (40001, 40001, 4001))
+        image = oracle.synth_image(spec, True)
+        xyz, _ = oracle.synth_columns(spec)
+        world = xyz.astype(np.float64) * scale + np.array(offset)
+        c = world[rng.integers(0, len(world))]
+        half = rng.uniform(0.5, 8000.0, size=3) * scale
+        bmin, bmax = [float(v) for v in c - half], [float(v) for v in c + half]
+        buf = oracle.buffer_collector()
+        assert oracle.search_last_bounds(image, bmin, bmax, buf) == 0
+        got = buf.points()
+        int_match = np.zeros(len(world), dtype=bool)
+        # recover which points matched: positions are unique enough to look up by value
+        lmin, lmax = oracle.box_to_local(bmin, bmax, [scale] * 3, offset)
+        int_match = np.all((xyz >= lmin) & (xyz <= lmax), axis=1)
+        assert int(int_match.sum()) == len(got)
+        f64_match = np.all((world >= np.array(bmin)) & (world <= np.array(bmax)), axis=1)
+        differ = int_match != f64_match
+        if differ.any():
+            d = np.minimum(np.abs(world[differ] - np.array(bmin)), np.abs(world[differ] - np.array(bmax))).min(axis=1)
+            assert np.all(d <= 1.0000001 * scale), (trial, d.max(), scale)
+        buf.free()
