@@ -42,7 +42,48 @@ __global__ __launch_bounds__(256) void k_read_only(const v4i *__restrict__ p, ui
     if (x == 0x9e3779b9u) sink[0] = x;  // practically never true: keeps the loads alive
 }
 
+// wave-tile reader with LOADS 1 KiB loads per tile (contiguous LOADS KiB per wave), any block size
+template <int LOADS>
+__global__ void k_read_tiles(const v4i *__restrict__ p, uint64_t nvec, uint32_t *__restrict__ sink) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t waves_per_block = blockDim.x >> 6;
+    const uint64_t wave = (uint64_t)blockIdx.x * waves_per_block + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t nwaves = (uint64_t)gridDim.x * waves_per_block, tiles = nvec / (64 * LOADS);
+    v4i acc = {0, 0, 0, 0};
+    for (uint64_t t = wave; t < tiles; t += nwaves) {
+        const uint64_t b = t * 64 * LOADS + lane;
+        v4i v[LOADS];
+#pragma unroll
+        for (int u = 0; u < LOADS; u++) v[u] = __builtin_nontemporal_load(p + b + 64 * u);
+#pragma unroll
+        for (int u = 0; u < LOADS; u++) acc ^= v[u];
+    }
+    const uint32_t x = (uint32_t)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
+    if (x == 0x9e3779b9u) sink[0] = x;
+}
+
 }  // namespace
+
+extern "C" int pcq_membench_read_tiles(pcq_ctx *ctx, const void *d_buf, uint64_t bytes, int loads, int threads, int blocks,
+                                       void *stream) {
+    if (!ctx || !d_buf || ((uintptr_t)d_buf & 15) || threads < 64 || threads > 1024 || (threads & 63) || blocks < 1)
+        return pcq_fail(PCQ_ERR_ARG, "pcq_membench_read_tiles: bad arguments");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const uint64_t nvec = bytes / 16;
+    const v4i *p = reinterpret_cast<const v4i *>(d_buf);
+    uint32_t *sink = reinterpret_cast<uint32_t *>(ctx->d_scalars + 32);
+    switch (loads) {
+    case 1: hipLaunchKernelGGL(k_read_tiles<1>, dim3(blocks), dim3(threads), 0, s, p, nvec, sink); break;
+    case 2: hipLaunchKernelGGL(k_read_tiles<2>, dim3(blocks), dim3(threads), 0, s, p, nvec, sink); break;
+    case 3: hipLaunchKernelGGL(k_read_tiles<3>, dim3(blocks), dim3(threads), 0, s, p, nvec, sink); break;
+    case 4: hipLaunchKernelGGL(k_read_tiles<4>, dim3(blocks), dim3(threads), 0, s, p, nvec, sink); break;
+    case 6: hipLaunchKernelGGL(k_read_tiles<6>, dim3(blocks), dim3(threads), 0, s, p, nvec, sink); break;
+    case 8: hipLaunchKernelGGL(k_read_tiles<8>, dim3(blocks), dim3(threads), 0, s, p, nvec, sink); break;
+    default: return pcq_fail(PCQ_ERR_ARG, "pcq_membench_read_tiles: loads in {1,2,3,4,6,8}");
+    }
+    PCQ_HIP(hipGetLastError());
+    return PCQ_OK;
+}
 
 extern "C" int pcq_membench_read(pcq_ctx *ctx, const void *d_buf, uint64_t bytes, int shape, int nontemporal, int blocks_per_cu,
                                  void *stream) {

@@ -80,7 +80,7 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
     }
     if (const char *e = getenv("PCQ_K1_VARIANT")) {
         const int v = atoi(e);
-        if (v >= 0 && v <= 6) ctx->k1_variant = v;
+        if (v >= 0 && v <= 7) ctx->k1_variant = v;
     }
     *out_ctx = ctx;
     return PCQ_OK;
@@ -150,7 +150,7 @@ extern "C" int pcq_ctx_synchronize(pcq_ctx *ctx) {
 extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return pcq_fail(PCQ_ERR_ARG, "pcq_set_option: null argument");
     if (!strcmp(key, "k1_variant")) {
-        if (value < 0 || value > 6) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..6");
+        if (value < 0 || value > 7) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..7");
         ctx->k1_variant = (int)value;
     } else if (!strcmp(key, "blocks_per_cu")) {
         if (value < 1 || value > 16) return pcq_fail(PCQ_ERR_ARG, "blocks_per_cu must be 1..16");

@@ -160,7 +160,8 @@ __device__ __forceinline__ void block_store_partial(uint64_t wave_total, uint64_
 // K1.  VARIANT 0: mask algebra (default) · 1: dwordx3 per lane · 2: 48-byte lane stride
 //      · 3: mask algebra, two tiles in flight per wave · 4: mask algebra, plain (temporal) loads
 //      · 5: mask algebra, each wave owns two ADJACENT tiles (6 KiB contiguous), six loads in flight
-//      · 6: mask algebra with software prefetch of the wave's next tile.
+//      · 6: mask algebra with software prefetch of the wave's next tile (compiler-scheduled)
+//      · 7: the same pipeline with inline-asm loads and counted waits.
 template <int VARIANT>
 __global__ __launch_bounds__(BLOCK) void k_bounds_count_xyz12(const v4i *__restrict__ base, uint64_t n,
                                                               DevPred pred, uint64_t *__restrict__ partials) {
@@ -179,23 +180,79 @@ __global__ __launch_bounds__(BLOCK) void k_bounds_count_xyz12(const v4i *__restr
         }
         if (t < tiles) total += tile_count_masks(base + t * 192, lane, lb);
     } else if (VARIANT == 6) {
-        // software prefetch: the loads of the wave's NEXT tile are issued before the current tile is
-        // evaluated, so a wave always has a tile in flight while its SALU/VALU work runs
-        uint64_t t = wave_id;
-        v4i cur[3], nxt[3];
-        if (t < tiles) {
+        // software pipeline, ping-pong registers (no copies): while tile A is evaluated the loads of
+        // tile B are in flight and vice versa, so each wave keeps 3 KiB outstanding at all times.
+        // The prefetch is unconditional (index clamped to the wave's current tile at the tail, an L2
+        // hit) so that the compiler can count exactly which loads an evaluation has to wait for.
+        if (wave_id < tiles) {
+            v4i a[3], b[3];
+            uint64_t t = wave_id;
 #pragma unroll
-            for (int k = 0; k < 3; k++) cur[k] = ld_nt(base + t * 192 + 64 * k + lane);
-        }
-        for (; t < tiles; t += stride) {
-            const uint64_t tn = t + stride;
-            if (tn < tiles) {
+            for (int k = 0; k < 3; k++) a[k] = ld_nt(base + t * 192 + 64 * k + lane);
+            for (;;) {
+                const uint64_t t1 = t + stride;
+                const uint64_t t1c = t1 < tiles ? t1 : t;
 #pragma unroll
-                for (int k = 0; k < 3; k++) nxt[k] = ld_nt(base + tn * 192 + 64 * k + lane);
+                for (int k = 0; k < 3; k++) b[k] = ld_nt(base + t1c * 192 + 64 * k + lane);
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE the evaluation it overlaps
+                total += tile_count_regs(a, lb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t1 >= tiles) break;
+                const uint64_t t2 = t1 + stride;
+                const uint64_t t2c = t2 < tiles ? t2 : t1;
+#pragma unroll
+                for (int k = 0; k < 3; k++) a[k] = ld_nt(base + t2c * 192 + 64 * k + lane);
+                __builtin_amdgcn_sched_barrier(0);
+                total += tile_count_regs(b, lb);
+                __builtin_amdgcn_sched_barrier(0);
+                if (t2 >= tiles) break;
+                t = t2;
             }
-            total += tile_count_regs(cur, lb);
-#pragma unroll
-            for (int k = 0; k < 3; k++) cur[k] = nxt[k];
+        }
+    } else if (VARIANT == 7) {
+        // The same software pipeline with the loads and their waits written as inline asm: hipcc sinks
+        // ordinary loads down to their first use (and rotates the loop), which serialises "prefetch B"
+        // behind "evaluate A".  asm volatile statements keep their order; the counted s_waitcnt names
+        // the three registers it guards as in/out operands so no use can be hoisted above it.
+        if (wave_id < tiles) {
+            v4i a0, a1, a2, b0, b1, b2;
+#define PCQ_LOAD3(r0, r1, r2, tile_index)                                                                       \
+    {                                                                                                            \
+        const v4i *q_ = base + (tile_index) * 192 + lane;                                                         \
+        asm volatile("global_load_dwordx4 %0, %3, off nt\n\tglobal_load_dwordx4 %1, %3, off offset:1024 nt\n\t"   \
+                     "global_load_dwordx4 %2, %3, off offset:2048 nt"                                             \
+                     : "=&v"(r0), "=&v"(r1), "=&v"(r2)                                                            \
+                     : "v"(q_)                                                                                    \
+                     : "memory");                                                                                 \
+    }
+#define PCQ_WAIT3(r0, r1, r2, n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(r0), "+v"(r1), "+v"(r2)::"memory")
+            uint64_t t = wave_id;
+            PCQ_LOAD3(a0, a1, a2, t);
+            for (;;) {
+                const uint64_t t1 = t + stride;
+                const uint64_t t1c = t1 < tiles ? t1 : t;
+                PCQ_LOAD3(b0, b1, b2, t1c);
+                PCQ_WAIT3(a0, a1, a2, 3);  // A has landed, B's three loads stay in flight
+                {
+                    const v4i va[3] = {a0, a1, a2};
+                    total += tile_count_regs(va, lb);
+                }
+                if (t1 >= tiles) break;
+                const uint64_t t2 = t1 + stride;
+                const uint64_t t2c = t2 < tiles ? t2 : t1;
+                PCQ_LOAD3(a0, a1, a2, t2c);
+                PCQ_WAIT3(b0, b1, b2, 3);
+                {
+                    const v4i vb[3] = {b0, b1, b2};
+                    total += tile_count_regs(vb, lb);
+                }
+                if (t2 >= tiles) break;
+                t = t2;
+            }
+            // the clamped tail prefetch is still in flight: land it before its registers are reused
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(b0), "+v"(b1), "+v"(b2)::"memory");
+#undef PCQ_LOAD3
+#undef PCQ_WAIT3
         }
     } else if (VARIANT == 5) {
         const uint64_t pairs = tiles / 2;
@@ -419,6 +476,7 @@ int pcq_launch_bounds_count_xyz12(pcq_ctx *ctx, const void *d_xyz, uint64_t n, c
     case 4: hipLaunchKernelGGL(k_bounds_count_xyz12<4>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     case 5: hipLaunchKernelGGL(k_bounds_count_xyz12<5>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     case 6: hipLaunchKernelGGL(k_bounds_count_xyz12<6>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
+    case 7: hipLaunchKernelGGL(k_bounds_count_xyz12<7>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     default: hipLaunchKernelGGL(k_bounds_count_xyz12<0>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     }
     hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, grid, d_count);

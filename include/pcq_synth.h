@@ -46,6 +46,10 @@ int pcq_synth_fill_dev(pcq_ctx *ctx, const pcq_synth_spec *spec, uint64_t first,
 int pcq_membench_read(pcq_ctx *ctx, const void *d_buf, uint64_t bytes, int shape, int nontemporal,
                       int blocks_per_cu, void *stream);
 
+/* Same, as wave tiles of `loads` x 1 KiB with an explicit launch geometry (threads per block, blocks). */
+int pcq_membench_read_tiles(pcq_ctx *ctx, const void *d_buf, uint64_t bytes, int loads, int threads, int blocks,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

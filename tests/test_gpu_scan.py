@@ -57,7 +57,7 @@ BOXES = [
 
 
 @pytest.mark.parametrize("n", [0, 1, 3, 255, 256, 257, 1000, 4099, 100_003, 1_000_003])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
 def test_bounds_count_dev_matches_oracle(oracle, gpu_ctx, n, variant):
     spec = small_spec(1234 + n, n)
     image = oracle.synth_image(spec, transposed=True)
