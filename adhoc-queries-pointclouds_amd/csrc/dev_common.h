@@ -23,12 +23,23 @@ struct RawPoint {
     int32_t x, y, z;
 };
 
+struct __attribute__((packed, aligned(4))) PackedXYZ {
+    int32_t x, y, z;
+};
+
 __device__ __forceinline__ RawPoint ld_xyz(const DevCols &c, uint64_t i) {
     const uint8_t *p = c.xyz + i * c.xyz_stride;
     RawPoint r;
-    r.x = ld_i32(p);
-    r.y = ld_i32(p + 4);
-    r.z = ld_i32(p + 8);
+    if (((uintptr_t)p & 3) == 0) {  // one global_load_dwordx3 (LAST blocks and even-pitch LAS records)
+        const PackedXYZ v = *reinterpret_cast<const PackedXYZ *>(p);
+        r.x = v.x;
+        r.y = v.y;
+        r.z = v.z;
+    } else {
+        r.x = ld_i32(p);
+        r.y = ld_i32(p + 4);
+        r.z = ld_i32(p + 8);
+    }
     return r;
 }
 
