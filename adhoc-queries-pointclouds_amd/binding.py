@@ -19,7 +19,7 @@ PCQ_OK = 0
 PCQ_ERR_IO, PCQ_ERR_HEADER, PCQ_ERR_FORMAT, PCQ_ERR_EXTENSION, PCQ_ERR_EOF = -1, -2, -3, -4, -5
 PCQ_ERR_GRID, PCQ_ERR_PANIC, PCQ_ERR_ARG, PCQ_ERR_HIP, PCQ_ERR_CAPACITY = -6, -7, -8, -9, -10
 PCQ_ERR_UNSUPPORTED, PCQ_ERR_NOMEM = -11, -12
-PRED_BOUNDS, PRED_CLASS = 0, 1
+PRED_BOUNDS, PRED_CLASS, PRED_BOUNDS_F64 = 0, 1, 2
 
 # readers/src/lib.rs:10-19 — packed 31-byte result record
 POINT_DTYPE = np.dtype(
@@ -49,7 +49,16 @@ class Columns(C.Structure):
 
 class Predicate(C.Structure):
     _fields_ = [("kind", C.c_int32), ("cls", C.c_uint8), ("_pad", C.c_uint8 * 3), ("lmin", C.c_int64 * 3),
-                ("lmax", C.c_int64 * 3)]
+                ("lmax", C.c_int64 * 3), ("wmin", C.c_double * 3), ("wmax", C.c_double * 3)]
+
+    @staticmethod
+    def bounds_f64(wmin: Sequence[float], wmax: Sequence[float]) -> "Predicate":
+        p = Predicate()
+        p.kind = PRED_BOUNDS_F64
+        for a in range(3):
+            p.wmin[a] = float(wmin[a])
+            p.wmax[a] = float(wmax[a])
+        return p
 
     @staticmethod
     def bounds(lmin: Sequence[int], lmax: Sequence[int]) -> "Predicate":

@@ -53,6 +53,16 @@ __device__ __forceinline__ bool eval_pred(const DevCols &c, const DevPred &pr, u
         return ((uint32_t)(rp.x - pr.lo[0]) <= pr.width[0]) & ((uint32_t)(rp.y - pr.lo[1]) <= pr.width[1]) &
                ((uint32_t)(rp.z - pr.lo[2]) <= pr.width[2]);
     }
+    if (pr.kind == PCQ_PRED_BOUNDS_F64) {  // lazer.rs:65-69 on world = offset + scale * x (lazer_reader.rs:600-607)
+        rp = ld_xyz(c, i);
+        have_xyz = true;
+        const double wx = c.offset[0] + c.scale[0] * (double)rp.x, wy = c.offset[1] + c.scale[1] * (double)rp.y,
+                     wz = c.offset[2] + c.scale[2] * (double)rp.z;
+        // AABB::contains rejects on `p < min || p > max` per axis [recalled, pasture-core 0.1.0 math/bounds.rs],
+        // so a NaN coordinate (NaN scale/offset in the header) is NOT rejected
+        return !((wx < pr.wmin[0]) | (wy < pr.wmin[1]) | (wz < pr.wmin[2]) | (wx > pr.wmax[0]) | (wy > pr.wmax[1]) |
+                 (wz > pr.wmax[2]));
+    }
     have_xyz = false;
     return (uint32_t)c.cls[i * c.cls_stride] == pr.cls;
 }

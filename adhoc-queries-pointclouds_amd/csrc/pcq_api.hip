@@ -237,6 +237,10 @@ int pcq_make_dev_pred(const pcq_predicate *p, DevPred *out) {
         out->cls = p->cls;
         return PCQ_OK;
     }
+    if (p->kind == PCQ_PRED_BOUNDS_F64) {
+        for (int a = 0; a < 3; a++) out->wmin[a] = p->wmin[a], out->wmax[a] = p->wmax[a];
+        return PCQ_OK;
+    }
     if (p->kind != PCQ_PRED_BOUNDS) return pcq_fail(PCQ_ERR_ARG, "unknown predicate kind %d", p->kind);
     for (int a = 0; a < 3; a++) {
         const int64_t lo = p->lmin[a] < INT32_MIN ? (int64_t)INT32_MIN : p->lmin[a];
@@ -425,9 +429,10 @@ extern "C" int pcq_collector_grid_params(const pcq_collector *c, uint64_t dims[3
 // ---------------------------------------------------------------------------------------------
 static int validate_scan(const pcq_columns *cols, const pcq_predicate *pred, const pcq_collector *c) {
     if (!cols || !pred || !c) return pcq_fail(PCQ_ERR_ARG, "scan: null argument");
-    if (pred->kind != PCQ_PRED_BOUNDS && pred->kind != PCQ_PRED_CLASS) return pcq_fail(PCQ_ERR_ARG, "scan: bad predicate kind %d", pred->kind);
+    if (pred->kind != PCQ_PRED_BOUNDS && pred->kind != PCQ_PRED_CLASS && pred->kind != PCQ_PRED_BOUNDS_F64)
+        return pcq_fail(PCQ_ERR_ARG, "scan: bad predicate kind %d", pred->kind);
     if (cols->n == 0) return PCQ_OK;
-    const bool need_xyz = pred->kind == PCQ_PRED_BOUNDS || c->kind != COLL_COUNT;
+    const bool need_xyz = pred->kind != PCQ_PRED_CLASS || c->kind != COLL_COUNT;
     const bool need_cls = pred->kind == PCQ_PRED_CLASS || c->kind != COLL_COUNT;
     if (need_xyz && (!cols->xyz || cols->xyz_stride < 12)) return pcq_fail(PCQ_ERR_ARG, "scan: positions column missing or stride < 12");
     if (need_cls && (!cols->cls || cols->cls_stride < 1)) return pcq_fail(PCQ_ERR_ARG, "scan: classification column missing");
@@ -468,6 +473,7 @@ static int count_into(pcq_ctx *ctx, const DevCols &dc, const DevPred &dp, uint64
         }
         return pcq_launch_generic_count(ctx, dc, dp, d_count, s);
     }
+    if (dp.kind == PCQ_PRED_BOUNDS_F64) return pcq_launch_generic_count(ctx, dc, dp, d_count, s);
     if (dc.cls_stride == 1) return pcq_launch_class_count_u8(ctx, dc.cls, dc.n, (uint8_t)dp.cls, d_count, s);
     return pcq_launch_generic_count(ctx, dc, dp, d_count, s);
 }
@@ -596,7 +602,7 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
     PCQ_HIP(hipSetDevice(ctx->device));
 
     StagePlan pl{};
-    pl.need_xyz = pred->kind == PCQ_PRED_BOUNDS || c->kind != COLL_COUNT;
+    pl.need_xyz = pred->kind != PCQ_PRED_CLASS || c->kind != COLL_COUNT;
     pl.need_cls = pred->kind == PCQ_PRED_CLASS || c->kind != COLL_COUNT;
     pl.need_rgb = c->kind != COLL_COUNT && cols->rgb != nullptr;
     const uint8_t *hx = (const uint8_t *)cols->xyz, *hc = (const uint8_t *)cols->cls, *hr = (const uint8_t *)cols->rgb;

@@ -36,6 +36,8 @@ struct DevPred {
     int32_t lo[3];
     uint32_t width[3];
     uint32_t cls;
+    uint32_t _pad;
+    double wmin[3], wmax[3];  // PCQ_PRED_BOUNDS_F64
 };
 
 struct DevCols {

@@ -2,6 +2,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include "lz4_frame.hpp"
 #include "pcq_host.hpp"
 #include "pcq_query.h"
 
@@ -65,6 +66,12 @@ extern "C" int pcq_query_get_total_bounds(const char *const *files, size_t nfile
     if (st.ok())
         for (int a = 0; a < 3; a++) bmin[a] = b.min[a], bmax[a] = b.max[a];
     return done(st);
+}
+
+extern "C" int pcq_query_lz4_frame_decode(const uint8_t *src, size_t n, uint64_t need, uint64_t unit, uint8_t *out, uint64_t cap) {
+    if ((!src && n) || (!out && need) || cap < need) return done(Status::Err(PCQ_ERR_ARG, "bad argument"));
+    // the same entry the LAZER reader uses: straight into the destination, spilling frames redone via a vector
+    return done(lz4_frame_decode_into(src, n, (size_t)need, (size_t)unit, out));
 }
 
 template <typename F>

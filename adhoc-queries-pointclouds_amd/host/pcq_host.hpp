@@ -11,6 +11,7 @@
 //   search_{last,las}_file_by_{bounds,classification}_optimized
 //                                                    query/src/search/last.rs:46-166, 213-293
 //                                                    query/src/search/las.rs:52-148, 192-261
+//   search_lazer_file_by_{bounds,classification}     query/src/search/lazer.rs:34-116
 //   trait PointDumper, IgnoreDumper, FileDumper      query/src/dump_points.rs:13-121
 //   get_all_input_files, parse_aabb, get_total_bounds, run_search_sequential,
 //   run_search_parallel, is_valid_file               query/src/main.rs:29-189
@@ -140,6 +141,10 @@ Status search_last_file_by_bounds_optimized(const std::string &path, const AABB 
 Status search_last_file_by_classification_optimized(const std::string &path, uint8_t cls, ResultCollector &rc);
 Status search_las_file_by_bounds_optimized(const std::string &path, const AABB &bounds, ResultCollector &rc, SearchLog *log);
 Status search_las_file_by_classification_optimized(const std::string &path, uint8_t cls, ResultCollector &rc);
+// search/lazer.rs:34-116 over readers/src/lazer_reader.rs (one implementation for both --optimized settings)
+Status search_lazer_file_by_bounds(const std::string &path, const AABB &bounds, ResultCollector &rc);
+Status search_lazer_file_by_classification(const std::string &path, uint8_t cls, ResultCollector &rc);
+Status lazer_file_bounds(const std::string &path, AABB *out);  // LAZERSource::from(..).get_metadata().bounds()
 
 // ---- search/searcher.rs ----------------------------------------------------------------------------
 enum class SearchImplementation { Regular, Optimized };

@@ -89,6 +89,13 @@ Status get_total_bounds(const std::vector<std::string> &files, AABB *out) {
     const double lo[3] = {mx, mx, mx}, hi[3] = {-mx, -mx, -mx};
     AABB total = AABB::from_min_max_unchecked(lo, hi);  // :114
     for (const auto &f : files) {
+        if (f.size() >= 6 && f.compare(f.size() - 6, 6, ".lazer") == 0) {  // :102-107
+            AABB b;
+            Status st = lazer_file_bounds(f, &b);
+            if (!st.ok()) return st;
+            total = AABB::union_of(total, b);
+            continue;
+        }
         MappedFile mf;
         Status st = mf.open(f);
         if (!st.ok()) return st;

@@ -279,7 +279,8 @@ Status BoundsSearcher::search_file(const std::string &path, SearchImplementation
         return *ext == "las" ? search_las_file_by_bounds_optimized(path, bounds_, collector, log)
                              : search_last_file_by_bounds_optimized(path, bounds_, collector);
     }
-    if (*ext == "laz" || *ext == "lazer") return out_of_scope("compressed format ." + *ext, path);
+    if (*ext == "lazer") return search_lazer_file_by_bounds(path, bounds_, collector);  // searcher.rs:83, either implementation
+    if (*ext == "laz") return out_of_scope("compressed format .laz", path);
     return Status::Err(PCQ_ERR_EXTENSION, "Unsupported file extension in file " + path);
 }
 
@@ -292,7 +293,8 @@ Status ClassSearcher::search_file(const std::string &path, SearchImplementation 
         return *ext == "las" ? search_las_file_by_classification_optimized(path, class_, collector)
                              : search_last_file_by_classification_optimized(path, class_, collector);
     }
-    if (*ext == "laz" || *ext == "lazer") return out_of_scope("compressed format ." + *ext, path);
+    if (*ext == "lazer") return search_lazer_file_by_classification(path, class_, collector);  // searcher.rs:144
+    if (*ext == "laz") return out_of_scope("compressed format .laz", path);
     return Status::Err(PCQ_ERR_EXTENSION, "Unsupported file extension in file " + path);
 }
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PCQ_ABI_VERSION 1
+#define PCQ_ABI_VERSION 2
 
 typedef enum pcq_status {
     PCQ_OK = 0,
@@ -107,18 +107,25 @@ typedef struct pcq_columns {
     double offset[3];
 } pcq_columns;
 
-typedef enum pcq_predicate_kind { PCQ_PRED_BOUNDS = 0, PCQ_PRED_CLASS = 1 } pcq_predicate_kind;
+typedef enum pcq_predicate_kind { PCQ_PRED_BOUNDS = 0, PCQ_PRED_CLASS = 1, PCQ_PRED_BOUNDS_F64 = 2 } pcq_predicate_kind;
 
-/* The predicate in the file's local integer space.
- * BOUNDS: lmin <= (x,y,z) <= lmax, inclusive, compared as i64 (last.rs:122-135).  lmin/lmax are
- *         what pcq_box_to_local produced; values outside the i32 range are legal.
- * CLASS:  classification byte == cls, whole byte (last.rs:259-262). */
+/* The predicate.
+ * BOUNDS:     in the file's local integer space: lmin <= (x,y,z) <= lmax, inclusive, compared as i64
+ *             (last.rs:122-135).  lmin/lmax are what pcq_box_to_local produced; values outside the i32
+ *             range are legal.
+ * CLASS:      classification byte == cls, whole byte (last.rs:259-262).
+ * BOUNDS_F64: in world space, the reference's non-integer form used by the LAZER scan
+ *             (query/src/search/lazer.rs:65-69 on positions rebuilt as offset + scale * x,
+ *             readers/src/lazer_reader.rs:600-607): wmin <= world <= wmax per axis, inclusive
+ *             (pasture AABB::contains). */
 typedef struct pcq_predicate {
     int32_t kind;               /* pcq_predicate_kind */
     uint8_t cls;
     uint8_t _pad[3];
     int64_t lmin[3];
     int64_t lmax[3];
+    double wmin[3];
+    double wmax[3];
 } pcq_predicate;
 
 /* last.rs:98-109 / las.rs:88-99 — f64 query box -> local integer box, bug-for-bug (all three min

@@ -44,6 +44,12 @@ int pcq_query_parse_aabb(const char *s, double bmin[3], double bmax[3]);
 int pcq_query_is_valid_file(const char *path);
 int pcq_query_get_total_bounds(const char *const *files, size_t nfiles, double bmin[3], double bmax[3]);
 
+/* The LZ4 Frame reader the LAZER searches inflate column blobs with (stand-in for lz4::Decoder,
+ * readers/src/lazer_reader.rs:176-265): the first `need` bytes of the frame at src -> out (cap >= need),
+ * as read_exact calls of `unit` bytes each would get them (4 = read_i32 ..., 0 = a single call).
+ * Host-only, no GPU needed.  PCQ_ERR_EOF = read_exact's UnexpectedEof, PCQ_ERR_HEADER = an LZ4 error. */
+int pcq_query_lz4_frame_decode(const uint8_t *src, size_t n, uint64_t need, uint64_t unit, uint8_t *out, uint64_t cap);
+
 /* Collectors on the calling thread's context for `device`. */
 int pcq_query_collector_new_count(int device, pcq_host_collector **out);
 int pcq_query_collector_new_buffer(int device, pcq_host_collector **out);

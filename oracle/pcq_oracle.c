@@ -37,6 +37,7 @@ static int fail(int code, const char *fmt, ...) {
 }
 
 const char *pcqo_last_error(void) { return g_err; }
+int pcqo_fail_msg(int code, const char *msg) { return fail(code, "%s", msg); } /* for lazer_oracle.c */
 
 /* ------------------------------------------------------------------------------------------ */
 /* Rust numeric cast semantics                                                                */
@@ -630,8 +631,8 @@ int pcqo_search_file(const char *path, int query_kind, const double bmin[3], con
                      uint8_t cls, pcqo_collector *c, int *record_size_printed) {
     const char *ext = path_extension(path);
     if (!ext) return fail(PCQO_ERR_EXTENSION, "Invalid extension on file %s", path);
-    int is_las = strcmp(ext, "las") == 0, is_last = strcmp(ext, "last") == 0;
-    if (!is_las && !is_last)
+    int is_las = strcmp(ext, "las") == 0, is_last = strcmp(ext, "last") == 0, is_lazer = strcmp(ext, "lazer") == 0;
+    if (!is_las && !is_last && !is_lazer)
         return fail(PCQO_ERR_EXTENSION, "Unsupported file extension in file %s", path);
 
     int fd = open(path, O_RDONLY);
@@ -652,7 +653,10 @@ int pcqo_search_file(const char *path, int query_kind, const double bmin[3], con
     }
     close(fd);
     int rc;
-    if (is_last)
+    if (is_lazer) /* searcher.rs:83, :144 — one implementation for Regular and Optimized */
+        rc = query_kind == PCQO_QUERY_BOUNDS ? pcqo_search_lazer_mem_by_bounds(p, len, bmin, bmax, c)
+                                             : pcqo_search_lazer_mem_by_classification(p, len, cls, c);
+    else if (is_last)
         rc = query_kind == PCQO_QUERY_BOUNDS
                  ? pcqo_search_last_mem_by_bounds_optimized(p, len, bmin, bmax, c)
                  : pcqo_search_last_mem_by_classification_optimized(p, len, cls, c);
@@ -661,6 +665,22 @@ int pcqo_search_file(const char *path, int query_kind, const double bmin[3], con
                  ? pcqo_search_las_mem_by_bounds_optimized(p, len, bmin, bmax, c, record_size_printed)
                  : pcqo_search_las_mem_by_classification_optimized(p, len, cls, c);
     if (p) munmap((void *)p, len);
+    return rc;
+}
+
+int pcqo_lazer_file_bounds(const char *path, double mn[3], double mx[3]) {
+    int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(PCQO_ERR_IO, "%s: %s", path, strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0 || st.st_size == 0) {
+        close(fd);
+        return fail(PCQO_ERR_HEADER, "%s: failed to fill whole buffer", path);
+    }
+    const uint8_t *p = (const uint8_t *)mmap(NULL, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (p == MAP_FAILED) return fail(PCQO_ERR_IO, "%s: mmap failed", path);
+    int rc = pcqo_lazer_mem_bounds(p, (size_t)st.st_size, mn, mx);
+    munmap((void *)p, (size_t)st.st_size);
     return rc;
 }
 

@@ -123,8 +123,28 @@ int pcqo_search_las_mem_by_bounds_optimized(const uint8_t *data, size_t len, con
 int pcqo_search_las_mem_by_classification_optimized(const uint8_t *data, size_t len, uint8_t cls,
                                                     pcqo_collector *c);
 
+/* ---- LAZER (lazer_oracle.c): query/src/search/lazer.rs:34-116 over readers/src/lazer_reader.rs ---- */
+int pcqo_search_lazer_mem_by_bounds(const uint8_t *data, size_t len, const double bmin[3], const double bmax[3],
+                                    pcqo_collector *c);
+/* bug-for-bug: the point buffer is never cleared, so every chunk re-filters the first chunk's points */
+int pcqo_search_lazer_mem_by_classification(const uint8_t *data, size_t len, uint8_t cls, pcqo_collector *c);
+/* LAZERSource::from(..).get_metadata().bounds() (main.rs:102-111) */
+int pcqo_lazer_mem_bounds(const uint8_t *data, size_t len, double mn[3], double mx[3]);
+int pcqo_lazer_file_bounds(const char *path, double mn[3], double mx[3]);
+/* lz4::Decoder restatement: the first `need` bytes of the LZ4 frame at src, pulled with read_exact calls of
+ * `unit` bytes (0: one call); returns need or a PCQO_ERR_*. */
+int64_t pcqo_lz4f_decode(const uint8_t *src, size_t n, uint8_t *out, size_t need, size_t unit);
+uint32_t pcqo_xxh32(const uint8_t *d, size_t n);
+/* Test-side writers (the reference repository has no LAZER writer).  flags: 1 independent blocks,
+ * 2 block checksums, 4 content checksum, 8 content size, 16 stored blocks, 32 leading skippable frame;
+ * block_id 4..7 = 64 KiB .. 4 MiB.  Results are malloc'd; release with pcqo_free. */
+uint8_t *pcqo_lz4f_compress(const uint8_t *content, size_t n, unsigned flags, int block_id, size_t *out_n);
+uint8_t *pcqo_lazer_from_last(const uint8_t *last, size_t len, uint64_t block_size, unsigned flags, int block_id,
+                              size_t *out_n);
+void pcqo_free(void *p);
+
 /* ---- file-level: open + mmap (last.rs:27-34) then the scans above; dispatch by extension
- *      restates searcher.rs:43-152 for the ("las"|"last", Optimized) arms. ---- */
+ *      restates searcher.rs:43-152 for the ("las"|"last", Optimized) and "lazer" arms. ---- */
 enum { PCQO_QUERY_BOUNDS = 0, PCQO_QUERY_CLASS = 1 };
 int pcqo_search_file(const char *path, int query_kind, const double bmin[3], const double bmax[3],
                      uint8_t cls, pcqo_collector *c, int *record_size_printed);

@@ -210,7 +210,15 @@ int main(int argc, char **argv) {
             for (size_t i = 0; i < files.n; i++) {
                 const char *e = ext_of(files.v[i]);
                 pcqo_las_header h;
-                int rc = read_header(files.v[i], e && !strcmp(e, "last"), &h);
+                int rc;
+                if (e && !strcmp(e, "lazer")) /* main.rs:102-107: the full LAZERSource::from */
+                    rc = pcqo_lazer_file_bounds(files.v[i], h.min, h.max);
+                else
+                    rc = read_header(files.v[i], e && !strcmp(e, "last"), &h);
+                if (rc == PCQO_ERR_PANIC) {
+                    fprintf(stderr, "thread 'main' panicked: %s\n", pcqo_last_error());
+                    return 101;
+                }
                 if (rc) {
                     fprintf(stderr, "Error: %s\n", pcqo_last_error());
                     return 1;
@@ -233,9 +241,14 @@ int main(int argc, char **argv) {
             return 1;
         }
     }
-    if (!optimized) {
-        fprintf(stderr, "Error: the oracle restates only the --optimized search implementation\n");
-        return 1;
+    if (!optimized) { /* .lazer has one implementation for both settings (searcher.rs:83, :144) */
+        for (size_t i = 0; i < files.n; i++) {
+            const char *e = ext_of(files.v[i]);
+            if (!e || strcmp(e, "lazer")) {
+                fprintf(stderr, "Error: the oracle restates only the --optimized search implementation\n");
+                return 1;
+            }
+        }
     }
 
     printf("Searching %zu files...\n", files.n); /* main.rs:289 */

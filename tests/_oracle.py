@@ -124,6 +124,18 @@ class Oracle:
         lib.pcqo_synth_build_image.argtypes = [P(SynthSpec), C.c_int, vp, C.c_size_t, C.c_int]
         lib.pcqo_synth_write_file.argtypes = [P(SynthSpec), C.c_int, C.c_char_p, C.c_int]
         lib.pcqo_synth_build_header.argtypes = [P(SynthSpec), vp]
+        lib.pcqo_search_lazer_mem_by_bounds.argtypes = [vp, C.c_size_t, dd, dd, vp]
+        lib.pcqo_search_lazer_mem_by_classification.argtypes = [vp, C.c_size_t, C.c_uint8, vp]
+        lib.pcqo_lazer_mem_bounds.argtypes = [vp, C.c_size_t, dd, dd]
+        lib.pcqo_lz4f_decode.restype = C.c_int64
+        lib.pcqo_lz4f_decode.argtypes = [vp, C.c_size_t, vp, C.c_size_t, C.c_size_t]
+        lib.pcqo_xxh32.restype = C.c_uint32
+        lib.pcqo_xxh32.argtypes = [vp, C.c_size_t]
+        lib.pcqo_lz4f_compress.restype = vp
+        lib.pcqo_lz4f_compress.argtypes = [vp, C.c_size_t, C.c_uint, C.c_int, P(C.c_size_t)]
+        lib.pcqo_lazer_from_last.restype = vp
+        lib.pcqo_lazer_from_last.argtypes = [vp, C.c_size_t, u64, C.c_uint, C.c_int, P(C.c_size_t)]
+        lib.pcqo_free.argtypes = [vp]
 
     # --- helpers ------------------------------------------------------------------------------
     def err(self) -> str:
@@ -189,6 +201,44 @@ class Oracle:
     def search_las_class(self, image, cls, coll: OracleCollector) -> int:
         a, p, n = self._img(image)
         return self.lib.pcqo_search_las_mem_by_classification_optimized(p, n, cls, coll.h)
+
+    # --- LAZER / LZ4 ----------------------------------------------------------------------------
+    def search_lazer_bounds(self, image, bmin, bmax, coll: OracleCollector) -> int:
+        a, p, n = self._img(image)
+        return self.lib.pcqo_search_lazer_mem_by_bounds(p, n, _d3(bmin), _d3(bmax), coll.h)
+
+    def search_lazer_class(self, image, cls, coll: OracleCollector) -> int:
+        a, p, n = self._img(image)
+        return self.lib.pcqo_search_lazer_mem_by_classification(p, n, cls, coll.h)
+
+    def xxh32(self, data: bytes) -> int:
+        a, p, n = self._img(bytes(data) or b"\0")
+        return self.lib.pcqo_xxh32(p, len(data))
+
+    def lz4f_decode(self, frame: bytes, need: int, unit: int = 0):
+        """(bytes, 0) or (None, error code): the first `need` bytes of the frame, `unit` bytes per read."""
+        a, p, n = self._img(bytes(frame) or b"\0")
+        out = np.zeros(max(need, 1), dtype=np.uint8)
+        rc = self.lib.pcqo_lz4f_decode(p, len(frame), out.ctypes.data_as(C.c_void_p), need, unit)
+        return (out[:need].tobytes(), 0) if rc >= 0 else (None, int(rc))
+
+    def _take(self, ptr, n) -> bytes:
+        if not ptr:
+            raise OracleError(ERR_ARG, "oracle writer failed")
+        data = C.string_at(ptr, n)
+        self.lib.pcqo_free(ptr)
+        return data
+
+    def lz4f_compress(self, content: bytes, flags=4, block_id=4) -> bytes:
+        a, p, n = self._img(bytes(content) or b"\0")
+        out_n = C.c_size_t(0)
+        return self._take(self.lib.pcqo_lz4f_compress(p, len(content), flags, block_id, C.byref(out_n)), out_n.value)
+
+    def lazer_from_last(self, last_image, block_size: int, flags=4, block_id=4) -> np.ndarray:
+        a, p, n = self._img(last_image)
+        out_n = C.c_size_t(0)
+        raw = self._take(self.lib.pcqo_lazer_from_last(p, n, block_size, flags, block_id, C.byref(out_n)), out_n.value)
+        return np.frombuffer(raw, dtype=np.uint8).copy()
 
     def search_file(self, path, kind, bmin, bmax, cls, coll: OracleCollector):
         rec = C.c_int(-1)

@@ -30,7 +30,7 @@ def pytest_configure(config):
 
 def _build_oracle():
     so = os.path.join(ROOT, "oracle", "liboracle.so")
-    srcs = [os.path.join(ROOT, "oracle", f) for f in ("pcq_oracle.c", "synth.c", "pcq_oracle.h", "query_oracle.c")]
+    srcs = [os.path.join(ROOT, "oracle", f) for f in ("pcq_oracle.c", "lazer_oracle.c", "synth.c", "pcq_oracle.h", "query_oracle.c")]
     exe = os.path.join(ROOT, "oracle", "query_oracle")
     newest = max(os.path.getmtime(s) for s in srcs)
     if not (os.path.exists(so) and os.path.exists(exe)) or min(os.path.getmtime(so), os.path.getmtime(exe)) < newest:

@@ -272,8 +272,97 @@ def main():
     g_big = Grid([0.0] * 3, [1e9] * 3, 1e-4)  # 3 x 44 bits > 64
     out["grid"]["too_many_cells"] = {"bmin": [0.0] * 3, "bmax": [1e9] * 3, "cell": 1e-4, "bits": g_big.bits, "too_many": g_big.too_many}
 
+    lazer_section(out, last, pts_world)
     json.dump(out, open(os.path.join(HERE, "expected.json"), "w"), indent=1)
     print("wrote expected.json, tiny_fmt2.last (%d B), tiny_fmt3.las (%d B)" % (len(last), len(las)))
+
+
+# ---- LAZER (readers/src/lazer_reader.rs, query/src/search/lazer.rs) ------------------------------------------
+# The column blobs are compressed by the image's real liblz4 (tests/_lz4ref.py), the library under the
+# reference's `lz4` crate — not by anything in oracle/ or the product.  Without liblz4 on the host the
+# committed files are left as they are.
+LAZER_BLOCK = 7
+
+
+def contains(bmin, bmax, p):  # pasture AABB::contains [recalled]: reject on p < min || p > max
+    return not (any(p[a] < bmin[a] for a in range(3)) or any(p[a] > bmax[a] for a in range(3)))
+
+
+def lazer_section(out, last, pts_world):
+    import sys
+    sys.path.insert(0, os.path.dirname(HERE))
+    import _lz4ref
+    real = _lz4ref.load()
+    if real is None:
+        old = json.load(open(os.path.join(HERE, "expected.json")))
+        out["lazer"] = old["lazer"]
+        print("liblz4 not found: kept tiny_fmt2.lazer / lz4_frames.json")
+        return
+    n = len(POINTS)
+    # lz4 crate EncoderBuilder defaults: 64 KiB linked blocks, content checksum, level 0
+    frame = lambda b: real.compress_frame(bytes(b), 0, False, True, False, False, 0)
+    nattr = 9  # format 2: 8 + colour (lazer_reader.rs:92-105)
+    nb = (n + LAZER_BLOCK - 1) // LAZER_BLOCK
+    head = bytearray(last[:227])
+    body = bytearray(struct.pack("<Q", LAZER_BLOCK)) + bytearray(8 * nb)
+    for b in range(nb):
+        lo, hi = b * LAZER_BLOCK, min(n, (b + 1) * LAZER_BLOCK)
+        cols = [b"".join(struct.pack("<iii", *POINTS[i][:3]) for i in range(lo, hi)),          # 0 positions
+                b"".join(struct.pack("<H", 100 + i) for i in range(lo, hi)),                  # 1 intensity
+                bytes([0x11] * (hi - lo)),                                                    # 2 return bits
+                bytes(POINTS[i][3] for i in range(lo, hi)),                                   # 3 classification
+                bytes(hi - lo), bytes(hi - lo), bytes(2 * (hi - lo)), bytes(hi - lo),         # 4..7
+                b"".join(struct.pack("<HHH", *POINTS[i][4]) for i in range(lo, hi))]           # 8 colour
+        blobs = [frame(c) for c in cols]
+        at = 227 + len(body)
+        struct.pack_into("<Q", body, 8 + 8 * b, at)
+        table = bytearray(8 * nattr)
+        pos = at + 8 * nattr
+        for k, blob in enumerate(blobs):
+            struct.pack_into("<Q", table, 8 * k, pos)
+            pos += len(blob)
+        body += table + b"".join(blobs)
+    lazer = bytes(head) + bytes(body)
+    open(os.path.join(HERE, "tiny_fmt2.lazer"), "wb").write(lazer)
+
+    wpos = [tuple(OFFSET[a] + SCALE[a] * float(p[a]) for a in range(3)) for p in POINTS]  # lazer_reader.rs:602-609
+    hmin = [min(p[a] for p in pts_world) for a in range(3)]
+    hmax = [max(p[a] for p in pts_world) for a in range(3)]
+
+    def rec(i):
+        return struct.pack("<dddHHHB", *wpos[i], *POINTS[i][4], POINTS[i][3])
+
+    queries = [((100.0, 200.0, -10.0), (110.0, 210.0, 0.0)), ((0.0, 0.0, -100.0), (1000.0, 1000.0, 100.0)),
+               (wpos[3], wpos[3]), ((1e6, 1e6, 1e6), (2e6, 2e6, 2e6)),
+               ((hmin[0], hmin[1], hmin[2]), (hmin[0], hmax[1], hmax[2]))]
+    res = {"block_size": LAZER_BLOCK, "bounds": [], "class": []}
+    for bmin, bmax in queries:
+        idx = [i for i in range(n) if contains(bmin, bmax, wpos[i])] if intersects(hmin, hmax, bmin, bmax) else []
+        res["bounds"].append({"min": list(bmin), "max": list(bmax), "count": len(idx), "indices": idx,
+                              "points_hex": b"".join(rec(i) for i in idx).hex()})
+    for cls in sorted({p[3] for p in POINTS} | {99}):
+        # lazer.rs:80-116: the buffer is never cleared -> chunk k filters points [0, points_in_chunk(k)) of chunk 0
+        idx = []
+        for k in range(nb):
+            in_chunk = min(LAZER_BLOCK, n - k * LAZER_BLOCK)
+            idx += [i for i in range(in_chunk) if POINTS[i][3] == cls]
+        res["class"].append({"class": cls, "count": len(idx), "indices": idx, "true_count": sum(1 for p in POINTS if p[3] == cls)})
+    out["lazer"] = res
+
+    # real-liblz4 frames as fixtures for the LZ4 readers; content = pattern * repeat
+    frames = []
+    patterns = [("one_byte", b"x", 1), ("hello", b"hello ", 9), ("zeros_3_blocks", b"\0", 150000), ("text_2_blocks", b"lorem ipsum dolor sit amet, ", 3000),
+                ("period3", bytes([1, 2, 3]), 30000), ("bytes256", bytes(range(256)), 2)]
+    for name, pat, rep in patterns:
+        content = pat * rep
+        for tag, kw in (("default", dict()), ("indep_bsum_size", dict(independent=True, block_checksum=True, content_size=True)),
+                        ("nochecks_256k", dict(block_id=5, content_checksum=False)), ("hc", dict(level=9))):
+            fr = real.compress_frame(content, **kw)
+            if len(fr) > 2000:
+                continue
+            frames.append({"name": name + "/" + tag, "pattern": pat.hex(), "repeat": rep, "frame": fr.hex()})
+    json.dump({"liblz4_version": real.version(), "frames": frames}, open(os.path.join(HERE, "lz4_frames.json"), "w"), indent=1)
+    print("wrote tiny_fmt2.lazer (%d B), lz4_frames.json (%d frames)" % (len(lazer), len(frames)))
 
 
 if __name__ == "__main__":
