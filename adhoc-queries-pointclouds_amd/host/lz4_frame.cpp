@@ -8,6 +8,8 @@
 //            | { block size u32 (bit 31: stored) | data | [block checksum u32] }* | EndMark 0
 //            | [content checksum u32]
 //   block  = sequences of { token | [literal length bytes] | literals | offset u16 | [match length bytes] }
+// Not modelled: the read-ahead the crate falls into after a stored (uncompressed) block, which lets the
+// real reader notice damage behind the last byte it hands out.
 // Header and block checksums (xxHash32) are verified where liblz4 verifies them; see lz4_frame_decode
 // for what a streaming reader that stops after `need` bytes does and does not get to check.
 #include "lz4_frame.hpp"
@@ -82,51 +84,71 @@ struct Out {
 static Status overflowed() { return Status::Err(PCQ_ERR_ARG, "LZ4: destination too small"); }
 
 // One LZ4 block appended to `out`; matches may reach back to `window_start` (linked blocks: the whole
-// frame so far; independent blocks: this block's own output).
-static Status lz4_block(const uint8_t *src, size_t n, Out *out, size_t window_start) {
-    const uint8_t *ip = src, *iend = src + n;
-    while (ip < iend) {
-        const uint8_t token = *ip++;
-        size_t lit = token >> 4;
+// frame so far — offsets are 16-bit, liblz4 keeps 64 KiB of history; independent blocks: this block's own
+// output).  Accepts and rejects exactly what liblz4's LZ4_decompress_safe (lz4.c, LZ4_decompress_generic
+// with endOnInput, full decoding) does when LZ4F inflates a block into its `max_block`-sized buffer — a
+// damaged file must fail here whenever it fails in the reference:
+//   * a literal run that comes within 8 bytes of the end of the input, or within 12 bytes of the end of
+//     the output buffer, has to be the last sequence: it must end exactly at the end of the input;
+//   * an extended literal length may not start in the last 15 input bytes; after every byte of an extended
+//     match length at least 5 input bytes must remain;
+//   * a match may not end in the last 5 bytes of the output buffer, nor start before the window.
+// (Offset 0 is rejected here; liblz4 1.9.3 copies stale buffer bytes for it, which has no defined result.)
+static Status lz4_block(const uint8_t *src, size_t n, Out *out, size_t window_start, size_t max_block) {
+    const Status bad = Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_decompressionFailed");
+    const int64_t in = (int64_t)n, cap = (int64_t)max_block;
+    const size_t base = out->size;
+    int64_t ip = 0, op = 0;
+    if (n == 0) return bad;
+    for (;;) {
+        const uint8_t token = src[ip++];
+        int64_t lit = token >> 4;
         if (lit == 15) {
+            if (ip >= in - 15) return bad;
             uint8_t b;
             do {
-                if (ip >= iend) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_decompressionFailed");
-                b = *ip++;
+                b = src[ip++];
                 lit += b;
-            } while (b == 255);
+            } while (b == 255 && ip < in - 15);  // running into the last 15 bytes ends the length early (lz4.c read_variable_length)
         }
-        if ((size_t)(iend - ip) < lit) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_decompressionFailed");
+        if (op + lit > cap - 12 || ip + lit > in - 8) {  // must be the last sequence
+            if (ip + lit != in || op + lit > cap) return bad;
+            if (!out->room((size_t)lit)) return overflowed();
+            memcpy(out->p + out->size, src + ip, (size_t)lit);
+            out->size += (size_t)lit;
+            return Status::Ok();
+        }
         if (lit) {
-            if (!out->room(lit)) return overflowed();
-            memcpy(out->p + out->size, ip, lit);
-            out->size += lit;
+            if (!out->room((size_t)lit)) return overflowed();
+            memcpy(out->p + out->size, src + ip, (size_t)lit);
+            out->size += (size_t)lit;
             ip += lit;
+            op += lit;
         }
-        if (ip == iend) break;  // the last sequence has no match part
-        if (iend - ip < 2) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_decompressionFailed");
-        const size_t offset = (size_t)ip[0] | ((size_t)ip[1] << 8);
+        const size_t offset = (size_t)src[ip] | ((size_t)src[ip + 1] << 8);
         ip += 2;
-        size_t mlen = token & 15;
+        int64_t mlen = token & 15;
         if (mlen == 15) {
             uint8_t b;
             do {
-                if (ip >= iend) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_decompressionFailed");
-                b = *ip++;
+                b = src[ip++];
                 mlen += b;
+                if (ip >= in - 4) return bad;
             } while (b == 255);
         }
         mlen += 4;
-        if (offset == 0 || offset > out->size - window_start) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_decompressionFailed");
-        if (!out->room(mlen)) return overflowed();
+        if (offset == 0 || offset > out->size - window_start) return bad;
+        if (op + mlen > cap - 5) return bad;
+        if (!out->room((size_t)mlen)) return overflowed();
         uint8_t *dst = out->p + out->size;
         const uint8_t *from = dst - offset;
-        if (offset >= mlen) memcpy(dst, from, mlen);
+        if (offset >= (size_t)mlen) memcpy(dst, from, (size_t)mlen);
         else
-            for (size_t k = 0; k < mlen; k++) dst[k] = from[k];  // overlapping match: the pattern repeats
-        out->size += mlen;
+            for (int64_t k = 0; k < mlen; k++) dst[k] = from[k];  // overlapping match: the pattern repeats
+        out->size += (size_t)mlen;
+        op += mlen;
     }
-    return Status::Ok();
+    (void)base;
 }
 
 // Decodes the frame at `src` until at least `need` bytes of content exist (whole blocks), the way the
@@ -170,6 +192,7 @@ static Status frame_core(const uint8_t *src, size_t n, size_t need, size_t unit,
     if (n - p < 1) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
     if (src[p] != ((xxh32(src + hdr, p - hdr) >> 8) & 0xFF)) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_headerChecksum_invalid");
     p++;
+    bool after_stored = false;
     while (out->size < need) {
         if (n - p < 4) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
         const uint32_t bs = rd32(src + p);
@@ -185,17 +208,26 @@ static Status frame_core(const uint8_t *src, size_t n, size_t need, size_t unit,
         const bool stored = bs & 0x80000000u;
         const size_t sz = bs & 0x7FFFFFFFu;
         if (sz > max_block) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_maxBlockSize_invalid");
-        if (n - p < sz || (block_checksum && n - p - sz < 4)) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
-        if (block_checksum && rd32(src + p + sz) != xxh32(src + p, sz)) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_blockChecksum_invalid");
         const size_t block_out_start = out->size;
+        after_stored = stored;
         if (stored) {
-            if (!out->room(sz)) return overflowed();
-            memcpy(out->p + out->size, src + p, sz);
-            out->size += sz;
+            // A stored block is passed through as its bytes arrive (LZ4F's copyDirect stage): what is there is
+            // delivered even if the block is cut short, and its checksum is only looked at by the read after
+            // the one that handed out its last byte (with the usual full-size stored block the crate's
+            // 32 KiB input buffer ends exactly at the block end).
+            const size_t avail = std::min(sz, n - p);
+            if (!out->room(avail)) return overflowed();
+            memcpy(out->p + out->size, src + p, avail);
+            out->size += avail;
+            if (out->size >= need) return Status::Ok();
+            const bool complete = avail == sz && (!block_checksum || n - p - sz >= 4);
+            if (!complete) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
+            if (block_checksum && rd32(src + p + sz) != xxh32(src + p, sz)) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_blockChecksum_invalid");
         } else {
-            Status st = lz4_block(src + p, sz, out, independent ? block_out_start : 0);
+            if (n - p < sz || (block_checksum && n - p - sz < 4)) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
+            if (block_checksum && rd32(src + p + sz) != xxh32(src + p, sz)) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_blockChecksum_invalid");
+            Status st = lz4_block(src + p, sz, out, independent ? block_out_start : 0, max_block);
             if (!st.ok()) return st;
-            if (out->size - block_out_start > max_block) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_decompressionFailed");
             // A compressed block is inflated into liblz4's own buffer and handed out `unit` bytes per read.
             // lz4::Decoder only calls LZ4F_decompress while it holds unread INPUT bytes or can fetch some
             // (decoder.rs: `if self.pos >= self.len { self.len = self.r.read(..)?; if self.len == 0 { break } }`),
@@ -215,7 +247,8 @@ static Status frame_core(const uint8_t *src, size_t n, size_t need, size_t unit,
     // 4 header bytes together with the block): an EndMark gets the content-size check — but not the
     // content checksum, whose 4 bytes are only fetched by a read that never comes — and an oversized
     // block header is rejected.
-    if (out->size == need && n - p >= 4) {
+    // (Behind a stored block the crate's input buffering decides what else liblz4 gets to see — not modelled.)
+    if (out->size == need && !after_stored && n - p >= 4) {
         const uint32_t bs = rd32(src + p);
         if (bs == 0) {
             if (has_size && content_size != out->size) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_frameSize_wrong");

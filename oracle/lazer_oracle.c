@@ -74,6 +74,10 @@ typedef struct {
     size_t have, cap, rd;  /* inflated bytes, capacity, bytes already handed out              */
     int stage;             /* 0 header not parsed, 1 in blocks, 2 frame finished, <0 error     */
     int dry;               /* an inflated block is buffered in liblz4 but no input byte is left  */
+    int last_stored;       /* the newest block was a stored one                                  */
+    int stored_open;       /* the newest block is a stored one whose checksum has not been looked at */
+    const uint8_t *stored_at;
+    size_t stored_len;
     int independent, block_sum, content_sum, has_size;
     uint64_t content_size;
     size_t max_block;
@@ -135,47 +139,75 @@ static int lz4r_header(lz4_reader *r) {
     return 0;
 }
 
-/* one compressed block -> appended to content */
+/* One compressed block -> appended to content.  liblz4's LZ4_decompress_safe (lz4.c,
+ * LZ4_decompress_generic: endOnInput, full decode, output capacity = the frame's maximum block size, as
+ * LZ4F uses it for its tmpOut buffer) restated with its end-of-block parsing restrictions, so that a
+ * damaged block is refused exactly when the real library refuses it:
+ *   MFLIMIT 12, LASTLITERALS 5, RUN_MASK 15; `ip` / `op` count from the start of the block. */
 static int lz4r_sequences(lz4_reader *r, const uint8_t *b, size_t bn, size_t floor) {
-    size_t i = 0, start = r->have;
-    while (i < bn) {
-        unsigned tok = b[i++];
-        size_t ll = tok >> 4;
-        if (ll == 15)
+    long long iend = (long long)bn, oend = (long long)r->max_block, ip = 0, op = 0;
+    if (bn == 0) return PCQO_ERR_HEADER;
+    for (;;) {
+        unsigned tok = b[ip++];
+        long long len = tok >> 4;
+        if (len == 15) { /* read_variable_length(&ip, iend - RUN_MASK, 1, 1): only the initial check is fatal */
+            if (ip >= iend - 15) return PCQO_ERR_HEADER;
             for (;;) {
-                if (i >= bn) return PCQO_ERR_HEADER;
-                unsigned x = b[i++];
-                ll += x;
+                unsigned x = b[ip++];
+                len += x;
+                if (ip >= iend - 15) break; /* loop_error: ignored by the caller */
                 if (x != 255) break;
             }
-        if (ll > bn - i) return PCQO_ERR_HEADER;
-        if (r->have - start + ll > r->max_block) return PCQO_ERR_HEADER;
-        if (lz4r_room(r, ll)) return PCQO_ERR_ARG;
-        memcpy(r->content + r->have, b + i, ll);
-        r->have += ll;
-        i += ll;
-        if (i == bn) return 0;
-        if (bn - i < 2) return PCQO_ERR_HEADER;
-        size_t dist = b[i] | (b[i + 1] << 8);
-        i += 2;
-        size_t ml = tok & 15;
-        if (ml == 15)
+        }
+        long long cpy = op + len;
+        if (cpy > oend - 12 || ip + len > iend - (2 + 1 + 5)) { /* parsing restriction: must be the last sequence */
+            if (ip + len != iend || cpy > oend) return PCQO_ERR_HEADER;
+            if (lz4r_room(r, (size_t)len)) return PCQO_ERR_ARG;
+            memcpy(r->content + r->have, b + ip, (size_t)len);
+            r->have += (size_t)len;
+            return 0;
+        }
+        if (lz4r_room(r, (size_t)len)) return PCQO_ERR_ARG;
+        memcpy(r->content + r->have, b + ip, (size_t)len);
+        r->have += (size_t)len;
+        ip += len;
+        op = cpy;
+        size_t dist = b[ip] | (b[ip + 1] << 8);
+        ip += 2;
+        long long ml = tok & 15;
+        if (ml == 15) /* read_variable_length(&ip, iend - LASTLITERALS + 1, 1, 0): any error is fatal */
             for (;;) {
-                if (i >= bn) return PCQO_ERR_HEADER;
-                unsigned x = b[i++];
+                unsigned x = b[ip++];
                 ml += x;
+                if (ip >= iend - 5 + 1) return PCQO_ERR_HEADER;
                 if (x != 255) break;
             }
         ml += 4;
-        if (dist == 0 || dist > r->have - floor) return PCQO_ERR_HEADER;
-        if (r->have - start + ml > r->max_block) return PCQO_ERR_HEADER;
-        if (lz4r_room(r, ml)) return PCQO_ERR_ARG;
-        for (size_t k = 0; k < ml; k++, r->have++) r->content[r->have] = r->content[r->have - dist];
+        if (dist > r->have - floor) return PCQO_ERR_HEADER; /* match + dictSize < lowPrefix */
+        if (dist == 0) return PCQO_ERR_HEADER;              /* liblz4 1.9.3 would copy stale buffer bytes: undefined result */
+        if (op + ml > oend - 5) return PCQO_ERR_HEADER;     /* last LASTLITERALS bytes must be literals */
+        if (lz4r_room(r, (size_t)ml)) return PCQO_ERR_ARG;
+        for (long long k = 0; k < ml; k++, r->have++) r->content[r->have] = r->content[r->have - dist];
+        op += ml;
     }
+}
+
+/* dstage_getBlockChecksum behind a stored block: reached once all of its bytes have been handed out */
+static int lz4r_close_stored(lz4_reader *r) {
+    if (!r->stored_open) return 0;
+    if (r->stored_open == 2) return PCQO_ERR_EOF; /* the block was cut short */
+    if (r->block_sum) {
+        if (r->n - r->ip < 4) return PCQO_ERR_EOF;
+        if (le32(r->src + r->ip) != pcqo_xxh32(r->stored_at, r->stored_len)) return PCQO_ERR_HEADER;
+        r->ip += 4;
+    }
+    r->stored_open = 0;
     return 0;
 }
 
 static int lz4r_next_block(lz4_reader *r) {
+    int pending = lz4r_close_stored(r);
+    if (pending) return pending;
     if (r->n - r->ip < 4) return PCQO_ERR_EOF;
     uint32_t word = le32(r->src + r->ip);
     r->ip += 4;
@@ -191,16 +223,23 @@ static int lz4r_next_block(lz4_reader *r) {
     }
     size_t len = word & 0x7FFFFFFFu;
     if (len > r->max_block) return PCQO_ERR_HEADER;
-    if (r->n - r->ip < len + (r->block_sum ? 4u : 0u)) return PCQO_ERR_EOF;
     const uint8_t *b = r->src + r->ip;
-    if (r->block_sum && le32(b + len) != pcqo_xxh32(b, len)) return PCQO_ERR_HEADER;
-    r->ip += len + (r->block_sum ? 4 : 0);
-    if (word >> 31) {
-        if (lz4r_room(r, len)) return PCQO_ERR_ARG;
-        memcpy(r->content + r->have, b, len);
-        r->have += len;
+    r->last_stored = (int)(word >> 31);
+    if (word >> 31) { /* stored: LZ4F's copyDirect passes the bytes through as they arrive; the block checksum
+                       * comes after the data and is checked once the data is out */
+        size_t avail = r->n - r->ip < len ? r->n - r->ip : len;
+        if (lz4r_room(r, avail)) return PCQO_ERR_ARG;
+        memcpy(r->content + r->have, b, avail);
+        r->have += avail;
+        r->ip += avail;
+        r->stored_open = avail < len ? 2 : 1;
+        r->stored_at = b;
+        r->stored_len = len;
         return 0;
     }
+    if (r->n - r->ip < len + (r->block_sum ? 4u : 0u)) return PCQO_ERR_EOF;
+    if (r->block_sum && le32(b + len) != pcqo_xxh32(b, len)) return PCQO_ERR_HEADER;
+    r->ip += len + (r->block_sum ? 4 : 0);
     int e = lz4r_sequences(r, b, len, r->independent ? r->have : 0);
     /* lz4::Decoder::read only calls LZ4F_decompress while it has unread input or can fetch more
      * (decoder.rs: `if self.pos >= self.len { self.len = self.r.read(..)?; if self.len == 0 { break; } }`).
@@ -227,11 +266,14 @@ static int lz4r_read_exact(lz4_reader *r, void *dst, size_t want) {
     }
     memcpy(dst, r->content + r->rd, want);
     r->rd += want;
+    /* (the checksum of a stored block is looked at by the NEXT read: with the usual full-size stored
+     * block the crate's 32 KiB input buffer ends exactly at the end of the block data) */
     /* The LZ4F_decompress call that flushes the last byte of a block moves on to the next block header
      * if the input holds it (the crate feeds `block + 4` bytes at a time): an EndMark is followed by the
      * content-size check (dstage_getSuffix) — the content checksum needs 4 more input bytes, which only
      * a further read would fetch — and a header announcing more than the maximum block size is an error. */
-    if (r->rd == r->have && r->stage == 1 && !r->dry && r->n - r->ip >= 4) {
+    /* (behind a stored block the crate's input buffering decides what else liblz4 sees: not modelled) */
+    if (r->rd == r->have && r->stage == 1 && !r->dry && !r->last_stored && r->n - r->ip >= 4) {
         uint32_t word = le32(r->src + r->ip);
         if (word == 0) {
             if (r->has_size && r->content_size != r->have) return r->stage = PCQO_ERR_HEADER;

@@ -354,3 +354,164 @@ def test_golden_lazer_file(oracle):
         assert oracle.search_lazer_class(image, q["class"], c) == OK
         assert c.point_count() == q["count"]
         c.free()
+
+
+# ---- differential fuzz: mutated frames through the real reader, the oracle and the product ---------------------
+@needs_liblz4
+def test_mutated_frames_differential(oracle, product):
+    """Random damage (bit flips, truncation, splices, length-field edits) to real liblz4 frames: both
+    readers must end exactly like lz4::Decoder over the real LZ4F_decompress — same error class, and the
+    same bytes when the read succeeds — for the reference's read sizes."""
+    rng = np.random.default_rng(0xF022)
+    base = []
+    text = contents()["text"][:140_000]
+    xyz = contents()["xyz"][:100_000]
+    for data in (text, xyz, b"abcabcabc" * 30, bytes(70_000)):
+        for kw in (dict(), dict(independent=True, block_checksum=True, content_size=True), dict(content_checksum=False, block_checksum=True),
+                   dict(content_checksum=False, content_size=True)):
+            base.append((data, REAL.compress_frame(data, 4, **kw)))
+    checked = errors = 0
+    for it in range(400):
+        data, frame = base[it % len(base)]
+        fr = bytearray(frame)
+        kind = it % 5
+        if kind == 0:  # bit flips anywhere
+            for _ in range(int(rng.integers(1, 4))):
+                fr[int(rng.integers(0, len(fr)))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:  # truncation
+            fr = fr[:int(rng.integers(0, len(fr)))]
+        elif kind == 2:  # damage in the header / first block header
+            fr[int(rng.integers(4, min(24, len(fr))))] = int(rng.integers(0, 256))
+        elif kind == 3:  # cut a slice out of the middle
+            a = int(rng.integers(7, len(fr) - 1))
+            b = min(len(fr), a + int(rng.integers(1, 64)))
+            fr = fr[:a] + fr[b:]
+        else:  # truncation exactly at a block boundary (walk the block headers of the intact frame)
+            p = 4 + 2 + (8 if frame[4] & 8 else 0) + 1
+            cuts = []
+            while p + 4 <= len(frame):
+                w = int.from_bytes(frame[p:p + 4], "little")
+                if w == 0:
+                    cuts += [p, p + 4]
+                    break
+                p += 4 + (w & 0x7FFFFFFF) + (4 if frame[4] & 0x10 else 0)
+                cuts.append(p)
+            fr = fr[:cuts[int(rng.integers(0, len(cuts)))]]
+        fr = bytes(fr)
+        need = [len(data), len(data) // 2 + 1, 65536, 65537, 1][int(rng.integers(0, 5))]
+        need = min(need, len(data))
+        for unit in (4, 1) if it % 3 else (2, 0):
+            try:
+                want, real = REAL.read_exact(fr, need, unit), OK
+            except _lz4ref.UnexpectedEof:
+                want, real = None, ERR_EOF
+            except _lz4ref.LZ4Error:
+                want, real = None, ERR_HEADER
+            got_o, rc_o = oracle.lz4f_decode(fr, need, unit)
+            got_p, rc_p = product(fr, need, unit)
+            assert rc_o == real and rc_p == real, (it, kind, need, unit, real, rc_o, rc_p)
+            if real == OK:
+                assert got_o == want and got_p == want, (it, kind, need, unit)
+            else:
+                errors += 1
+            checked += 1
+    assert checked >= 800 and errors > 200
+
+
+@needs_liblz4
+def test_stored_blocks_are_passed_through_as_they_arrive(oracle, product):
+    """Incompressible columns (noisy i32 positions) make liblz4 emit stored blocks.  LZ4F hands their bytes
+    out as they arrive: a cut-off stored block still yields what is there, and its block checksum is looked at
+    only by the read after its last byte."""
+    data = contents()["random"][:66_000]
+    frame = REAL.compress_frame(data, 4, False, False, True, False)  # block checksums, no content checksum
+    first = int.from_bytes(frame[7:11], "little")
+    assert first >> 31 and first & 0x7FFFFFFF == 65536  # a full stored block, then a short one
+
+    def outcome(fr, need):
+        res = set()
+        for unit in (4, 2, 1):
+            try:
+                want, real = REAL.read_exact(fr, need, unit), OK
+            except _lz4ref.UnexpectedEof:
+                want, real = None, ERR_EOF
+            except _lz4ref.LZ4Error:
+                want, real = None, ERR_HEADER
+            got_o, rc_o = oracle.lz4f_decode(fr, need, unit)
+            got_p, rc_p = product(fr, need, unit)
+            assert rc_o == real and rc_p == real, (need, unit, real, rc_o, rc_p)
+            if real == OK:
+                assert got_o == want == got_p
+            res.add(real)
+        assert len(res) == 1
+        return res.pop()
+
+    assert outcome(frame, 66_000) == OK
+    cut = frame[:11 + 40_000]  # inside the first stored block
+    assert outcome(cut, 40_000) == OK
+    assert outcome(cut, 39_999) == OK
+    assert outcome(cut, 40_001) == ERR_EOF
+    bad = bytearray(frame)
+    bad[11 + 65536] ^= 0xFF  # the first block's checksum
+    bad = bytes(bad)
+    assert outcome(bad, 65_536) == OK  # all of the block's data, checksum not looked at yet
+    assert outcome(bad, 65_537) == ERR_HEADER
+    flip = bytearray(frame)
+    flip[11 + 100] ^= 1  # damaged data, intact checksum field
+    assert outcome(bytes(flip), 65_536) == OK
+    assert outcome(bytes(flip), 65_540) == ERR_HEADER
+
+
+def test_lz4_reader_under_address_sanitizer(oracle, tmp_path):
+    """The product's LZ4 Frame reader parses untrusted bytes on the host: run it, built with ASan + UBSan
+    (CPU build only; GPU sanitizers are not available), over damaged frames of every kind."""
+    import shutil
+    import struct
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "lz4_asan")
+    host = os.path.join(PKG, "host")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+           "-I" + os.path.join(ROOT, "include"), "-I" + host, os.path.join(ROOT, "tests", "native", "lz4_asan_driver.cpp"),
+           os.path.join(host, "lz4_frame.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr and "cannot find" in r.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr
+    rng = np.random.default_rng(99)
+    c = contents()
+    frames = []
+    for data in (c["text"][:140_000], c["xyz"][:80_000], c["random"][:66_000], b"abcabcabc" * 30, bytes(70_000), c["period3"][:131_077]):
+        for flags in (0, 1 | 2 | 8, 4, 2 | 4, 16 | 2, 4 | 8):
+            frames.append((len(data), oracle.lz4f_compress(data, flags, 4)))
+    corpus = str(tmp_path / "corpus.bin")
+    n_cases = 0
+    with open(corpus, "wb") as f:
+        for it in range(3000):
+            size, frame = frames[int(rng.integers(0, len(frames)))]
+            fr = bytearray(frame)
+            k = int(rng.integers(0, 6))
+            if k == 0:
+                for _ in range(int(rng.integers(1, 5))):
+                    fr[int(rng.integers(0, len(fr)))] ^= 1 << int(rng.integers(0, 8))
+            elif k == 1:
+                fr = fr[:int(rng.integers(0, len(fr) + 1))]
+            elif k == 2:
+                fr[int(rng.integers(4, min(24, len(fr))))] = int(rng.integers(0, 256))
+            elif k == 3:
+                a = int(rng.integers(7, len(fr) - 1))
+                fr = fr[:a] + fr[min(len(fr), a + int(rng.integers(1, 64))):]
+            elif k == 4:  # random bytes spliced in (long literal / match length runs of 0xFF among them)
+                a = int(rng.integers(7, len(fr) - 1))
+                junk = bytes([255] * int(rng.integers(1, 40))) if it % 2 else rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8).tobytes()
+                fr = fr[:a] + junk + fr[a:]
+            need = int([size, size // 2 + 1, 65536, 65537, 1, 0, size + 5, 2 * size][int(rng.integers(0, 8))])
+            unit = int([4, 2, 1, 0][int(rng.integers(0, 4))])
+            f.write(struct.pack("<III", len(fr), need, unit) + bytes(fr))
+            n_cases += 1
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe, corpus], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    tag, cases, errors = r.stdout.split()
+    assert tag == "ok" and int(cases) == n_cases and int(errors) > n_cases // 3
