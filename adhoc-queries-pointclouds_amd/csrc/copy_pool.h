@@ -1,0 +1,121 @@
+// copy_pool.h — a few helper threads that fill a pinned staging buffer in parallel slices.
+//
+// The host-block path (pcq_scan_host / pcq_scan_fd) is bound by how fast host bytes reach the pinned
+// buffer the DMA engine reads from: one thread's memcpy / pread from the page cache runs at about half
+// the PCIe Gen5 x16 rate (profiles/r01_host_path_rate.json), so the copy is split over the calling
+// thread plus `helpers` workers.  Fork-join per staging chunk; no work is queued across calls.
+#pragma once
+
+#include <errno.h>
+#include <string.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+class CopyPool {
+public:
+    // result of run(): 0, or 1 = short read (end of file), or -errno of a failed pread
+    explicit CopyPool(int helpers) {
+        for (int i = 0; i < helpers; i++) workers_.emplace_back([this] { loop(); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> g(m_);
+            stop_ = true;
+        }
+        wake_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    CopyPool(const CopyPool &) = delete;
+    CopyPool &operator=(const CopyPool &) = delete;
+
+    int helpers() const { return (int)workers_.size(); }
+
+    int run(int fd, uint8_t *dst, const uint8_t *src, size_t bytes) {
+        constexpr size_t kMinSlice = 1u << 20;
+        size_t parts = bytes / kMinSlice;
+        if (parts > workers_.size() + 1) parts = workers_.size() + 1;
+        if (parts <= 1) return copy(fd, dst, src, bytes);
+        const size_t slice = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+        {
+            std::lock_guard<std::mutex> g(m_);
+            fd_ = fd;
+            dst_ = dst;
+            src_ = src;
+            bytes_ = bytes;
+            slice_ = slice;
+            nslices_ = (bytes + slice - 1) / slice;
+            next_.store(0, std::memory_order_relaxed);
+            pending_ = nslices_;
+            result_ = 0;
+            generation_++;
+        }
+        wake_.notify_all();
+        work();
+        std::unique_lock<std::mutex> g(m_);
+        done_.wait(g, [this] { return pending_ == 0; });
+        return result_;
+    }
+
+private:
+    static int copy(int fd, uint8_t *dst, const uint8_t *src, size_t bytes) {
+        if (fd < 0) {
+            memcpy(dst, src, bytes);
+            return 0;
+        }
+        off_t off = (off_t)(uintptr_t)src;
+        while (bytes) {
+            const ssize_t r = pread(fd, dst, bytes, off);
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                return -errno;
+            }
+            if (r == 0) return 1;
+            dst += r;
+            off += r;
+            bytes -= (size_t)r;
+        }
+        return 0;
+    }
+    void work() {
+        for (;;) {
+            const size_t k = next_.fetch_add(1, std::memory_order_relaxed);
+            if (k >= nslices_) return;
+            const size_t at = k * slice_;
+            const size_t len = bytes_ - at < slice_ ? bytes_ - at : slice_;
+            const int r = copy(fd_, dst_ + at, src_ + at, len);
+            std::lock_guard<std::mutex> g(m_);
+            if (r && !result_) result_ = r;
+            if (--pending_ == 0) done_.notify_all();
+        }
+    }
+    void loop() {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> g(m_);
+                wake_.wait(g, [&] { return stop_ || generation_ != seen; });
+                if (stop_) return;
+                seen = generation_;
+            }
+            work();
+        }
+    }
+
+    std::vector<std::thread> workers_;
+    std::mutex m_;
+    std::condition_variable wake_, done_;
+    bool stop_ = false;
+    uint64_t generation_ = 0;
+    int fd_ = -1;
+    uint8_t *dst_ = nullptr;
+    const uint8_t *src_ = nullptr;
+    size_t bytes_ = 0, slice_ = 0, nslices_ = 0, pending_ = 0;
+    std::atomic<size_t> next_{0};
+    int result_ = 0;
+};

@@ -78,6 +78,10 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
         const long long v = atoll(e);
         if (v >= 4) ctx->chunk_points = (uint64_t)v;
     }
+    if (const char *e = getenv("PCQ_COPY_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) ctx->copy_threads = v;
+    }
     if (const char *e = getenv("PCQ_K1_VARIANT")) {
         const int v = atoi(e);
         if (v >= 0 && v <= 7) ctx->k1_variant = v;
@@ -97,6 +101,8 @@ extern "C" int pcq_shutdown(pcq_ctx *ctx) {
         if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
         if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
     }
+    delete ctx->copy_pool;
+    ctx->copy_pool = nullptr;
     pcq_grid_cache_clear(ctx);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
@@ -156,6 +162,9 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
         if (value < 1 || value > 16) return pcq_fail(PCQ_ERR_ARG, "blocks_per_cu must be 1..16");
         ctx->grid_blocks_per_cu = (int)value;
         ctx->batch_blocks_per_cu = (int)value;
+    } else if (!strcmp(key, "copy_threads")) {
+        if (value < 1 || value > 64) return pcq_fail(PCQ_ERR_ARG, "copy_threads must be 1..64");
+        ctx->copy_threads = (int)value;
     } else if (!strcmp(key, "chunk_points")) {
         if (value < 4) return pcq_fail(PCQ_ERR_ARG, "chunk_points must be >= 4");
         ctx->chunk_points = (uint64_t)value;
@@ -574,23 +583,15 @@ static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 // Copies `bytes` from the host source into pinned memory: memcpy from caller memory, or — when the
 // columns are given as offsets into an open file (pcq_scan_fd) — pread straight from the page cache
 // (no mmap page-table work: measured ~2x the rate of memcpy from a freshly mmapped file).
-static int fetch(int fd, uint8_t *dst, const uint8_t *src, size_t bytes) {
-    if (fd < 0) {
-        memcpy(dst, src, bytes);
-        return PCQ_OK;
+// The copy is split over the context's helper threads (copy_pool.h).
+static int fetch(pcq_ctx *ctx, int fd, uint8_t *dst, const uint8_t *src, size_t bytes) {
+    if (!ctx->copy_pool || ctx->copy_pool->helpers() != ctx->copy_threads - 1) {
+        delete ctx->copy_pool;
+        ctx->copy_pool = new CopyPool(ctx->copy_threads - 1);
     }
-    off_t off = (off_t)(uintptr_t)src;
-    while (bytes) {
-        const ssize_t r = pread(fd, dst, bytes, off);
-        if (r < 0) {
-            if (errno == EINTR) continue;
-            return pcq_fail(PCQ_ERR_IO, "pread failed: %s", strerror(errno));
-        }
-        if (r == 0) return pcq_fail(PCQ_ERR_EOF, "failed to fill whole buffer");
-        dst += r;
-        off += r;
-        bytes -= (size_t)r;
-    }
+    const int r = ctx->copy_pool->run(fd, dst, src, bytes);
+    if (r < 0) return pcq_fail(PCQ_ERR_IO, "pread failed: %s", strerror(-r));
+    if (r > 0) return pcq_fail(PCQ_ERR_EOF, "failed to fill whole buffer");
     return PCQ_OK;
 }
 
@@ -665,13 +666,13 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
         if (pl.aos) {
             // up to the last needed byte of the last record (never past the caller's mapping)
             bytes = (size_t)((cnt - 1) * pl.stride + pl.span);
-            int frc = fetch(fd, h, pl.aos_base + first * pl.stride, bytes);
+            int frc = fetch(ctx, fd, h, pl.aos_base + first * pl.stride, bytes);
             if (frc) return frc;
         } else {
             int frc = PCQ_OK;
-            if (pl.need_xyz) frc = fetch(fd, h + off_xyz, hx + first * 12, (size_t)cnt * 12);
-            if (!frc && pl.need_cls) frc = fetch(fd, h + off_cls, hc + first, (size_t)cnt);
-            if (!frc && pl.need_rgb) frc = fetch(fd, h + off_rgb, hr + first * 6, (size_t)cnt * 6);
+            if (pl.need_xyz) frc = fetch(ctx, fd, h + off_xyz, hx + first * 12, (size_t)cnt * 12);
+            if (!frc && pl.need_cls) frc = fetch(ctx, fd, h + off_cls, hc + first, (size_t)cnt);
+            if (!frc && pl.need_rgb) frc = fetch(ctx, fd, h + off_rgb, hr + first * 6, (size_t)cnt * 6);
             if (frc) return frc;
             bytes = off_rgb + (pl.need_rgb ? (size_t)cnt * 6 : 0);
             if (!pl.need_rgb) bytes = off_cls + (pl.need_cls ? (size_t)cnt : 0);

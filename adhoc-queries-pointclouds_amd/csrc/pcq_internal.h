@@ -1,6 +1,7 @@
 // pcq_internal.h — shared declarations of libpcq.so (not part of the public ABI; see include/pcq.h).
 #pragma once
 
+#include "copy_pool.h"
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -139,6 +140,8 @@ struct pcq_ctx {
     int k1_variant = 0;
     int grid_blocks_per_cu = 2;   // persistent blocks per CU of the streaming count kernels: 8 waves x 3 KiB in flight per CU measured best (profiles/r01_k1_variant_sweep_interleaved.log)
     int batch_blocks_per_cu = 3;  // the batched K1 measured best at 3 (same log)
+    int copy_threads = 4;         // threads filling a staging buffer (caller + helpers); tools/host_path_rate.py
+    CopyPool *copy_pool = nullptr;  // created on first use by pcq_scan_host / pcq_scan_fd
     uint64_t chunk_points = 2ull << 20;    // 24 MB of positions per staging chunk (profiles/r01_host_path_rate.json: 1-8 Mi equal)
 };
 

@@ -228,7 +228,8 @@ int pcq_copy_to_device(pcq_ctx *ctx, void *dst_device, const void *src_host, uin
 int pcq_copy_to_host(pcq_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
 int pcq_device_memset(pcq_ctx *ctx, void *dst_device, int value, uint64_t bytes, void *stream);
 
-/* Tuning knob for experiments: selects the bounds-count kernel variant (0 = default). */
+/* Tuning knobs: "k1_variant" (bounds-count kernel variant, 0 = default), "blocks_per_cu", "chunk_points"
+ * (points per staging chunk of the host paths), "copy_threads" (threads filling a staging chunk, default 4). */
 int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value);
 
 #ifdef __cplusplus

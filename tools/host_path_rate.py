@@ -39,8 +39,9 @@ def main():
         cols = binding.make_columns(xyz=host.ctypes.data, n=n, scale=list(spec.scale), offset=list(spec.offset))
         pred = pkg.Predicate.bounds(lmin, lmax)
         out = {}
-        for chunk in (1 << 20, 8 << 20, 32 << 20):
+        for threads, chunk in ((1, 2 << 20), (2, 2 << 20), (4, 1 << 20), (4, 2 << 20), (4, 8 << 20), (6, 2 << 20), (8, 2 << 20), (8, 8 << 20)):
             ctx.set_option("chunk_points", chunk)
+            ctx.set_option("copy_threads", threads)
             times = []
             for _ in range(args.rounds + 1):
                 cc = ctx.count_collector()
@@ -51,7 +52,7 @@ def main():
                 cc.free()
             times = sorted(times[1:])
             med = times[len(times) // 2]
-            out[f"chunk_{chunk}"] = {"seconds": med, "mpoints_per_s": n / med / 1e6, "gb_per_s": 12 * n / med / 1e9, "count": cnt}
+            out[f"threads_{threads}_chunk_{chunk}"] = {"seconds": med, "mpoints_per_s": n / med / 1e6, "gb_per_s": 12 * n / med / 1e9, "count": cnt}
         print(json.dumps({"points": n, "path": "pageable host memory -> pinned staging (memcpy) -> hipMemcpyAsync -> K1", **out}))
 
 
