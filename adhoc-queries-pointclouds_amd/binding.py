@@ -153,6 +153,7 @@ def load_library() -> C.CDLL:
         "pcq_synth_fill_dev": (C.c_int, [vp, P(SynthSpec), u64, u64, vp, vp, vp]),
         "pcq_membench_read": (C.c_int, [vp, vp, u64, C.c_int, C.c_int, C.c_int, vp]),
         "pcq_membench_read_tiles": (C.c_int, [vp, vp, u64, C.c_int, C.c_int, C.c_int, vp]),
+        "pcq_membench_read_xcd": (C.c_int, [vp, vp, u64, C.c_int, C.c_int, C.c_int, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)

@@ -62,7 +62,63 @@ __global__ void k_read_tiles(const v4i *__restrict__ p, uint64_t nvec, uint32_t 
     if (x == 0x9e3779b9u) sink[0] = x;
 }
 
+// The same 3 KiB wave tiles as K1, with the workgroup -> tile mapping made XCD-aware in two ways.
+// Workgroups are dealt round-robin to the 8 XCDs (block b runs on XCD b % 8), each with its own L2.
+//   MAP 0: tile = wave + k * nwaves (K1's mapping: neighbouring tiles land on different XCDs)
+//   MAP 1: blocks renumbered so that every XCD owns a contiguous eighth of each grid-wide window
+//   MAP 2: every XCD streams its own contiguous eighth of the whole buffer
+template <int MAP>
+__global__ void k_read_tiles_xcd(const v4i *__restrict__ p, uint64_t nvec, uint32_t *__restrict__ sink) {
+    constexpr int LOADS = 3;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wpb = blockDim.x >> 6;
+    const uint32_t w_in_block = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t tiles = nvec / (64 * LOADS);
+    const uint64_t per_xcd = gridDim.x / 8;  // launch with gridDim.x % 8 == 0
+    const uint64_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    v4i acc = {0, 0, 0, 0};
+    auto body = [&](uint64_t t) {
+        const uint64_t b = t * 64 * LOADS + lane;
+        v4i v[LOADS];
+#pragma unroll
+        for (int u = 0; u < LOADS; u++) v[u] = __builtin_nontemporal_load(p + b + 64 * u);
+#pragma unroll
+        for (int u = 0; u < LOADS; u++) acc ^= v[u];
+    };
+    if (MAP == 0) {
+        const uint64_t wave = (uint64_t)blockIdx.x * wpb + w_in_block, nwaves = (uint64_t)gridDim.x * wpb;
+        for (uint64_t t = wave; t < tiles; t += nwaves) body(t);
+    } else if (MAP == 1) {
+        const uint64_t wave = (xcd * per_xcd + slot) * wpb + w_in_block, nwaves = (uint64_t)gridDim.x * wpb;
+        for (uint64_t t = wave; t < tiles; t += nwaves) body(t);
+    } else {
+        const uint64_t share = (tiles + 7) / 8, lo = xcd * share, hi = lo + share < tiles ? lo + share : tiles;
+        const uint64_t wave = slot * wpb + w_in_block, nwaves = per_xcd * wpb;
+        for (uint64_t t = lo + wave; t < hi; t += nwaves) body(t);
+    }
+    const uint32_t x = (uint32_t)(acc[0] ^ acc[1] ^ acc[2] ^ acc[3]);
+    if (x == 0x9e3779b9u) sink[0] = x;
+}
+
 }  // namespace
+
+extern "C" int pcq_membench_read_xcd(pcq_ctx *ctx, const void *d_buf, uint64_t bytes, int mapping, int threads, int blocks,
+                                     void *stream) {
+    if (!ctx || !d_buf || ((uintptr_t)d_buf & 15) || threads < 64 || threads > 1024 || (threads & 63) || blocks < 8 || (blocks & 7))
+        return pcq_fail(PCQ_ERR_ARG, "pcq_membench_read_xcd: bad arguments (blocks must be a multiple of 8)");
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const uint64_t nvec = bytes / 16;
+    const v4i *p = reinterpret_cast<const v4i *>(d_buf);
+    uint32_t *sink = reinterpret_cast<uint32_t *>(ctx->d_scalars + 32);
+    switch (mapping) {
+    case 0: hipLaunchKernelGGL(k_read_tiles_xcd<0>, dim3(blocks), dim3(threads), 0, s, p, nvec, sink); break;
+    case 1: hipLaunchKernelGGL(k_read_tiles_xcd<1>, dim3(blocks), dim3(threads), 0, s, p, nvec, sink); break;
+    case 2: hipLaunchKernelGGL(k_read_tiles_xcd<2>, dim3(blocks), dim3(threads), 0, s, p, nvec, sink); break;
+    default: return pcq_fail(PCQ_ERR_ARG, "pcq_membench_read_xcd: mapping 0..2");
+    }
+    PCQ_HIP(hipGetLastError());
+    return PCQ_OK;
+}
 
 extern "C" int pcq_membench_read_tiles(pcq_ctx *ctx, const void *d_buf, uint64_t bytes, int loads, int threads, int blocks,
                                        void *stream) {

@@ -50,6 +50,12 @@ int pcq_membench_read(pcq_ctx *ctx, const void *d_buf, uint64_t bytes, int shape
 int pcq_membench_read_tiles(pcq_ctx *ctx, const void *d_buf, uint64_t bytes, int loads, int threads, int blocks,
                             void *stream);
 
+/* Same 3 KiB wave tiles with an XCD-aware workgroup -> tile mapping (0 = K1's, 1 = XCD-contiguous inside
+ * each grid-wide window, 2 = one contiguous eighth of the buffer per XCD); blocks % 8 == 0.
+ * tools/xcd_mapping_sweep.py. */
+int pcq_membench_read_xcd(pcq_ctx *ctx, const void *d_buf, uint64_t bytes, int mapping, int threads, int blocks,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif
