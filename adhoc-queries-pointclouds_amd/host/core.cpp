@@ -8,6 +8,7 @@
 
 #include <cerrno>
 #include <cstring>
+#include <mutex>
 #include <map>
 
 namespace pcq {
@@ -175,7 +176,14 @@ Status thread_context(int device, pcq_ctx **out) {
         return Status::Ok();
     }
     pcq_ctx *ctx = nullptr;
-    const int rc = pcq_init(device, &ctx);
+    int rc;
+    {
+        // one at a time: HIP start-up (runtime init, first queue creation) run concurrently from several
+        // threads was measured to take longer in total than back to back
+        static std::mutex init_mutex;
+        std::lock_guard<std::mutex> g(init_mutex);
+        rc = pcq_init(device, &ctx);
+    }
     if (rc) return Status::FromLib(rc);
     tc.by_device[device] = ctx;
     *out = ctx;

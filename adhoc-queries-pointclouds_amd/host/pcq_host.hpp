@@ -224,7 +224,10 @@ struct FileStat {  // filled by the drivers when RunOptions::stats is set (extra
 };
 struct RunOptions {
     std::vector<int> devices = {0};  // GPUs to use; files are the independent units (main.rs:153-161)
-    int threads_per_device = 2;      // host threads feeding each GPU in --parallel mode
+    // host threads feeding each GPU in --parallel mode.  One is the measured optimum: the library splits
+    // the staging copy over its own helper threads and reaches the PCIe rate from a single caller, while a
+    // second context on the same GPU costs another ~100-200 ms of HIP start-up (profiles/r01_cli_fixed_cost.log)
+    int threads_per_device = 1;
     std::vector<FileStat> *stats = nullptr;
 };
 // stdout lines go through `print` (so tests can capture them).

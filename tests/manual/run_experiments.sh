@@ -1,0 +1,18 @@
+#!/bin/bash
+# Manual: the paper's five experiments on scaled-down synthetic datasets, product CLI next to the oracle CLI.
+#   tests/manual/run_experiments.sh OUTDIR [points flags for make_experiment_datasets.py]
+set -e
+OUT=${1:-gpurun_out/experiments}; shift || true
+ROOT=$(mktemp -d /tmp/pcq_exp.XXXXXX)
+trap 'rm -rf "$ROOT"' EXIT
+mkdir -p "$OUT"
+python tests/manual/make_experiment_datasets.py "$ROOT" "$@" | tee "$OUT/datasets.txt"
+DRV=adhoc-queries-pointclouds_amd/host/run_query_experiments
+for e in 1 2 3 4 5; do
+  echo "== experiment $e (product, 5 runs, warm cache)" | tee -a "$OUT/product.txt"
+  $DRV -i "$ROOT" -e $e --extensions las,last,lazer 2>>"$OUT/product.err" | tee -a "$OUT/product.txt"
+done
+for e in 1 2 3 4 5; do
+  echo "== experiment $e (oracle CLI: single-threaded restatement of the reference, 1 run)" | tee -a "$OUT/oracle.txt"
+  $DRV -i "$ROOT" -e $e --extensions las,last,lazer --runs 1 --query oracle/query_oracle 2>>"$OUT/oracle.err" | tee -a "$OUT/oracle.txt"
+done
