@@ -227,3 +227,46 @@ def test_get_total_bounds_is_the_union_of_header_boxes(oracle, qlib, tmp_path):
     open(bad, "wb").write(b"not a las file at all")
     arr2 = (C.c_char_p * 1)(bad.encode())
     assert qlib.pcq_query_get_total_bounds(arr2, 1, mn, mx) == -2
+
+
+def test_run_query_experiments_driver_protocol(oracle, tmp_path):
+    """host/run_query_experiments mirrors query/src/bin/run_query_experiments.rs: directory layout
+    <root>/<dataset>/<ext>/, 5 runs, `name;mean;median;stddev` lines.  Driven here with the oracle CLI as
+    the `query` executable (no GPU)."""
+    import importlib
+    import subprocess
+    specs = importlib.import_module("adhoc-queries-pointclouds_amd.synth_specs")
+    root = tmp_path / "data"
+    for name, ss in (("navvis3", specs.synth_navvis(points_per_file=3000)), ("doc", specs.synth_doc(points_per_file=1000, files=2)),
+                     ("ca13", specs.synth_ca13(points_per_file=1000, files=3))):
+        for ext in ("las", "last"):
+            d = root / name / ext
+            d.mkdir(parents=True)
+            for i, s in enumerate(ss):
+                oracle.synth_write(s, str(d / f"f{i}.{ext}"))
+    drv = os.path.join(PKG, "host", "run_query_experiments")
+    q = os.path.join(ROOT, "oracle", "query_oracle")
+
+    def run(exp, *extra):
+        r = subprocess.run([drv, "-i", str(root), "-e", str(exp), "--extensions", "las,last", "--query", q, *extra],
+                           capture_output=True, text=True)
+        return r.returncode, r.stdout.splitlines(), r.stderr
+
+    rc, lines, err = run(1, "--runs", "3")
+    assert rc == 0, err
+    want = [f"navvis3_{b}_{k}_{e}" for b in ("s", "l", "xl") for k in ("full", "lod") for e in ("las", "last")]
+    assert [l.split(";")[0] for l in lines] == want  # run_query_experiments.rs:153-190, :257-285
+    for l in lines:
+        name, mean, med, sd = l.split(";")
+        assert float(mean) > 0 and float(med) > 0 and float(sd) >= 0
+    assert "Running experiments... Output is: experiment_name;mean;median;stddev with runtimes in seconds" in err
+    assert "Experiment navvis3_s_las..." in err
+    rc, lines, err = run(5, "--runs", "1")
+    assert rc == 0 and [l.split(";")[0] for l in lines] == ["ca13_building_las", "ca13_building_last", "ca13_noclass_las", "ca13_noclass_last"]
+    assert all(l.endswith(";0") for l in lines)  # one run: stddev 0
+    rc, lines, err = run(4, "--runs", "1", "--cold")
+    assert rc == 0 and len(lines) == 4
+    assert run(6)[0] == 1 and "Invalid experiment ID 6" in run(6)[2]
+    # a format the query cannot search fails the run, like the reference's `?` on the child's exit status
+    rc, lines, err = subprocess.run([drv, "-i", str(root), "-e", "1", "--query", q, "--runs", "1"], capture_output=True, text=True).returncode, None, None
+    assert rc == 1
