@@ -683,13 +683,20 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
         return PCQ_OK;
     };
 
+    // on any failure the copies and kernels already queued must drain before the staging buffers (or the
+    // caller's memory) can be touched again
+    auto fail = [&](int code) {
+        (void)hipStreamSynchronize(cs);
+        (void)hipStreamSynchronize(s);
+        return code;
+    };
     rc = stage(0);
-    if (rc) return rc;
+    if (rc) return fail(rc);
     for (uint64_t k = 0; k < nchunks; k++) {
         const int b = (int)(k & 1);
         if (k + 1 < nchunks) {  // stage the next chunk while this one is scanned
             rc = stage(k + 1);
-            if (rc) return rc;
+            if (rc) return fail(rc);
         }
         const uint64_t first = k * chunk;
         const uint64_t cnt = cols->n - first < chunk ? cols->n - first : chunk;
@@ -708,7 +715,7 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
         dcols.n = cnt;
         dcols.first_index = cols->first_index + first;
         rc = scan_dev_impl(ctx, &dcols, pred, c, s);
-        if (rc) return rc;
+        if (rc) return fail(rc);
         PCQ_HIP(hipEventRecord(ctx->consumed[b], s));
     }
     PCQ_HIP(hipStreamSynchronize(s));

@@ -149,3 +149,61 @@ def test_random_files_and_queries(oracle, tmp_path, seed):
             assert q.count(hc) == oc.point_count(), (meta, cls)
             assert q.points(hb).tobytes() == ob.points().tobytes(), (meta, cls)
         q.free(hc), q.free(hb), oc.free(), ob.free()
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_lazer_files_and_queries(oracle, tmp_path, seed):
+    """The same randomly built point sets as LAZER files (random block size, LZ4 frame flags, every point
+    format): world-space `contains` on the GPU vs the oracle's streaming restatement, boxes whose faces
+    pass exactly through points included; n = 0 panics on both sides (lazer_reader.rs:123,143)."""
+    rng = np.random.default_rng(7000 + seed)
+    q = Q()
+    image, world, meta = build(rng, True)
+    if meta["n"] == 0:
+        blocks = [1]
+    else:
+        blocks = [int(rng.choice([1, 2, 63, 64, 100, 1000, 4096, max(1, meta["n"] // 3), meta["n"], meta["n"] + 5]))]
+    if meta["n"] > 3000:
+        blocks = [b for b in blocks if b >= 16] or [1000]
+    flags = int(rng.choice([0, 1, 2, 4, 8, 1 | 2 | 4 | 8, 16, 16 | 2, 4 | 8]))
+    lazer = oracle.lazer_from_last(image, blocks[0], flags, int(rng.choice([4, 5])))
+    path = str(tmp_path / "f.lazer")
+    lazer.tofile(path)
+    for _ in range(4):
+        bmin, bmax = random_box(rng, world)
+        oc, ob = oracle.count_collector(), oracle.buffer_collector()
+        rc_o = oracle.search_file(path, 0, bmin, bmax, 0, oc)[0]
+        oracle.search_file(path, 0, bmin, bmax, 0, ob)
+        hc, hb = q.collector("count"), q.collector("buffer")
+        rc_c = q.search_bounds(path, bmin, bmax, hc)[0]
+        rc_b = q.search_bounds(path, bmin, bmax, hb)[0]
+        assert rc_c == rc_o == rc_b, (meta, blocks, flags, q.lib.pcq_query_last_error())
+        if rc_o == 0:
+            assert q.count(hc) == oc.point_count(), (meta, bmin, bmax)
+            assert q.points(hb).tobytes() == ob.points().tobytes(), (meta, bmin, bmax)
+        q.free(hc), q.free(hb), oc.free(), ob.free()
+        cell = float(rng.choice([0.05, 1.0, 12.5, 1000.0]))
+        try:
+            og = oracle.grid_collector(bmin, bmax, cell)
+        except Exception:
+            continue
+        h = C.c_void_p()
+        rc_new = q.lib.pcq_query_collector_new_grid(0, q.d3(bmin), q.d3(bmax), cell, C.byref(h))
+        if rc_new != 0:
+            og.free()
+            continue
+        assert oracle.search_file(path, 0, bmin, bmax, 0, og)[0] == q.search_bounds(path, bmin, bmax, h)[0]
+        gk, gp = sorted_grid(q, h)
+        assert np.array_equal(gk, og.grid_cells()), (meta, bmin, bmax, cell)
+        assert gp.tobytes() == og.points().tobytes(), (meta, bmin, bmax, cell)
+        q.free(h), og.free()
+    for cls in (6, 134, 19):
+        oc, ob = oracle.count_collector(), oracle.buffer_collector()
+        rc_o = oracle.search_file(path, 1, None, None, cls, oc)[0]
+        oracle.search_file(path, 1, None, None, cls, ob)
+        hc, hb = q.collector("count"), q.collector("buffer")
+        assert q.search_class(path, cls, hc) == rc_o and q.search_class(path, cls, hb) == rc_o, (meta, blocks, flags)
+        if rc_o == 0:
+            assert q.count(hc) == oc.point_count(), (meta, cls)
+            assert q.points(hb).tobytes() == ob.points().tobytes(), (meta, cls)
+        q.free(hc), q.free(hb), oc.free(), ob.free()
