@@ -100,6 +100,13 @@ def lib_path() -> str:
     return os.path.join(_HERE, "libpcq.so")
 
 
+class Lz4Job(C.Structure):
+    """pcq_lz4_job: one LZ4 frame (behind its descriptor) to inflate on the device."""
+    _fields_ = [("src", C.c_void_p), ("src_len", C.c_uint64), ("dst", C.c_void_p), ("need", C.c_uint64),
+                ("content_size", C.c_uint64), ("block_size_id", C.c_uint8), ("independent_blocks", C.c_uint8),
+                ("block_checksum", C.c_uint8), ("has_content_size", C.c_uint8), ("status", C.c_int32)]
+
+
 _lib = None
 
 
@@ -150,6 +157,8 @@ def load_library() -> C.CDLL:
         "pcq_copy_to_host": (C.c_int, [vp, vp, vp, u64]),
         "pcq_device_memset": (C.c_int, [vp, vp, C.c_int, u64, vp]),
         "pcq_set_option": (C.c_int, [vp, C.c_char_p, i64]),
+        "pcq_lz4_inflate_dev": (C.c_int, [vp, P(Lz4Job), C.c_size_t, vp]),
+        "pcq_read_fd_to_device": (C.c_int, [vp, C.c_int, u64, u64, vp]),
         "pcq_synth_fill_dev": (C.c_int, [vp, P(SynthSpec), u64, u64, vp, vp, vp]),
         "pcq_membench_read": (C.c_int, [vp, vp, u64, C.c_int, C.c_int, C.c_int, vp]),
         "pcq_membench_read_tiles": (C.c_int, [vp, vp, u64, C.c_int, C.c_int, C.c_int, vp]),
@@ -317,6 +326,13 @@ class Context:
 
     def memset(self, dst: int, value: int, nbytes: int, stream: Optional[int] = None) -> None:
         _check(self.lib.pcq_device_memset(self.handle, C.c_void_p(dst), value, nbytes, C.c_void_p(stream)))
+
+    def lz4_inflate(self, jobs, stream: Optional[int] = None) -> None:
+        """jobs: a ctypes array of Lz4Job; statuses are filled in (0 = inflated, 1 = left to the caller)."""
+        _check(self.lib.pcq_lz4_inflate_dev(self.handle, jobs, len(jobs), C.c_void_p(stream)))
+
+    def read_fd_to_device(self, fd: int, offset: int, nbytes: int, dst: int) -> None:
+        _check(self.lib.pcq_read_fd_to_device(self.handle, fd, offset, nbytes, C.c_void_p(dst)))
 
     # scans ------------------------------------------------------------------------------------
     def scan_dev(self, cols: Columns, pred: Predicate, coll: Collector, stream: Optional[int] = None) -> None:

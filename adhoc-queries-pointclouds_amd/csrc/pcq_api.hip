@@ -568,6 +568,31 @@ static int ensure_stage(pcq_ctx *ctx, size_t bytes) {
     return PCQ_OK;
 }
 
+static int fetch(pcq_ctx *ctx, int fd, uint8_t *dst, const uint8_t *src, size_t bytes);
+
+int pcq_stream_fd_to_device(pcq_ctx *ctx, int fd, uint64_t offset, uint64_t bytes, uint8_t *d_dst) {
+    const size_t chunk = 32u << 20;
+    int rc = ensure_stage(ctx, (bytes < chunk ? (size_t)bytes : chunk) + 64);
+    if (rc) return rc;
+    hipStream_t cs = ctx->copy_stream;
+    const uint64_t nchunks = (bytes + chunk - 1) / chunk;
+    // events reused as "staging buffer b has been copied out"
+    for (uint64_t k = 0; k < nchunks; k++) {
+        const int b = (int)(k & 1);
+        const uint64_t at = k * chunk, len = bytes - at < chunk ? bytes - at : chunk;
+        if (k >= 2) PCQ_HIP(hipEventSynchronize(ctx->copied[b]));
+        rc = fetch(ctx, fd, ctx->h_stage[b], (const uint8_t *)(uintptr_t)(offset + at), (size_t)len);
+        if (rc) {
+            (void)hipStreamSynchronize(cs);
+            return rc;
+        }
+        PCQ_HIP(hipMemcpyAsync(d_dst + at, ctx->h_stage[b], (size_t)len, hipMemcpyHostToDevice, cs));
+        PCQ_HIP(hipEventRecord(ctx->copied[b], cs));
+    }
+    PCQ_HIP(hipStreamSynchronize(cs));
+    return PCQ_OK;
+}
+
 struct StagePlan {
     bool aos;                  // LAS records: one interleaved range
     bool need_xyz, need_cls, need_rgb;

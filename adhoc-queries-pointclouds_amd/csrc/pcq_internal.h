@@ -145,6 +145,9 @@ struct pcq_ctx {
     uint64_t chunk_points = 2ull << 20;    // 24 MB of positions per staging chunk (profiles/r01_host_path_rate.json: 1-8 Mi equal)
 };
 
+// pcq_api.hip: [offset, offset+bytes) of fd -> device memory through the pinned staging buffers
+int pcq_stream_fd_to_device(pcq_ctx *ctx, int fd, uint64_t offset, uint64_t bytes, uint8_t *d_dst);
+
 enum { COLL_COUNT = 0, COLL_BUFFER = 1, COLL_GRID = 2 };
 
 struct pcq_collector {

@@ -228,6 +228,30 @@ int pcq_copy_to_device(pcq_ctx *ctx, void *dst_device, const void *src_host, uin
 int pcq_copy_to_host(pcq_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
 int pcq_device_memset(pcq_ctx *ctx, void *dst_device, int value, uint64_t bytes, void *stream);
 
+/* ---- LAZER support (query/src/search/lazer.rs over readers/src/lazer_reader.rs) ----
+ * The column blobs of a LAZER file are LZ4 frames.  The host layer parses each frame descriptor and hands
+ * the block sequence behind it to the device, one job per blob; the kernel inflates the first `need`
+ * bytes into `dst` exactly as the reference's streaming reader (lz4::Decoder over LZ4F_decompress,
+ * lazer_reader.rs:590-716) would produce them.  status = 0: done.  status = 1: not handled on the device
+ * (block checksums, damage, a frame that ends early, ...) — the caller inflates that blob with its own
+ * reader, which also decides which error the reference would raise.  Synchronous. */
+typedef struct pcq_lz4_job {
+    const void *src;            /* device: first block header of the frame (behind the frame descriptor) */
+    uint64_t src_len;           /* bytes from src to the end of the blob */
+    void *dst;                  /* device: receives the first `need` inflated bytes */
+    uint64_t need;
+    uint64_t content_size;      /* frame descriptor: content size, if present */
+    uint8_t block_size_id;      /* frame descriptor BD: 4..7 = 64 KiB, 256 KiB, 1 MiB, 4 MiB */
+    uint8_t independent_blocks; /* FLG bit 5 */
+    uint8_t block_checksum;     /* FLG bit 4 (such frames are left to the caller) */
+    uint8_t has_content_size;   /* FLG bit 3 */
+    int32_t status;             /* out */
+} pcq_lz4_job;
+int pcq_lz4_inflate_dev(pcq_ctx *ctx, pcq_lz4_job *jobs, size_t njobs, void *stream);
+/* Reads [file_offset, file_offset + bytes) of an open file into device memory at the rate of the host
+ * block path (pinned double buffering, parallel pread).  Synchronous. */
+int pcq_read_fd_to_device(pcq_ctx *ctx, int fd, uint64_t file_offset, uint64_t bytes, void *d_dst);
+
 /* Tuning knobs: "k1_variant" (bounds-count kernel variant, 0 = default), "blocks_per_cu", "chunk_points"
  * (points per staging chunk of the host paths), "copy_threads" (threads filling a staging chunk, default 4). */
 int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value);
