@@ -13,6 +13,7 @@
 // which have exactly the LAST layout.  No per-point work happens here.
 #include <algorithm>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -209,6 +210,109 @@ void fill_columns(const LazerFile &lz, const Columns &c, uint64_t n, pcq_columns
 
 }  // namespace
 
+// ---- inflate on the device -------------------------------------------------------------------------------
+// The whole block region of the file goes to HBM compressed; every column blob becomes one job of
+// pcq_lz4_inflate_dev (one wave per LZ4 frame).  A frame the kernel does not take — block checksums,
+// damage, anything unusual — is inflated here with the host reader, which also yields the reference's
+// error for it.  Errors surface in the order a sequential reader meets them: block by block, positions,
+// classifications, colours; a block whose tables cannot be read ends the walk.
+struct DeviceColumns {
+    pcq_ctx *ctx = nullptr;
+    void *comp = nullptr, *xyz = nullptr, *cls = nullptr, *rgb = nullptr;
+    ~DeviceColumns() {
+        for (void *p : {comp, xyz, cls, rgb})
+            if (p) pcq_device_free(ctx, p);
+    }
+};
+
+static Status inflate_on_device(const LazerFile &lz, pcq_ctx *ctx, DeviceColumns *dc) {
+    dc->ctx = ctx;
+    const uint64_t n = lz.header.number_of_points, fsz = lz.file.size(), region = lz.block_offsets[0];
+    std::vector<BlockBlobs> blobs;
+    blobs.reserve(lz.num_blocks);
+    Status walk_end = Status::Ok();
+    for (size_t b = 0; b < lz.num_blocks; b++) {
+        BlockBlobs bl;
+        Status st = lz.locate(b, &bl);
+        if (!st.ok()) {
+            walk_end = st;
+            break;
+        }
+        blobs.push_back(bl);
+    }
+    int r = pcq_device_alloc(ctx, fsz - region, &dc->comp);
+    if (!r) r = pcq_device_alloc(ctx, n * 12, &dc->xyz);
+    if (!r) r = pcq_device_alloc(ctx, n, &dc->cls);
+    if (!r && lz.has_colors) r = pcq_device_alloc(ctx, n * 6, &dc->rgb);
+    if (!r) r = pcq_read_fd_to_device(ctx, lz.file.fd(), region, fsz - region, dc->comp);
+    if (r) return Status::FromLib(r);
+
+    struct Piece {
+        const Blob *blob;
+        uint64_t need;
+        size_t unit;
+        uint8_t *dst;
+    };
+    std::vector<Piece> pieces;
+    std::vector<pcq_lz4_job> jobs;
+    const uint8_t *region_base = lz.file.data() + region;
+    for (size_t b = 0; b < blobs.size(); b++) {
+        const uint64_t at = (uint64_t)b * lz.block_size, count = lz.points_in_block(b);
+        const Piece three[3] = {{&blobs[b].positions, count * 12, 4, (uint8_t *)dc->xyz + at * 12},      // :598-600 read_i32 x3
+                                {&blobs[b].classifications, count, 1, (uint8_t *)dc->cls + at},           // :665 read_u8
+                                {&blobs[b].colors, count * 6, 2, (uint8_t *)dc->rgb + at * 6}};           // :693-695 read_u16 x3
+        for (int k = 0; k < (lz.has_colors ? 3 : 2); k++) {
+            const Piece &pc = three[k];
+            pcq_lz4_job j{};
+            Lz4FrameInfo fi;
+            if (lz4_frame_descriptor(pc.blob->p, pc.blob->n, &fi).ok()) {
+                j.src = (const uint8_t *)dc->comp + (pc.blob->p - region_base) + fi.payload;
+                j.src_len = pc.blob->n - fi.payload;
+                j.dst = pc.dst;
+                j.need = pc.need;
+                j.content_size = fi.content_size;
+                j.block_size_id = (uint8_t)fi.block_size_id;
+                j.independent_blocks = fi.independent;
+                j.block_checksum = fi.block_checksum;
+                j.has_content_size = fi.has_size;
+            }  // else: src stays null, the library leaves the job alone and the host reader reports the descriptor's fault
+            j.status = 1;
+            pieces.push_back(pc);
+            jobs.push_back(j);
+        }
+    }
+    r = pcq_lz4_inflate_dev(ctx, jobs.data(), jobs.size(), nullptr);
+    if (r) return Status::FromLib(r);
+    std::vector<uint8_t> tmp;
+    for (size_t i = 0; i < jobs.size(); i++) {
+        if (jobs[i].status == 0) continue;
+        tmp.resize((size_t)pieces[i].need);
+        Status st = lz4_frame_decode_into(pieces[i].blob->p, pieces[i].blob->n, (size_t)pieces[i].need, pieces[i].unit, tmp.data());
+        if (!st.ok()) return st;
+        r = pcq_copy_to_device(ctx, pieces[i].dst, tmp.data(), pieces[i].need);
+        if (r) return Status::FromLib(r);
+    }
+    return walk_end;
+}
+
+// Where the LZ4 work happens: PCQ_LAZER_INFLATE=device | host.  Default: host threads — measured faster
+// today (profiles/r01_lazer_rate.log); the device inflater is correct but not yet tuned.
+static bool inflate_on_host() {
+    const char *e = getenv("PCQ_LAZER_INFLATE");
+    return !(e && !strcmp(e, "device"));
+}
+
+static void device_columns(const LazerFile &lz, const DeviceColumns &dc, pcq_columns *cols) {
+    *cols = pcq_columns{};
+    cols->xyz = dc.xyz;
+    cols->xyz_stride = 12;
+    cols->cls = dc.cls;
+    cols->cls_stride = 1;
+    cols->rgb = lz.has_colors ? dc.rgb : nullptr;  // no colour decoder: the record's colour stays 0 (:683-685)
+    cols->rgb_stride = 6;
+    for (int a = 0; a < 3; a++) cols->scale[a] = lz.header.scale[a], cols->offset[a] = lz.header.offset[a];  // :602-609
+}
+
 // ---- lazer.rs:34-78 -----------------------------------------------------------------------------------------
 Status search_lazer_file_by_bounds(const std::string &path, const AABB &bounds, ResultCollector &rc) {
     LazerFile lz;
@@ -217,21 +321,33 @@ Status search_lazer_file_by_bounds(const std::string &path, const AABB &bounds, 
     if (!lz.header.bounds.intersects(bounds)) return Status::Ok();  // :47-53
 
     // :56-76 — chunk == block: every block is inflated, filtered with bounds.contains(world position)
-    // and its matches collected in file order.  All blocks go through one streamed scan.
+    // and its matches collected in file order.  All blocks go through one scan.
     const uint64_t n = lz.header.number_of_points;
     st = impossible_point_count(lz);
-    if (!st.ok()) return st;
-    Columns c;
-    c.alloc(n, lz.has_colors);
-    st = inflate_blocks(lz, 0, lz.num_blocks, &c);
     if (!st.ok()) return st;
     pcq_predicate pred{};
     pred.kind = PCQ_PRED_BOUNDS_F64;  // :69
     for (int a = 0; a < 3; a++) pred.wmin[a] = bounds.min[a], pred.wmax[a] = bounds.max[a];
     pcq_columns cols;
-    fill_columns(lz, c, n, &cols);
-    cols.first_index = rc.next_index;
-    const int r = pcq_scan_host(rc.context(), &cols, &pred, rc.handle());
+    int r;
+    if (inflate_on_host()) {
+        Columns c;
+        c.alloc(n, lz.has_colors);
+        st = inflate_blocks(lz, 0, lz.num_blocks, &c);
+        if (!st.ok()) return st;
+        fill_columns(lz, c, n, &cols);
+        cols.first_index = rc.next_index;
+        r = pcq_scan_host(rc.context(), &cols, &pred, rc.handle());
+    } else {
+        DeviceColumns dc;
+        st = inflate_on_device(lz, rc.context(), &dc);
+        if (!st.ok()) return st;
+        device_columns(lz, dc, &cols);
+        cols.n = n;
+        cols.first_index = rc.next_index;
+        r = pcq_scan_dev(rc.context(), &cols, &pred, rc.handle(), nullptr);
+        if (!r) r = pcq_ctx_synchronize(rc.context());  // the columns are released when dc goes out of scope
+    }
     rc.next_index += n;
     return Status::FromLib(r);
 }
@@ -240,7 +356,7 @@ Status search_lazer_file_by_bounds(const std::string &path, const AABB &bounds, 
 // The reference never clears its point buffer on this path (no `point_buffer.clear()` as at :75), so
 // `get_attribute_range_ref(0..points_in_chunk)` and `get_point(idx)` always address the FIRST block's
 // points: chunk k re-filters points [0, points_in_chunk(k)) of block 0.  Every block is still inflated
-// (and can fail).  Reproduced as is: block 0's columns are uploaded once and scanned once per chunk.
+// (and can fail).  Reproduced as is: block 0's columns are scanned once per chunk.
 Status search_lazer_file_by_classification(const std::string &path, uint8_t cls, ResultCollector &rc) {
     LazerFile lz;
     Status st = lazer_open(path, &lz);  // :85-87
@@ -249,44 +365,37 @@ Status search_lazer_file_by_classification(const std::string &path, uint8_t cls,
     st = impossible_point_count(lz);
     if (!st.ok()) return st;
 
-    Columns c0;  // block 0
-    c0.alloc(n0, lz.has_colors);
-    st = inflate_blocks(lz, 0, 1, &c0);
-    if (!st.ok()) return st;
-    if (lz.num_blocks > 1) {  // the other blocks: inflated by read_into (:101), their points never looked at
-        Columns rest;
-        const uint64_t nr = n - n0;
-        rest.alloc(nr, lz.has_colors);
-        st = inflate_blocks(lz, 1, lz.num_blocks, &rest);
-        if (!st.ok()) return st;
-    }
-
     pcq_ctx *ctx = rc.context();
-    void *d_xyz = nullptr, *d_cls = nullptr, *d_rgb = nullptr;
-    auto release = [&]() {
-        if (d_xyz) pcq_device_free(ctx, d_xyz);
-        if (d_cls) pcq_device_free(ctx, d_cls);
-        if (d_rgb) pcq_device_free(ctx, d_rgb);
-    };
-    int r = pcq_device_alloc(ctx, n0 * 12, &d_xyz);
-    if (!r) r = pcq_device_alloc(ctx, n0, &d_cls);
-    if (!r && lz.has_colors) r = pcq_device_alloc(ctx, n0 * 6, &d_rgb);
-    if (!r) r = pcq_copy_to_device(ctx, d_xyz, c0.xyz.get(), n0 * 12);
-    if (!r) r = pcq_copy_to_device(ctx, d_cls, c0.cls.get(), n0);
-    if (!r && lz.has_colors) r = pcq_copy_to_device(ctx, d_rgb, c0.rgb.get(), n0 * 6);
-    if (r) {
-        Status e = Status::FromLib(r);
-        release();
-        return e;
+    DeviceColumns dc;
+    if (inflate_on_host()) {
+        Columns c0;  // block 0
+        c0.alloc(n0, lz.has_colors);
+        st = inflate_blocks(lz, 0, 1, &c0);
+        if (!st.ok()) return st;
+        if (lz.num_blocks > 1) {  // the other blocks: inflated by read_into (:101), their points never looked at
+            Columns rest;
+            rest.alloc(n - n0, lz.has_colors);
+            st = inflate_blocks(lz, 1, lz.num_blocks, &rest);
+            if (!st.ok()) return st;
+        }
+        dc.ctx = ctx;
+        int r = pcq_device_alloc(ctx, n0 * 12, &dc.xyz);
+        if (!r) r = pcq_device_alloc(ctx, n0, &dc.cls);
+        if (!r && lz.has_colors) r = pcq_device_alloc(ctx, n0 * 6, &dc.rgb);
+        if (!r) r = pcq_copy_to_device(ctx, dc.xyz, c0.xyz.get(), n0 * 12);
+        if (!r) r = pcq_copy_to_device(ctx, dc.cls, c0.cls.get(), n0);
+        if (!r && lz.has_colors) r = pcq_copy_to_device(ctx, dc.rgb, c0.rgb.get(), n0 * 6);
+        if (r) return Status::FromLib(r);
+    } else {
+        st = inflate_on_device(lz, ctx, &dc);  // all blocks (:101 reads every chunk); block 0 sits at the front
+        if (!st.ok()) return st;
     }
     pcq_predicate pred{};
     pred.kind = PCQ_PRED_CLASS;
     pred.cls = cls;  // :107
     pcq_columns cols;
-    fill_columns(lz, c0, 0, &cols);
-    cols.xyz = d_xyz;
-    cols.cls = d_cls;
-    cols.rgb = d_rgb;
+    device_columns(lz, dc, &cols);
+    int r = 0;
     for (uint64_t k = 0; k < lz.num_blocks && !r; k++) {  // :98-113
         cols.n = lz.points_in_block((size_t)k);  // points_in_chunk
         cols.first_index = rc.next_index;
@@ -294,9 +403,7 @@ Status search_lazer_file_by_classification(const std::string &path, uint8_t cls,
         rc.next_index += cols.n;
     }
     if (!r) r = pcq_ctx_synchronize(ctx);
-    Status out = Status::FromLib(r);
-    release();
-    return out;
+    return Status::FromLib(r);
 }
 
 }  // namespace pcq

@@ -158,31 +158,33 @@ static Status lz4_block(const uint8_t *src, size_t n, Out *out, size_t window_st
 // function for the one exception).  Running out of input, or out of frame, before `need` bytes is read_exact's
 // UnexpectedEof ("failed to fill whole buffer"); a frame that ends early is checked (content checksum,
 // content size) first, as LZ4F_decompress does at the EndMark.
-static Status frame_core(const uint8_t *src, size_t n, size_t need, size_t unit, Out *out) {
-    if (need == 0) return Status::Ok();  // zero reads: the Decoder is never polled
-    size_t pos = 0;
-    if (n - pos < 4) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
+// The frame descriptor: magic | FLG | BD | [content size] | [dictionary id] | header checksum.
+Status lz4_frame_descriptor(const uint8_t *src, size_t n, Lz4FrameInfo *fi) {
+    *fi = Lz4FrameInfo{};
+    if (n < 4) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
     // A skippable frame is a complete frame to LZ4F_decompress: it returns 0 after it, lz4::Decoder then
     // treats the stream as finished (decoder.rs `self.next = 0`) and read_exact fails — the data frame
     // behind it is never reached (checked against the real library in tests/test_lz4_lazer.py).
-    if ((rd32(src + pos) & 0xFFFFFFF0u) == 0x184D2A50u) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
-    if (rd32(src + pos) != 0x184D2204u) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_frameType_unknown");
-    const size_t hdr = pos + 4;
+    if ((rd32(src) & 0xFFFFFFF0u) == 0x184D2A50u) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
+    if (rd32(src) != 0x184D2204u) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_frameType_unknown");
+    const size_t hdr = 4;
     if (n - hdr < 3) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
     const uint8_t flg = src[hdr], bd = src[hdr + 1];
     if ((flg >> 6) != 1) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_headerVersion_wrong");
     if (flg & 0x02) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_reservedFlag_set");
     if (bd & 0x8F) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_reservedFlag_set");
-    const unsigned bsid = (bd >> 4) & 7;
-    if (bsid < 4) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_maxBlockSize_invalid");
-    const size_t max_block = (size_t)1 << (8 + 2 * bsid);  // 4: 64 KiB ... 7: 4 MiB
-    const bool independent = flg & 0x20, block_checksum = flg & 0x10, has_size = flg & 0x08, content_checksum = flg & 0x04,
-               has_dict = flg & 0x01;
+    fi->block_size_id = (bd >> 4) & 7;
+    if (fi->block_size_id < 4) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_maxBlockSize_invalid");
+    fi->max_block = (size_t)1 << (8 + 2 * fi->block_size_id);  // 4: 64 KiB ... 7: 4 MiB
+    fi->independent = flg & 0x20;
+    fi->block_checksum = flg & 0x10;
+    fi->has_size = flg & 0x08;
+    fi->content_checksum = flg & 0x04;
+    const bool has_dict = flg & 0x01;
     size_t p = hdr + 2;
-    uint64_t content_size = 0;
-    if (has_size) {
+    if (fi->has_size) {
         if (n - p < 8) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
-        content_size = (uint64_t)rd32(src + p) | ((uint64_t)rd32(src + p + 4) << 32);
+        fi->content_size = (uint64_t)rd32(src + p) | ((uint64_t)rd32(src + p + 4) << 32);
         p += 8;
     }
     if (has_dict) {
@@ -191,7 +193,19 @@ static Status frame_core(const uint8_t *src, size_t n, size_t need, size_t unit,
     }
     if (n - p < 1) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
     if (src[p] != ((xxh32(src + hdr, p - hdr) >> 8) & 0xFF)) return Status::Err(PCQ_ERR_HEADER, "LZ4 error: ERROR_headerChecksum_invalid");
-    p++;
+    fi->payload = p + 1;
+    return Status::Ok();
+}
+
+static Status frame_core(const uint8_t *src, size_t n, size_t need, size_t unit, Out *out) {
+    if (need == 0) return Status::Ok();  // zero reads: the Decoder is never polled
+    Lz4FrameInfo fi;
+    Status hst = lz4_frame_descriptor(src, n, &fi);
+    if (!hst.ok()) return hst;
+    const size_t max_block = fi.max_block;
+    const bool independent = fi.independent, block_checksum = fi.block_checksum, has_size = fi.has_size, content_checksum = fi.content_checksum;
+    const uint64_t content_size = fi.content_size;
+    size_t p = fi.payload;
     bool after_stored = false;
     while (out->size < need) {
         if (n - p < 4) return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
