@@ -6,9 +6,13 @@
 // frames are independent.  One wave inflates one frame:
 //
 //   * the 64 KiB LZ4 window lives in LDS as a ring (a wave's LDS accesses are ordered, so match copies
-//     read bytes written a few instructions earlier without any global-memory coherence question);
-//   * literal and match copies are wave-wide (64 bytes per step); overlapping matches use the periodic
-//     form src = out - offset + (i mod offset), in chunks that cannot wrap the ring onto their own source;
+//     read bytes written a few instructions earlier without any global-memory coherence question), and
+//     the compressed bytes the sequence parser looks at are staged 4 KiB at a time in LDS as well — a
+//     token, its length bytes and its offset cost LDS reads, not dependent global loads;
+//   * long literal runs and stored blocks (incompressible columns: noisy i32 positions) bypass the staging:
+//     16 bytes per lane, four loads in flight, aligned 16-byte stores to the destination and the ring;
+//   * short literals and matches are wave-wide byte copies (64 bytes per step); overlapping matches use the
+//     periodic form src = out - offset + (i mod offset), in chunks that cannot wrap the ring onto their own source;
 //   * everything the wave reads or writes is bounds-checked, and every loop consumes input, so a damaged
 //     frame ends the wave instead of faulting or spinning.
 //
@@ -20,7 +24,8 @@
 
 namespace {
 
-constexpr uint32_t RING = 65536;
+constexpr uint32_t RING = 65536;  // the LZ4 window
+constexpr uint32_t WIN = 4096;    // staged compressed input
 
 struct DevLz4Job {
     const uint8_t *src;  // first byte of the block sequence (behind the frame header)
@@ -36,44 +41,149 @@ struct DevLz4Job {
     uint32_t _pad2;
 };
 
-__device__ __forceinline__ uint32_t rd32(const uint8_t *p) {
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
-}
+// 16 bytes at any address: the compiler picks the widest access the target's unaligned mode allows
+struct __attribute__((packed, aligned(1))) U16B {
+    uint32_t w[4];
+};
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
 
-// src[from, from+len) -> ring + dst (dst writes clipped to `need`); all lanes take part
-__device__ __forceinline__ void copy_in(const uint8_t *__restrict__ src, uint64_t from, uint64_t len, uint8_t *__restrict__ dst,
-                                        uint64_t out, uint64_t need, uint8_t *ring, int lane) {
-    for (uint64_t i = lane; i < len; i += 64) {
-        const uint8_t b = src[from + i];
-        ring[(uint32_t)(out + i) & (RING - 1)] = b;
-        if (out + i < need) dst[out + i] = b;
+// One wave's view of a job.  `ring` holds the last 64 KiB of output at index (position + phase) mod 64 Ki,
+// where phase = dst & 15, so that a 16-byte-aligned destination address is a 16-byte-aligned ring slot;
+// `win` holds compressed bytes [win_base, win_base + WIN) for the sequence parser.
+struct Wave {
+    const uint8_t *__restrict__ src;
+    uint8_t *__restrict__ dst;
+    uint8_t *ring, *win;
+    uint64_t n, need, win_base;
+    uint32_t phase;
+    int lane;
+
+    __device__ __forceinline__ uint32_t slot(uint64_t pos) const { return (uint32_t)(pos + phase) & (RING - 1); }
+
+    __device__ void refill(uint64_t q) {  // compressed bytes [q, q + WIN), zeros behind the end of the blob
+        win_base = q;
+#pragma unroll
+        for (int k = 0; k < (int)(WIN / 1024); k++) {
+            const uint32_t off = (uint32_t)(k * 64 + lane) * 16;
+            const uint64_t a = q + off;
+            u4 v = {0, 0, 0, 0};
+            if (a + 16 <= n) {
+                const U16B t = *reinterpret_cast<const U16B *>(src + a);
+                v = u4{t.w[0], t.w[1], t.w[2], t.w[3]};
+            } else if (a < n) {
+                uint32_t w[4] = {0, 0, 0, 0};
+                for (uint64_t j = 0; j < n - a; j++) w[j >> 2] |= (uint32_t)src[a + j] << (8 * (j & 3));
+                v = u4{w[0], w[1], w[2], w[3]};
+            }
+            *reinterpret_cast<u4 *>(win + off) = v;
+        }
+        __syncthreads();
     }
-}
+    // makes [q, q + span) readable through in(); span <= 512
+    __device__ __forceinline__ void ensure(uint64_t q, uint32_t span) {
+        if (q < win_base || q + span > win_base + WIN) refill(q);
+    }
+    __device__ __forceinline__ uint32_t in(uint64_t q) const { return win[(uint32_t)(q - win_base)]; }
+
+    // short copy out of the staged input: src[q, q + len) -> output position `out`; len <= 256
+    __device__ __forceinline__ void copy_short(uint64_t q, uint32_t len, uint64_t out) {
+        for (uint32_t i = lane; i < len; i += 64) {
+            const uint8_t b = win[(uint32_t)(q + i - win_base)];
+            ring[slot(out + i)] = b;
+            if (out + i < need) dst[out + i] = b;
+        }
+        __syncthreads();
+    }
+
+    // bulk copy straight from the compressed stream (long literal runs, stored blocks): 16 bytes per lane,
+    // four loads in flight; destination and ring slots are 16-byte aligned by construction
+    __device__ void copy_bulk(uint64_t q, uint64_t len, uint64_t out) {
+        uint64_t head = (16 - ((uint64_t)(uintptr_t)(dst + out) & 15)) & 15;
+        if (head > len) head = len;
+        if ((uint64_t)lane < head) {
+            const uint8_t b = src[q + lane];
+            ring[slot(out + lane)] = b;
+            if (out + lane < need) dst[out + lane] = b;
+        }
+        const uint64_t nvec = (len - head) / 16, body = head + nvec * 16;
+        const uint8_t *s0 = src + q + head;
+        const uint64_t o0 = out + head;
+        uint64_t v = lane;
+        for (; v + 192 < nvec; v += 256) {
+            U16B t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] = *reinterpret_cast<const U16B *>(s0 + (v + 64 * u) * 16);
+#pragma unroll
+            for (int u = 0; u < 4; u++) put16(o0 + (v + 64 * u) * 16, t[u]);
+        }
+        for (; v < nvec; v += 64) put16(o0 + v * 16, *reinterpret_cast<const U16B *>(s0 + v * 16));
+        const uint64_t tail = len - body;
+        if ((uint64_t)lane < tail) {
+            const uint8_t b = src[q + body + lane];
+            ring[slot(out + body + lane)] = b;
+            if (out + body + lane < need) dst[out + body + lane] = b;
+        }
+        __syncthreads();
+    }
+    __device__ __forceinline__ void put16(uint64_t pos, const U16B &t) {
+        const u4 v = {t.w[0], t.w[1], t.w[2], t.w[3]};
+        *reinterpret_cast<u4 *>(ring + slot(pos)) = v;
+        if (pos + 16 <= need) {
+            *reinterpret_cast<u4 *>(dst + pos) = v;
+        } else if (pos < need) {
+            for (uint64_t j = 0; j < need - pos; j++) dst[pos + j] = (uint8_t)(t.w[j >> 2] >> (8 * (j & 3)));
+        }
+    }
+
+    // match: `len` bytes from `offset` back, through the ring, in chunks that cannot wrap onto their own source
+    __device__ void copy_match(uint32_t offset, uint64_t len, uint64_t out) {
+        while (len > 0) {
+            const uint64_t chunk = len < (uint64_t)(RING - offset) ? len : (uint64_t)(RING - offset);
+            const uint64_t from = out - offset;
+            for (uint64_t i = lane; i < chunk; i += 64) {
+                const uint32_t k = offset >= chunk ? (uint32_t)i : (uint32_t)(i % offset);
+                const uint8_t b = ring[slot(from + k)];
+                ring[slot(out + i)] = b;
+                if (out + i < need) dst[out + i] = b;
+            }
+            __syncthreads();
+            out += chunk;
+            len -= chunk;
+        }
+    }
+};
 
 __global__ __launch_bounds__(64) void k_lz4_inflate(DevLz4Job *jobs, int njobs) {
-    __shared__ uint8_t ring[RING];
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     if ((int)blockIdx.x >= njobs) return;
     DevLz4Job *job = jobs + blockIdx.x;
-    const uint8_t *__restrict__ src = job->src;
-    uint8_t *__restrict__ dst = job->dst;
-    const uint64_t n = job->n, need = job->need;
+    Wave w;
+    w.src = job->src;
+    w.dst = job->dst;
+    w.ring = lds;
+    w.win = lds + RING;
+    w.n = job->n;
+    w.need = job->need;
+    w.phase = (uint32_t)((uintptr_t)job->dst & 15);
+    w.lane = threadIdx.x;
+    w.win_base = ~0ull >> 1;  // nothing staged yet
+    const uint64_t n = w.n, need = w.need;
     const int64_t cap = (int64_t)job->max_block;
     const bool independent = job->independent != 0;
-    const int lane = threadIdx.x;
     uint64_t p = 0, out = 0;
     bool ok = true, last_stored = false;
 
     while (ok && out < need) {
         if (n - p < 4) { ok = false; break; }
-        const uint32_t bs = rd32(src + p);
+        w.ensure(p, 4);
+        const uint32_t bs = w.in(p) | (w.in(p + 1) << 8) | (w.in(p + 2) << 16) | (w.in(p + 3) << 24);
         p += 4;
         if (bs == 0) { ok = false; break; }  // EndMark before `need` bytes: the host reader sorts out which error
         const uint64_t sz = bs & 0x7FFFFFFFu;
         if (sz > (uint64_t)cap) { ok = false; break; }
         if (bs >> 31) {  // stored block: passed through, possibly cut short (host/lz4_frame.cpp)
             const uint64_t avail = sz < n - p ? sz : n - p;
-            copy_in(src, p, avail, dst, out, need, ring, lane);
-            __syncthreads();
+            w.copy_bulk(p, avail, out);
             out += avail;
             last_stored = true;
             if (out >= need) break;
@@ -83,38 +193,50 @@ __global__ __launch_bounds__(64) void k_lz4_inflate(DevLz4Job *jobs, int njobs) 
         }
         if (n - p < sz) { ok = false; break; }
         // ---- one compressed block: LZ4_decompress_safe's rules, positions relative to the block ----
-        const uint8_t *__restrict__ b = src + p;
         const int64_t in = (int64_t)sz;
         const uint64_t floor_out = independent ? out : 0;
         int64_t ip = 0, op = 0;
         if (in == 0) { ok = false; break; }
         for (;;) {
-            const uint32_t token = b[ip++];
+            w.ensure(p + (uint64_t)ip, 1);
+            const uint32_t token = w.in(p + (uint64_t)ip);
+            ip++;
             int64_t lit = token >> 4;
             if (lit == 15) {
                 if (ip >= in - 15) { ok = false; break; }
                 uint32_t x;
                 do {
-                    x = b[ip++];
+                    w.ensure(p + (uint64_t)ip, 1);
+                    x = w.in(p + (uint64_t)ip);
+                    ip++;
                     lit += x;
                 } while (x == 255 && ip < in - 15);
             }
             const bool last_seq = op + lit > cap - 12 || ip + lit > in - 8;
             if (last_seq && (ip + lit != in || op + lit > cap)) { ok = false; break; }
-            copy_in(b, (uint64_t)ip, (uint64_t)lit, dst, out, need, ring, lane);
-            __syncthreads();
+            if (lit > 0) {
+                if (lit <= 256) {
+                    w.ensure(p + (uint64_t)ip, (uint32_t)lit + (last_seq ? 0 : 2));
+                    w.copy_short(p + (uint64_t)ip, (uint32_t)lit, out);
+                } else {
+                    w.copy_bulk(p + (uint64_t)ip, (uint64_t)lit, out);
+                }
+            }
             out += (uint64_t)lit;
             ip += lit;
             op += lit;
             if (last_seq) break;
-            const uint32_t offset = (uint32_t)b[ip] | ((uint32_t)b[ip + 1] << 8);
+            w.ensure(p + (uint64_t)ip, 2);
+            const uint32_t offset = w.in(p + (uint64_t)ip) | (w.in(p + (uint64_t)ip + 1) << 8);
             ip += 2;
             int64_t mlen = token & 15;
             if (mlen == 15) {
                 uint32_t x;
                 bool bad = false;
                 do {
-                    x = b[ip++];
+                    w.ensure(p + (uint64_t)ip, 1);
+                    x = w.in(p + (uint64_t)ip);
+                    ip++;
                     mlen += x;
                     if (ip >= in - 4) { bad = true; break; }
                 } while (x == 255);
@@ -122,21 +244,8 @@ __global__ __launch_bounds__(64) void k_lz4_inflate(DevLz4Job *jobs, int njobs) 
             }
             mlen += 4;
             if (offset == 0 || (uint64_t)offset > out - floor_out || op + mlen > cap - 5) { ok = false; break; }
-            // match copy through the ring, in chunks that cannot wrap onto their own source region
-            int64_t left = mlen;
-            while (left > 0) {
-                const int64_t chunk = left < (int64_t)(RING - offset) ? left : (int64_t)(RING - offset);
-                const uint64_t from = out - offset;
-                for (int64_t i = lane; i < chunk; i += 64) {
-                    const uint32_t k = offset >= (uint32_t)chunk ? (uint32_t)i : (uint32_t)i % offset;
-                    const uint8_t v = ring[(uint32_t)(from + k) & (RING - 1)];
-                    ring[(uint32_t)(out + (uint64_t)i) & (RING - 1)] = v;
-                    if (out + (uint64_t)i < need) dst[out + (uint64_t)i] = v;
-                }
-                __syncthreads();
-                out += (uint64_t)chunk;
-                left -= chunk;
-            }
+            w.copy_match(offset, (uint64_t)mlen, out);
+            out += (uint64_t)mlen;
             op += mlen;
         }
         if (!ok) break;
@@ -146,14 +255,15 @@ __global__ __launch_bounds__(64) void k_lz4_inflate(DevLz4Job *jobs, int njobs) 
     }
     // what the read of the last needed byte still looks at (host/lz4_frame.cpp, end of frame_core)
     if (ok && out == need && !last_stored && n - p >= 4) {
-        const uint32_t w = rd32(src + p);
-        if (w == 0) {
+        w.ensure(p, 4);
+        const uint32_t x = w.in(p) | (w.in(p + 1) << 8) | (w.in(p + 2) << 16) | (w.in(p + 3) << 24);
+        if (x == 0) {
             if (job->has_size && job->content_size != out) ok = false;
-        } else if ((w & 0x7FFFFFFFu) > (uint32_t)cap) {
+        } else if ((x & 0x7FFFFFFFu) > (uint32_t)cap) {
             ok = false;
         }
     }
-    if (lane == 0) job->status = ok ? 0 : 1;
+    if (w.lane == 0) job->status = ok ? 0 : 1;
 }
 
 }  // namespace
@@ -193,8 +303,12 @@ extern "C" int pcq_lz4_inflate_dev(pcq_ctx *ctx, pcq_lz4_job *jobs, size_t njobs
     PCQ_HIP(hipMalloc((void **)&d_jobs, live * sizeof(DevLz4Job)));
     hipError_t e = hipMemcpyAsync(d_jobs, table.data(), live * sizeof(DevLz4Job), hipMemcpyHostToDevice, s);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_lz4_inflate, dim3((unsigned)live), dim3(64), 0, s, d_jobs, (int)live);
-        e = hipGetLastError();
+        constexpr size_t kLds = RING + WIN;  // above the 64 KiB a kernel gets by default
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_lz4_inflate), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLds);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_lz4_inflate, dim3((unsigned)live), dim3(64), kLds, s, d_jobs, (int)live);
+            e = hipGetLastError();
+        }
     }
     if (e == hipSuccess) e = hipMemcpyAsync(table.data(), d_jobs, live * sizeof(DevLz4Job), hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);

@@ -13,6 +13,8 @@
 // which have exactly the LAST layout.  No per-point work happens here.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -225,8 +227,12 @@ struct DeviceColumns {
     }
 };
 
+static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static Status inflate_on_device(const LazerFile &lz, pcq_ctx *ctx, DeviceColumns *dc) {
     dc->ctx = ctx;
+    const bool timing = getenv("PCQ_TIMING") != nullptr;
+    const double t0 = now_ms();
     const uint64_t n = lz.header.number_of_points, fsz = lz.file.size(), region = lz.block_offsets[0];
     std::vector<BlockBlobs> blobs;
     blobs.reserve(lz.num_blocks);
@@ -244,8 +250,10 @@ static Status inflate_on_device(const LazerFile &lz, pcq_ctx *ctx, DeviceColumns
     if (!r) r = pcq_device_alloc(ctx, n * 12, &dc->xyz);
     if (!r) r = pcq_device_alloc(ctx, n, &dc->cls);
     if (!r && lz.has_colors) r = pcq_device_alloc(ctx, n * 6, &dc->rgb);
+    const double t1 = now_ms();
     if (!r) r = pcq_read_fd_to_device(ctx, lz.file.fd(), region, fsz - region, dc->comp);
     if (r) return Status::FromLib(r);
+    const double t2 = now_ms();
 
     struct Piece {
         const Blob *blob;
@@ -281,8 +289,15 @@ static Status inflate_on_device(const LazerFile &lz, pcq_ctx *ctx, DeviceColumns
             jobs.push_back(j);
         }
     }
+    const double t3 = now_ms();
     r = pcq_lz4_inflate_dev(ctx, jobs.data(), jobs.size(), nullptr);
     if (r) return Status::FromLib(r);
+    const double t4 = now_ms();
+    size_t handed_back = 0;
+    for (const auto &j : jobs) handed_back += j.status != 0;
+    if (timing)
+        fprintf(stderr, "[pcq] lazer device inflate: alloc %.1f ms, upload %.1f ms (%.1f MB), jobs %.1f ms, kernel %.1f ms (%zu frames, %zu handed back)\n",
+                t1 - t0, t2 - t1, (double)(fsz - region) / 1e6, t3 - t2, t4 - t3, jobs.size(), handed_back);
     std::vector<uint8_t> tmp;
     for (size_t i = 0; i < jobs.size(); i++) {
         if (jobs[i].status == 0) continue;
