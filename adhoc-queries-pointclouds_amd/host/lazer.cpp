@@ -346,13 +346,18 @@ Status search_lazer_file_by_bounds(const std::string &path, const AABB &bounds, 
     pcq_columns cols;
     int r;
     if (inflate_on_host()) {
+        const double t0 = now_ms();
         Columns c;
         c.alloc(n, lz.has_colors);
         st = inflate_blocks(lz, 0, lz.num_blocks, &c);
         if (!st.ok()) return st;
+        const double t1 = now_ms();
         fill_columns(lz, c, n, &cols);
         cols.first_index = rc.next_index;
         r = pcq_scan_host(rc.context(), &cols, &pred, rc.handle());
+        if (getenv("PCQ_TIMING"))
+            fprintf(stderr, "[pcq] lazer host inflate: %.1f ms (%zu blocks), scan from host columns %.1f ms\n", t1 - t0, (size_t)lz.num_blocks,
+                    now_ms() - t1);
     } else {
         DeviceColumns dc;
         st = inflate_on_device(lz, rc.context(), &dc);

@@ -81,6 +81,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-file-launch", action="store_true", help="one launch per file instead of one batched launch")
     ap.add_argument("--blocks-per-cu", type=int, default=0, help="tuning: persistent blocks per CU (0 = library default)")
+    ap.add_argument("--sync-each-step", action="store_true",
+                    help="read every query's answer back before the next query starts (query latency); default: the K "
+                         "queries are enqueued back to back, each into its own result slot, and all K answers are read "
+                         "and checked after the timed region (query throughput)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank rehearsal on a single-GPU box: every rank uses device 0 and the gloo backend "
                          "(RCCL refuses two ranks on one device); numbers from such a run are not a measurement")
@@ -142,13 +146,14 @@ def main():
         headers.append(specs_mod.header_fields(s))
     torch.cuda.synchronize()
 
-    total = torch.zeros(2, dtype=torch.int64, device=dev)  # [0] = match count of the query
+    # one result slot per query: [k, 0] = match count of query k (all-reduced over the ranks)
+    answers = torch.zeros((args.warmup + args.steps + 1, 2), dtype=torch.int64, device=dev)
     local_points = sum(h["n"] for h in headers)
     global_points = sum(int(s.n) for s in all_specs)
 
-    def query_step(record=None):
+    def query_step(slot, record=None, sync=True):
         """One `--bounds XL --optimized --parallel` count query over the dataset."""
-        total.zero_()
+        total = answers[slot]
         cols, preds, scanned = [], [], 0
         for t, h in zip(blocks, headers):
             if not specs_mod.aabb_intersects(h["min"], h["max"], bmin, bmax):  # last.rs:92-94
@@ -178,7 +183,7 @@ def main():
                     e1.record(tstream)
                     record.append((e0, e1, scanned))
         sharding.global_count(total, world if not use_dist else max(world, 2))  # main.rs:164-180: one RCCL all-reduce
-        return int(total[0].item()), scanned  # the query's answer reaches the host every step
+        return (int(total[0].item()) if sync else None), scanned
 
     def barrier():
         torch.cuda.synchronize()
@@ -186,15 +191,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        matches, _ = query_step()
+    expected, _ = query_step(args.warmup + args.steps)  # the answer, read back once (untimed)
+    for k in range(args.warmup):
+        query_step(k, sync=args.sync_each_step)
     barrier()
     events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        matches, scanned_local = query_step(events)
+    for k in range(args.steps):
+        _, scanned_local = query_step(args.warmup + k, events, sync=args.sync_each_step)
     barrier()
     elapsed = time.perf_counter() - t0
+    # every timed query produced the answer (nothing was skipped or cached: each query wrote its own slot)
+    got = answers[args.warmup:args.warmup + args.steps, 0].cpu().tolist()
+    if any(g != expected for g in got):
+        raise SystemExit(f"query answers differ inside the timed region: expected {expected}, got {sorted(set(got))}")
+    matches = expected
     if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
@@ -244,6 +255,8 @@ def main():
                 "query": args.query,
                 "sharding": "file i -> rank i % N, one RCCL all-reduce(sum, u64) per query" if world > 1 else "single GPU",
                 "launch": "per-file" if args.per_file_launch else "one batched launch per query",
+                "queries": "answer read back before the next query" if args.sync_each_step else
+                           "enqueued back to back, one result slot each; all answers read and checked after the timed region",
                 "device": info["name"] + " " + info["gcn_arch"],
             },
             "matches": matches,
