@@ -515,3 +515,62 @@ def test_lz4_reader_under_address_sanitizer(oracle, tmp_path):
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     tag, cases, errors = r.stdout.split()
     assert tag == "ok" and int(cases) == n_cases and int(errors) > n_cases // 3
+
+
+def test_host_file_parsers_under_address_sanitizer(oracle, pcq, tmp_path):
+    """The host layer parses untrusted LAS headers and LAZER block / attribute tables before any GPU work.
+    ASan + UBSan build of those parsers over mutated files; the error class must equal the oracle's."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    host = os.path.join(PKG, "host")
+    exe = str(tmp_path / "host_parse_asan")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-pthread",
+           "-I" + os.path.join(ROOT, "include"), "-I" + host, os.path.join(ROOT, "tests", "native", "host_parse_asan_driver.cpp"),
+           os.path.join(host, "core.cpp"), os.path.join(host, "search.cpp"), os.path.join(host, "lazer.cpp"),
+           os.path.join(host, "lz4_frame.cpp"), "-L" + PKG, "-lpcq", "-Wl,-rpath," + PKG, "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr and "cannot find" in r.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-3000:]
+    rng = np.random.default_rng(77)
+    image = oracle.synth_image(_spec(pcq, 3000, 2), transposed=True)
+    good = oracle.lazer_from_last(image, 700, 4, 4)
+    h = oracle.parse_header(good[:400].tobytes())
+    otp = h.offset_to_point_data
+    first_block = int(good[otp + 8: otp + 16].view("<u8")[0])
+    paths = []
+    for it in range(400):
+        b = good.copy()
+        k = it % 5
+        if k == 0:  # anywhere in the LAS header
+            b[int(rng.integers(0, 227))] = int(rng.integers(0, 256))
+        elif k == 1:  # block size / block offsets table
+            b[int(rng.integers(otp, otp + 8 + 8 * 5))] = int(rng.integers(0, 256))
+        elif k == 2:  # attribute table of the first block
+            b[int(rng.integers(first_block, first_block + 72))] = int(rng.integers(0, 256))
+        elif k == 3:  # truncation somewhere in the tables
+            b = b[:int(rng.integers(0, first_block + 100))]
+        else:  # a 64-bit field set to an extreme
+            at = int(rng.choice([otp, otp + 8, otp + 16, first_block, first_block + 8, first_block + 64]))
+            extremes = [0, 1, 2 ** 63, 2 ** 64 - 1, len(good), len(good) + 1]
+            b[at:at + 8] = np.frombuffer(extremes[int(rng.integers(0, len(extremes)))].to_bytes(8, "little"), np.uint8)
+        p = str(tmp_path / f"m{it}.lazer")
+        np.asarray(b).tofile(p)
+        paths.append(p)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
+    r = subprocess.run([exe] + paths, capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-4000:])
+    lines = r.stdout.splitlines()
+    assert len(lines) == len(paths)
+    failures = 0
+    for line, p in zip(lines, paths):
+        _, hrc, lrc = line.rsplit(" ", 2)
+        img = np.fromfile(p, dtype=np.uint8)
+        mn, mx = (C.c_double * 3)(), (C.c_double * 3)()
+        want = oracle.lib.pcqo_lazer_mem_bounds(img.ctypes.data_as(C.c_void_p), img.size, mn, mx) if img.size else None
+        if want is not None:
+            assert int(lrc) == want, (p, lrc, want, oracle.err())
+        failures += int(lrc) != 0
+    assert 50 < failures < len(paths)
