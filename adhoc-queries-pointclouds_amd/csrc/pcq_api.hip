@@ -441,6 +441,13 @@ static int validate_scan(const pcq_columns *cols, const pcq_predicate *pred, con
     if (pred->kind != PCQ_PRED_BOUNDS && pred->kind != PCQ_PRED_CLASS && pred->kind != PCQ_PRED_BOUNDS_F64)
         return pcq_fail(PCQ_ERR_ARG, "scan: bad predicate kind %d", pred->kind);
     if (cols->n == 0) return PCQ_OK;
+    // index arithmetic (n * stride, first_index + n) must stay far from 2^64: a LAS record length is a u16
+    // and 2^40 points is ~3 orders of magnitude beyond the largest dataset of the reference
+    if (cols->n > (1ull << 40) || cols->first_index > (1ull << 62))
+        return pcq_fail(PCQ_ERR_ARG, "scan: %llu points (first index %llu) is out of range", (unsigned long long)cols->n,
+                        (unsigned long long)cols->first_index);
+    if (cols->xyz_stride > 65535 || cols->cls_stride > 65535 || cols->rgb_stride > 65535)
+        return pcq_fail(PCQ_ERR_ARG, "scan: column stride above 65535");
     const bool need_xyz = pred->kind != PCQ_PRED_CLASS || c->kind != COLL_COUNT;
     const bool need_cls = pred->kind == PCQ_PRED_CLASS || c->kind != COLL_COUNT;
     if (need_xyz && (!cols->xyz || cols->xyz_stride < 12)) return pcq_fail(PCQ_ERR_ARG, "scan: positions column missing or stride < 12");
