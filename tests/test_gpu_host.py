@@ -335,6 +335,19 @@ def test_cli_stdout_matches_oracle_cli(files, mode, query_args):
     assert rc_c == 0 and sorted(body_c) == sorted(body_o)
 
 
+@pytest.mark.parametrize("box", ["nan;0;0;1;1;1", "0;-400;-100;inf;inf;inf", "-inf;-inf;-inf;inf;inf;inf", "0;0;0;nan;nan;nan",
+                                 "-1e308;-1e308;-1e308;1e308;1e308;1e308", "1e-320;-400;-100;200;0;100", "90;-250;0;90;-250;0"])
+def test_cli_non_finite_and_extreme_boxes(files, box):
+    """`str::parse::<f64>` accepts nan / inf; NaN compares false everywhere (no panic in from_min_max, no
+    intersection), infinities saturate in `as i64` (last.rs:98-109)."""
+    d = os.path.dirname(files[0])
+    args = ["-i", d, "--optimized", "--parallel", "--bounds", box]
+    rc_p, body_p, _, err_p = _cli(QUERY, args)
+    rc_o, body_o, _, err_o = _cli(ORACLE_CLI, args)
+    assert rc_p == rc_o, (box, err_p, err_o)
+    assert sorted(body_p) == sorted(body_o), box
+
+
 def test_cli_density_with_output_dir_writes_one_file_per_grid(files, tmp_path):
     d = os.path.dirname(files[0])
     for mode in (["--parallel"], []):

@@ -212,6 +212,16 @@ def test_lazer_cli_matches_oracle_cli(lazer_files, mode, query_args):
         assert body_p[0] == f"Searching {len(lazer_files)} files..."
 
 
+@pytest.mark.parametrize("box", ["nan;0;0;1;1;1", "-inf;-inf;-inf;inf;inf;inf", "0;-400;-100;inf;inf;inf", "90;-250;0;90;-250;0"])
+def test_lazer_cli_non_finite_boxes(lazer_files, box):
+    d = os.path.dirname(lazer_files[0])
+    args = ["-i", d, "--parallel", "--bounds", box]
+    rc_p, body_p, _, err_p = _cli(QUERY, args)
+    rc_o, body_o, _, err_o = _cli(ORACLE_CLI, args)
+    assert rc_p == rc_o, (box, err_p, err_o)
+    assert sorted(body_p) == sorted(body_o), box
+
+
 def test_lazer_mixed_directory(oracle, lazer_files, tmp_path):
     """LAST, LAS and LAZER files side by side in one query (is_valid_file, main.rs:185-189)."""
     import shutil
