@@ -157,6 +157,7 @@ def load_library() -> C.CDLL:
         "pcq_copy_to_host": (C.c_int, [vp, vp, vp, u64]),
         "pcq_device_memset": (C.c_int, [vp, vp, C.c_int, u64, vp]),
         "pcq_set_option": (C.c_int, [vp, C.c_char_p, i64]),
+        "pcq_get_option": (C.c_int, [vp, C.c_char_p, P(i64)]),
         "pcq_lz4_inflate_dev": (C.c_int, [vp, P(Lz4Job), C.c_size_t, vp]),
         "pcq_read_fd_to_device": (C.c_int, [vp, C.c_int, u64, u64, vp]),
         "pcq_synth_fill_dev": (C.c_int, [vp, P(SynthSpec), u64, u64, vp, vp, vp]),
@@ -285,6 +286,11 @@ class Context:
 
     def set_option(self, key: str, value: int) -> None:
         _check(self.lib.pcq_set_option(self.handle, key.encode(), int(value)))
+
+    def get_option(self, key: str) -> int:
+        v = C.c_int64()
+        _check(self.lib.pcq_get_option(self.handle, key.encode(), C.byref(v)))
+        return v.value
 
     def synchronize(self) -> None:
         _check(self.lib.pcq_ctx_synchronize(self.handle))

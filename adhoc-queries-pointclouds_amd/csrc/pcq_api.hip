@@ -82,9 +82,13 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) ctx->copy_threads = v;
     }
+    if (const char *e = getenv("PCQ_BATCH_VARIANT")) {
+        const int v = atoi(e);
+        if (v >= 0 && v <= 2) ctx->batch_variant = v;
+    }
     if (const char *e = getenv("PCQ_K1_VARIANT")) {
         const int v = atoi(e);
-        if (v >= 0 && v <= 7) ctx->k1_variant = v;
+        if (v >= 0 && v <= 11) ctx->k1_variant = v;
     }
     *out_ctx = ctx;
     return PCQ_OK;
@@ -156,12 +160,21 @@ extern "C" int pcq_ctx_synchronize(pcq_ctx *ctx) {
 extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return pcq_fail(PCQ_ERR_ARG, "pcq_set_option: null argument");
     if (!strcmp(key, "k1_variant")) {
-        if (value < 0 || value > 7) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..7");
+        if (value < 0 || value > 11) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..11");
         ctx->k1_variant = (int)value;
     } else if (!strcmp(key, "blocks_per_cu")) {
-        if (value < 1 || value > 16) return pcq_fail(PCQ_ERR_ARG, "blocks_per_cu must be 1..16");
+        if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "blocks_per_cu must be 1..32");
         ctx->grid_blocks_per_cu = (int)value;
         ctx->batch_blocks_per_cu = (int)value;
+    } else if (!strcmp(key, "k1_waves_per_cu")) {
+        if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "k1_waves_per_cu must be 1..32");
+        ctx->k1_waves_per_cu = (int)value;
+    } else if (!strcmp(key, "batch_variant")) {
+        if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "batch_variant must be 0..2");
+        ctx->batch_variant = (int)value;
+    } else if (!strcmp(key, "batch_waves_per_cu")) {
+        if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "batch_waves_per_cu must be 1..32");
+        ctx->batch_waves_per_cu = (int)value;
     } else if (!strcmp(key, "copy_threads")) {
         if (value < 1 || value > 64) return pcq_fail(PCQ_ERR_ARG, "copy_threads must be 1..64");
         ctx->copy_threads = (int)value;
@@ -171,6 +184,19 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else {
         return pcq_fail(PCQ_ERR_ARG, "unknown option '%s'", key);
     }
+    return PCQ_OK;
+}
+
+extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
+    if (!ctx || !key || !value) return pcq_fail(PCQ_ERR_ARG, "pcq_get_option: null argument");
+    if (!strcmp(key, "k1_variant")) *value = ctx->k1_variant;
+    else if (!strcmp(key, "k1_waves_per_cu")) *value = ctx->k1_waves_per_cu;
+    else if (!strcmp(key, "batch_variant")) *value = ctx->batch_variant;
+    else if (!strcmp(key, "batch_waves_per_cu")) *value = ctx->batch_waves_per_cu;
+    else if (!strcmp(key, "blocks_per_cu")) *value = ctx->grid_blocks_per_cu;
+    else if (!strcmp(key, "chunk_points")) *value = (int64_t)ctx->chunk_points;
+    else if (!strcmp(key, "copy_threads")) *value = ctx->copy_threads;
+    else return pcq_fail(PCQ_ERR_ARG, "unknown option '%s'", key);
     return PCQ_OK;
 }
 

@@ -137,9 +137,12 @@ struct pcq_ctx {
     // measured to stall for seconds (profiles/r01_grid_timeline.txt)
     DevGridTable grid_cache = {};
     // options
-    int k1_variant = 0;
+    int k1_variant = 9;           // per-file K1: one wave per workgroup, two adjacent 3 KiB tiles per step (profiles/r01_k1_one_wave_blocks.log)
+    int k1_waves_per_cu = 8;      // workgroups (= waves) per CU for the one-wave variants 8..11
     int grid_blocks_per_cu = 2;   // persistent blocks per CU of the streaming count kernels: 8 waves x 3 KiB in flight per CU measured best (profiles/r01_k1_variant_sweep_interleaved.log)
     int batch_blocks_per_cu = 3;  // the batched K1 measured best at 3 (same log)
+    int batch_variant = 2;        // batched K1: 0 = 256-thread blocks, one tile per wave step; 1 / 2 = one wave per workgroup, 2 / 3 tiles per step
+    int batch_waves_per_cu = 5;   // for batch_variant 1, 2: 5 x 9 KiB in flight per CU measured best and flat up to 8 (profiles/r01_k1_one_wave_blocks.log)
     int copy_threads = 4;         // threads filling a staging buffer (caller + helpers); tools/host_path_rate.py
     CopyPool *copy_pool = nullptr;  // created on first use by pcq_scan_host / pcq_scan_fd
     uint64_t chunk_points = 2ull << 20;    // 24 MB of positions per staging chunk (profiles/r01_host_path_rate.json: 1-8 Mi equal)

@@ -291,6 +291,45 @@ __global__ __launch_bounds__(BLOCK) void k_bounds_count_xyz12(const v4i *__restr
     block_store_partial(total, partials);
 }
 
+// K1 with one wave per workgroup (variants 8..11): the read-only geometry sweep
+// (profiles/r01_hbm_read_geometry_sweep.log) puts 64-thread blocks 1-2 % above 256-thread blocks at the same
+// bytes in flight.  A wave owns TILES adjacent 3 KiB tiles per step and issues all 3 * TILES loads before it
+// evaluates any of them (variant 8: 1 tile, 9: 2, 10: 3, 11: 4); option "k1_waves_per_cu" sets the number of
+// such workgroups per CU.
+template <int TILES>
+__global__ __launch_bounds__(64) void k_bounds_count_w1(const v4i *__restrict__ base, uint64_t n, DevPred pred,
+                                                        uint64_t *__restrict__ partials) {
+    const int lane = threadIdx.x;
+    const uint64_t tiles = n / TILE_POINTS;
+    const LaneBox lb = rotate_box(pred.lo, pred.width, lane);
+    uint64_t total = 0;
+    const uint64_t groups = tiles / TILES;
+    for (uint64_t g = blockIdx.x; g < groups; g += gridDim.x) {
+        const v4i *tile = base + g * (192 * TILES);
+        v4i v[TILES][3];
+#pragma unroll
+        for (int t = 0; t < TILES; t++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[t][k] = ld_nt(tile + 192 * t + 64 * k + lane);
+#pragma unroll
+        for (int t = 0; t < TILES; t++) total += tile_count_regs(v[t], lb);
+    }
+    if (blockIdx.x == 0) {
+        for (uint64_t t = groups * TILES; t < tiles; t++) total += tile_count_masks(base + t * 192, lane, lb);  // < TILES leftover tiles
+        for (int k = 0; k < 4; k++) {  // ragged tail: fewer than 256 points
+            const uint64_t p = tiles * TILE_POINTS + (uint64_t)(64 * k + lane);
+            bool pass = false;
+            if (p < n) {
+                const int *q = reinterpret_cast<const int *>(base) + 3 * p;
+                pass = ((uint32_t)(q[0] - pred.lo[0]) <= pred.width[0]) & ((uint32_t)(q[1] - pred.lo[1]) <= pred.width[1]) &
+                       ((uint32_t)(q[2] - pred.lo[2]) <= pred.width[2]);
+            }
+            total += (uint64_t)__popcll(__ballot(pass));
+        }
+    }
+    if (lane == 0) partials[blockIdx.x] = total;
+}
+
 // Batched K1: many device-resident LAST position blocks (one per file) in one launch.
 __global__ __launch_bounds__(BLOCK) void k_bounds_count_batch(const DevSegment *__restrict__ segs, int nseg,
                                                               uint64_t total_tiles, uint64_t *__restrict__ partials) {
@@ -328,6 +367,57 @@ __global__ __launch_bounds__(BLOCK) void k_bounds_count_batch(const DevSegment *
         total += (uint64_t)__popcll(__ballot(pass));
     }
     block_store_partial(total, partials);
+}
+
+// Batched K1 with one wave per workgroup and TILES adjacent tiles per step (the shape variants 8..11
+// measure on one file).  Here `tile_begin` of the segment table counts steps (TILES * 256 points), and the
+// fewer-than-a-step leftover of segment i is handled point by point by block i % gridDim.x.
+template <int TILES>
+__global__ __launch_bounds__(64) void k_bounds_count_batch_w1(const DevSegment *__restrict__ segs, int nseg,
+                                                             uint64_t total_steps, uint64_t *__restrict__ partials) {
+    constexpr uint64_t STEP_POINTS = (uint64_t)TILES * TILE_POINTS;
+    const int lane = threadIdx.x;
+    uint64_t total = 0;
+    int s = 0;
+    uint64_t seg_begin = 0, seg_end = 0;
+    const v4i *seg_base = nullptr;
+    LaneBox lb = {};
+    bool seg_empty = true;
+    for (uint64_t u = blockIdx.x; u < total_steps; u += gridDim.x) {
+        if (u >= seg_end) {
+            while (s + 1 < nseg && u >= segs[s + 1].tile_begin) s++;
+            seg_begin = segs[s].tile_begin;
+            seg_end = seg_begin + segs[s].n / STEP_POINTS;
+            seg_base = reinterpret_cast<const v4i *>(segs[s].xyz);
+            seg_empty = segs[s].empty != 0;
+            lb = rotate_box(segs[s].lo, segs[s].width, lane);
+        }
+        if (seg_empty) continue;
+        const v4i *tile = seg_base + (u - seg_begin) * (192 * TILES);
+        v4i v[TILES][3];
+#pragma unroll
+        for (int t = 0; t < TILES; t++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) v[t][k] = ld_nt(tile + 192 * t + 64 * k + lane);
+#pragma unroll
+        for (int t = 0; t < TILES; t++) total += tile_count_regs(v[t], lb);
+    }
+    for (int i = blockIdx.x; i < nseg; i += gridDim.x) {
+        if (segs[i].empty) continue;
+        const uint64_t n = segs[i].n;
+        const int *q0 = reinterpret_cast<const int *>(segs[i].xyz);
+        for (uint64_t p = (n / STEP_POINTS) * STEP_POINTS + lane; p < ((n + 63) & ~63ull); p += 64) {
+            bool pass = false;
+            if (p < n) {
+                const int *q = q0 + 3 * p;
+                pass = ((uint32_t)(q[0] - segs[i].lo[0]) <= segs[i].width[0]) &
+                       ((uint32_t)(q[1] - segs[i].lo[1]) <= segs[i].width[1]) &
+                       ((uint32_t)(q[2] - segs[i].lo[2]) <= segs[i].width[2]);
+            }
+            total += (uint64_t)__popcll(__ballot(pass));
+        }
+    }
+    if (lane == 0) partials[blockIdx.x] = total;
 }
 
 // Bytes of a dword equal to zero -> 0x80 in that byte (exact, no borrow artefacts).
@@ -469,6 +559,23 @@ int pcq_launch_bounds_count_xyz12(pcq_ctx *ctx, const void *d_xyz, uint64_t n, c
     int rc = pcq_ensure_partials(ctx, (size_t)grid);
     if (rc) return rc;
     const v4i *base = reinterpret_cast<const v4i *>(d_xyz);
+    if (ctx->k1_variant >= 8 && ctx->k1_variant <= 11) {  // one wave per workgroup, TILES tiles per step
+        const int tiles_per_step = ctx->k1_variant - 7;
+        const uint64_t units = n / ((uint64_t)tiles_per_step * TILE_POINTS) + 1;
+        uint64_t g = (uint64_t)ctx->num_cus * ctx->k1_waves_per_cu;
+        if (g > units) g = units;
+        rc = pcq_ensure_partials(ctx, (size_t)g);
+        if (rc) return rc;
+        switch (tiles_per_step) {
+        case 1: hipLaunchKernelGGL(k_bounds_count_w1<1>, dim3((unsigned)g), dim3(64), 0, s, base, n, pred, ctx->d_partials); break;
+        case 2: hipLaunchKernelGGL(k_bounds_count_w1<2>, dim3((unsigned)g), dim3(64), 0, s, base, n, pred, ctx->d_partials); break;
+        case 3: hipLaunchKernelGGL(k_bounds_count_w1<3>, dim3((unsigned)g), dim3(64), 0, s, base, n, pred, ctx->d_partials); break;
+        default: hipLaunchKernelGGL(k_bounds_count_w1<4>, dim3((unsigned)g), dim3(64), 0, s, base, n, pred, ctx->d_partials); break;
+        }
+        hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, (int)g, d_count);
+        PCQ_HIP(hipGetLastError());
+        return PCQ_OK;
+    }
     switch (ctx->k1_variant) {
     case 1: hipLaunchKernelGGL(k_bounds_count_xyz12<1>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
     case 2: hipLaunchKernelGGL(k_bounds_count_xyz12<2>, dim3(grid), dim3(BLOCK), 0, s, base, n, pred, ctx->d_partials); break;
@@ -557,7 +664,7 @@ extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, c
         g.tile_begin = tiles;
         for (int a = 0; a < 3; a++) g.lo[a] = dp.lo[a], g.width[a] = dp.width[a];
         g.empty = dp.empty;
-        tiles += cols[i].n / TILE_POINTS;
+        tiles += cols[i].n / ((uint64_t)(ctx->batch_variant ? ctx->batch_variant + 1 : 1) * TILE_POINTS);
         points += cols[i].n;
     }
     if (ctx->segments_uploaded != nsegments || ctx->segments_kind != kind ||
@@ -576,6 +683,21 @@ extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, c
         hipLaunchKernelGGL(k_class_count_batch, dim3(cgrid), dim3(BLOCK), 0, s, ctx->d_segments, (int)nsegments, tiles,
                            ctx->d_partials);
         hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, cgrid, device_total);
+        PCQ_HIP(hipGetLastError());
+        return PCQ_OK;
+    }
+    if (ctx->batch_variant >= 1) {  // one wave per workgroup, 2 (variant 1) or 3 (variant 2) adjacent tiles per step
+        uint64_t g = (uint64_t)ctx->num_cus * ctx->batch_waves_per_cu;
+        if (g > tiles + nsegments) g = tiles + nsegments;
+        int wrc = pcq_ensure_partials(ctx, (size_t)g);
+        if (wrc) return wrc;
+        if (ctx->batch_variant == 1)
+            hipLaunchKernelGGL(k_bounds_count_batch_w1<2>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles,
+                               ctx->d_partials);
+        else
+            hipLaunchKernelGGL(k_bounds_count_batch_w1<3>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles,
+                               ctx->d_partials);
+        hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, (int)g, device_total);
         PCQ_HIP(hipGetLastError());
         return PCQ_OK;
     }

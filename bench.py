@@ -223,6 +223,11 @@ def main():
     alg_bytes = BYTES_PER_POINT * (sum(launch_pts) / max(1, len(launch_pts)))
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
 
+    k1v, bv = ctx.get_option("k1_variant"), ctx.get_option("batch_variant")
+    if args.per_file_launch:
+        kernel_name = f"k_bounds_count_w1<{k1v - 7}>" if k1v >= 8 else f"k_bounds_count_xyz12<{k1v}>"
+    else:
+        kernel_name = f"k_bounds_count_batch_w1<{bv + 1}>" if bv >= 1 else "k_bounds_count_batch"
     result = None
     if rank == 0:
         traffic = None
@@ -267,7 +272,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
-                "kernel": "k_bounds_count_xyz12" if args.per_file_launch else "k_bounds_count_batch",
+                "kernel": kernel_name,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": len(launch_ms),

@@ -252,9 +252,11 @@ int pcq_lz4_inflate_dev(pcq_ctx *ctx, pcq_lz4_job *jobs, size_t njobs, void *str
  * block path (pinned double buffering, parallel pread).  Synchronous. */
 int pcq_read_fd_to_device(pcq_ctx *ctx, int fd, uint64_t file_offset, uint64_t bytes, void *d_dst);
 
-/* Tuning knobs: "k1_variant" (bounds-count kernel variant, 0 = default), "blocks_per_cu", "chunk_points"
- * (points per staging chunk of the host paths), "copy_threads" (threads filling a staging chunk, default 4). */
+/* Tuning knobs: "k1_variant" (bounds-count kernel variant 0..11), "k1_waves_per_cu", "batch_variant" (0..2),
+ * "batch_waves_per_cu", "blocks_per_cu" (the 256-thread kernels), "chunk_points" (points per staging chunk of
+ * the host paths), "copy_threads" (threads filling a staging chunk, default 4). */
 int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value);
+int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value);
 
 #ifdef __cplusplus
 }

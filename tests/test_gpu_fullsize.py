@@ -47,7 +47,7 @@ def count_bounds(ctx, r, lmin, lmax, variant=None):
     n = cc.point_count()
     cc.free()
     if variant is not None:
-        ctx.set_option("k1_variant", 0)
+        ctx.set_option("k1_variant", 9)  # the default (csrc/pcq_internal.h)
     return n
 
 

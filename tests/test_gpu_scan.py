@@ -56,8 +56,11 @@ BOXES = [
 ]
 
 
-@pytest.mark.parametrize("n", [0, 1, 3, 255, 256, 257, 1000, 4099, 100_003, 1_000_003])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7])
+K1_DEFAULT, BATCH_DEFAULT = 9, 2  # csrc/pcq_internal.h
+
+
+@pytest.mark.parametrize("n", [0, 1, 3, 255, 256, 257, 511, 512, 513, 1000, 4099, 100_003, 1_000_003])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
 def test_bounds_count_dev_matches_oracle(oracle, gpu_ctx, n, variant):
     spec = small_spec(1234 + n, n)
     image = oracle.synth_image(spec, transposed=True)
@@ -83,7 +86,7 @@ def test_bounds_count_dev_matches_oracle(oracle, gpu_ctx, n, variant):
             finally:
                 f.free()
     finally:
-        gpu_ctx.set_option("k1_variant", 0)
+        gpu_ctx.set_option("k1_variant", K1_DEFAULT)
 
 
 @pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 31, 1000, 65_537, 1_000_003])
@@ -132,11 +135,13 @@ def test_count_collector_accumulates_and_external_counter(oracle, gpu_ctx):
         f.free()
 
 
-def test_count_batch_matches_sum_of_files(oracle, gpu_ctx):
+@pytest.mark.parametrize("batch_variant", [0, 1, 2])
+def test_count_batch_matches_sum_of_files(oracle, gpu_ctx, batch_variant):
     files, cols, preds, expect = [], [], [], 0
     bmin, bmax = (-20.0, -30.0, -3.0), (15.0, 45.0, 4.0)
+    gpu_ctx.set_option("batch_variant", batch_variant)
     try:
-        for i, n in enumerate([100_003, 0, 255, 256, 70_001, 1_000_003]):
+        for i, n in enumerate([100_003, 0, 255, 256, 70_001, 1_000_003, 511, 512, 513, 767, 768, 769, 1535, 1536, 1537]):
             spec = small_spec(500 + i, n, offset=(float(i), 0.0, 0.0))
             image = oracle.synth_image(spec, transposed=True)
             hdr = oracle.parse_header(image[:400].tobytes())
@@ -158,6 +163,7 @@ def test_count_batch_matches_sum_of_files(oracle, gpu_ctx):
         gpu_ctx.free(total)
         assert int(host[0]) == 2 * expect
     finally:
+        gpu_ctx.set_option("batch_variant", BATCH_DEFAULT)
         for f in files:
             f.free()
 
