@@ -143,6 +143,8 @@ struct pcq_ctx {
     int batch_blocks_per_cu = 3;  // the batched K1 measured best at 3 (same log)
     int batch_variant = 2;        // batched K1: 0 = 256-thread blocks, one tile per wave step; 1 / 2 = one wave per workgroup, 2 / 3 tiles per step
     int batch_waves_per_cu = 5;   // for batch_variant 1, 2: 5 x 9 KiB in flight per CU measured best and flat up to 8 (profiles/r01_k1_one_wave_blocks.log)
+    int class_batch_loads = 4;        // batched K2: 0 = 256-thread kernel; 4 / 6 / 8 / 12 = one-wave workgroups with that many 1 KiB loads per step
+    int class_batch_waves_per_cu = 8; // 8 x 4 KiB measured best (profiles/r01_k2_sweep.log)
     int copy_threads = 4;         // threads filling a staging buffer (caller + helpers); tools/host_path_rate.py
     CopyPool *copy_pool = nullptr;  // created on first use by pcq_scan_host / pcq_scan_fd
     uint64_t chunk_points = 2ull << 20;    // 24 MB of positions per staging chunk (profiles/r01_host_path_rate.json: 1-8 Mi equal)

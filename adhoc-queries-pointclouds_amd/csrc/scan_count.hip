@@ -528,6 +528,58 @@ __global__ __launch_bounds__(BLOCK) void k_class_count_batch(const DevSegment *_
     block_store_partial(w, partials);
 }
 
+// Batched K2 with one wave per workgroup and LOADS 1 KiB loads per step (tile_begin counts steps of
+// LOADS * 64 vectors); leftovers of segment i by block i % gridDim.x.
+template <int LOADS>
+__global__ __launch_bounds__(64) void k_class_count_batch_w1(const DevSegment *__restrict__ raw, int nseg, uint64_t total_steps,
+                                                            uint64_t *__restrict__ partials) {
+    constexpr uint64_t STEP_VEC = 64 * LOADS;
+    const int lane = threadIdx.x;
+    uint32_t cnt = 0;
+    int s = 0;
+    uint64_t seg_begin = 0, seg_end = 0;
+    const v4i *body = nullptr;
+    uint32_t pat = 0;
+    for (uint64_t t = blockIdx.x; t < total_steps; t += gridDim.x) {
+        if (t >= seg_end) {
+            while (s + 1 < nseg && t >= cseg(raw, s + 1).tile_begin) s++;
+            seg_begin = cseg(raw, s).tile_begin;
+            seg_end = seg_begin + cseg(raw, s).nvec / STEP_VEC;
+            body = reinterpret_cast<const v4i *>(cseg(raw, s).cls + cseg(raw, s).head);
+            pat = cseg(raw, s).pat;
+        }
+        const v4i *tile = body + (t - seg_begin) * STEP_VEC;
+        v4i v[LOADS];
+#pragma unroll
+        for (int k = 0; k < LOADS; k++) v[k] = ld_nt(tile + 64 * k + lane);
+#pragma unroll
+        for (int k = 0; k < LOADS; k++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) cnt += __popc(zero_bytes((uint32_t)v[k][j] ^ pat));
+    }
+    for (int i = blockIdx.x; i < nseg; i += gridDim.x) {
+        const DevClassSegment g = cseg(raw, i);
+        const uint8_t c8 = (uint8_t)(g.pat & 0xff);
+        const v4i *bd = reinterpret_cast<const v4i *>(g.cls + g.head);
+        for (uint64_t v = (g.nvec / STEP_VEC) * STEP_VEC + lane; v < g.nvec; v += 64) {
+            const v4i a = bd[v];
+#pragma unroll
+            for (int j = 0; j < 4; j++) cnt += __popc(zero_bytes((uint32_t)a[j] ^ g.pat));
+        }
+        if (lane < 16) {
+            const uint64_t p = lane;
+            if (p < g.head && g.cls[p] == c8) cnt++;
+        } else if (lane < 32) {
+            const uint64_t p = g.head + 16 * g.nvec + (lane - 16);
+            if (p < g.n && g.cls[p] == c8) cnt++;
+        }
+    }
+    uint64_t w = cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down((unsigned long long)w, off, 64);
+    if (lane == 0) partials[blockIdx.x] = w;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_finish_count(const uint64_t *__restrict__ partials, int nblocks,
                                                         uint64_t *__restrict__ d_count) {
     __shared__ uint64_t s[BLOCK];
@@ -648,7 +700,7 @@ extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, c
             g.tile_begin = tiles;
             g.pat = 0x01010101u * (uint32_t)preds[i].cls;
             memcpy(&table[i], &g, sizeof g);
-            tiles += g.nvec / 256;
+            tiles += g.nvec / (ctx->class_batch_loads ? 64 * (uint64_t)ctx->class_batch_loads : 256);
             points += g.n;
             continue;
         }
@@ -674,6 +726,21 @@ extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, c
         PCQ_HIP(hipMemcpyAsync(ctx->d_segments, ctx->h_segments, nsegments * sizeof(DevSegment), hipMemcpyHostToDevice, s));
         ctx->segments_uploaded = nsegments;
         ctx->segments_kind = kind;
+    }
+    if (kind == PCQ_PRED_CLASS && ctx->class_batch_loads) {  // one wave per workgroup, class_batch_loads KiB per step
+        uint64_t g = (uint64_t)ctx->num_cus * ctx->class_batch_waves_per_cu;
+        if (g > tiles + nsegments) g = tiles + nsegments;
+        int crc = pcq_ensure_partials(ctx, (size_t)g);
+        if (crc) return crc;
+        switch (ctx->class_batch_loads) {
+        case 4: hipLaunchKernelGGL(k_class_count_batch_w1<4>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles, ctx->d_partials); break;
+        case 6: hipLaunchKernelGGL(k_class_count_batch_w1<6>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles, ctx->d_partials); break;
+        case 8: hipLaunchKernelGGL(k_class_count_batch_w1<8>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles, ctx->d_partials); break;
+        default: hipLaunchKernelGGL(k_class_count_batch_w1<12>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles, ctx->d_partials); break;
+        }
+        hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, (int)g, device_total);
+        PCQ_HIP(hipGetLastError());
+        return PCQ_OK;
     }
     if (kind == PCQ_PRED_CLASS) {
         // one 4 KiB tile per wave per iteration; the class stream wants more waves in flight than K1
