@@ -67,6 +67,33 @@ __device__ __forceinline__ bool eval_pred(const DevCols &c, const DevPred &pr, u
     return (uint32_t)c.cls[i * c.cls_stride] == pr.cls;
 }
 
+// The same with the predicate kind fixed at compile time, so that unrolled callers get straight-line code
+// (loads of several points issued together instead of one branch diamond per point).
+template <int KIND>
+__device__ __forceinline__ bool eval_pred_kind(const DevCols &c, const DevPred &pr, uint64_t i) {
+    if (KIND == PCQ_PRED_CLASS) return (uint32_t)c.cls[i * c.cls_stride] == pr.cls;
+    const RawPoint rp = ld_xyz(c, i);
+    if (KIND == PCQ_PRED_BOUNDS)
+        return (pr.empty == 0) & ((uint32_t)(rp.x - pr.lo[0]) <= pr.width[0]) & ((uint32_t)(rp.y - pr.lo[1]) <= pr.width[1]) &
+               ((uint32_t)(rp.z - pr.lo[2]) <= pr.width[2]);
+    const double wx = c.offset[0] + c.scale[0] * (double)rp.x, wy = c.offset[1] + c.scale[1] * (double)rp.y,
+                 wz = c.offset[2] + c.scale[2] * (double)rp.z;
+    return !((wx < pr.wmin[0]) | (wy < pr.wmin[1]) | (wz < pr.wmin[2]) | (wx > pr.wmax[0]) | (wy > pr.wmax[1]) | (wz > pr.wmax[2]));
+}
+
+// Same, keeping the loaded position (bounds kinds) for the record that a match needs.
+template <int KIND>
+__device__ __forceinline__ bool eval_pred_kind(const DevCols &c, const DevPred &pr, uint64_t i, RawPoint &rp) {
+    if (KIND == PCQ_PRED_CLASS) return (uint32_t)c.cls[i * c.cls_stride] == pr.cls;
+    rp = ld_xyz(c, i);
+    if (KIND == PCQ_PRED_BOUNDS)
+        return (pr.empty == 0) & ((uint32_t)(rp.x - pr.lo[0]) <= pr.width[0]) & ((uint32_t)(rp.y - pr.lo[1]) <= pr.width[1]) &
+               ((uint32_t)(rp.z - pr.lo[2]) <= pr.width[2]);
+    const double wx = c.offset[0] + c.scale[0] * (double)rp.x, wy = c.offset[1] + c.scale[1] * (double)rp.y,
+                 wz = c.offset[2] + c.scale[2] * (double)rp.z;
+    return !((wx < pr.wmin[0]) | (wy < pr.wmin[1]) | (wz < pr.wmin[2]) | (wx > pr.wmax[0]) | (wy > pr.wmax[1]) | (wz > pr.wmax[2]));
+}
+
 // last.rs:156-160 — (i as f64 * scale) + offset, two roundings.
 __device__ __forceinline__ double world(int32_t v, double scale, double offset) {
     const double m = (double)v * scale;

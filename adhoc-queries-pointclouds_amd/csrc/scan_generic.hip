@@ -17,15 +17,22 @@ using namespace pcqdev;
 
 namespace {
 
+template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_generic_count(DevCols c, DevPred pr, uint64_t *__restrict__ partials) {
     const uint64_t tid = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
     uint64_t cnt = 0;
-    for (uint64_t i = tid; i < c.n; i += nthreads) {
-        RawPoint rp;
-        bool have;
-        cnt += eval_pred(c, pr, i, rp, have) ? 1 : 0;
+    uint64_t i = tid;
+    // four independent points per thread and step: a strided 12-byte (or 1-byte) load keeps only 64 x stride bytes
+    // of a wave in flight, so the loads of four steps are issued together (profiles/r01_las_aos_count_rate.log)
+    for (; i + 3 * nthreads < c.n; i += 4 * nthreads) {
+        bool m[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) m[k] = eval_pred_kind<KIND>(c, pr, i + k * nthreads);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cnt += m[k] ? 1 : 0;
     }
+    for (; i < c.n; i += nthreads) cnt += eval_pred_kind<KIND>(c, pr, i) ? 1 : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down((unsigned long long)cnt, off, 64);
     __shared__ uint64_t s_w[WAVES];
@@ -53,17 +60,19 @@ __global__ __launch_bounds__(BLOCK) void k_sum_partials(const uint64_t *__restri
 }
 
 // Pass 1: block b owns points [b*TILE, (b+1)*TILE); counts[b] = matches in the tile.
+template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_tile_counts(DevCols c, DevPred pr, uint64_t *__restrict__ counts) {
     const uint64_t base = (uint64_t)blockIdx.x * TILE;
     uint32_t cnt = 0;
+    bool m[ITEMS];
+    // all ITEMS loads of a thread are issued before the first compare (index clamped instead of branching)
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {
         const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
-        RawPoint rp;
-        bool have;
-        const bool pass = i < c.n && eval_pred(c, pr, i, rp, have);
-        cnt += (uint32_t)__popcll(__ballot(pass));  // wave-uniform
+        m[j] = eval_pred_kind<KIND>(c, pr, i < c.n ? i : c.n - 1) & (i < c.n);
     }
+#pragma unroll
+    for (int j = 0; j < ITEMS; j++) cnt += (uint32_t)__popcll(__ballot(m[j]));  // wave-uniform
     __shared__ uint32_t s_w[WAVES];
     if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
     __syncthreads();
@@ -113,6 +122,7 @@ __global__ __launch_bounds__(1024) void k_exclusive_scan(uint64_t *__restrict__ 
 constexpr int FLUSH_ITEMS = 4;                                  // input rows of 256 points per LDS flush
 constexpr int STAGE_BYTES = FLUSH_ITEMS * BLOCK * 31 + 16;      // 31,760 B: five blocks per CU fit in LDS
 
+template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, const uint64_t *__restrict__ offsets,
                                                        uint8_t *__restrict__ out31, uint64_t out_base) {
     __shared__ uint32_t s_w[WAVES];
@@ -125,13 +135,21 @@ __global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, co
         const uint64_t gbyte0 = run * 31ull;
         const uint32_t pad = (uint32_t)(gbyte0 & 15);
         uint32_t seg = 0;  // matches staged so far (block-uniform)
-#pragma unroll 1
+        // the predicate inputs of the FLUSH_ITEMS rows are loaded together, then the rows are ranked one by one
+        RawPoint rps[FLUSH_ITEMS];
+        bool passes[FLUSH_ITEMS];
+#pragma unroll
+        for (int jj = 0; jj < FLUSH_ITEMS; jj++) {
+            const uint64_t i = base + (uint64_t)(h * FLUSH_ITEMS + jj) * BLOCK + threadIdx.x;
+            passes[jj] = eval_pred_kind<KIND>(c, pr, i < c.n ? i : c.n - 1, rps[jj]) & (i < c.n);
+        }
+#pragma unroll
         for (int jj = 0; jj < FLUSH_ITEMS; jj++) {
             const int j = h * FLUSH_ITEMS + jj;
             const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
-            RawPoint rp;
-            bool have = false;
-            const bool pass = i < c.n && eval_pred(c, pr, i, rp, have);
+            RawPoint rp = rps[jj];
+            const bool have = KIND != PCQ_PRED_CLASS;
+            const bool pass = passes[jj];
             const uint64_t mask = __ballot(pass);
             if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
             __syncthreads();
@@ -179,7 +197,9 @@ int pcq_launch_generic_count(pcq_ctx *ctx, const DevCols &cols, const DevPred &p
     const int grid = (int)(want < cap ? want : cap);
     int rc = pcq_ensure_partials(ctx, (size_t)grid);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_generic_count, dim3(grid), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials);
+    if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_generic_count<PCQ_PRED_BOUNDS>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials);
+    else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_generic_count<PCQ_PRED_CLASS>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials);
+    else hipLaunchKernelGGL(k_generic_count<PCQ_PRED_BOUNDS_F64>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials);
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, grid, d_count);
     PCQ_HIP(hipGetLastError());
     return PCQ_OK;
@@ -193,7 +213,9 @@ int pcq_emit_prepare(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uin
     if (nblocks > 0x7fffffffull) return pcq_fail(PCQ_ERR_ARG, "scan chunk too large (%llu points)", (unsigned long long)cols.n);
     int rc = pcq_ensure_partials(ctx, (size_t)nblocks);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tile_counts, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials);
+    if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_BOUNDS>, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials);
+    else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_CLASS>, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials);
+    else hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_BOUNDS_F64>, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials);
     hipLaunchKernelGGL(k_exclusive_scan, dim3(1), dim3(1024), 0, s, ctx->d_partials, nblocks, ctx->d_scalars);
     PCQ_HIP(hipGetLastError());
     PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -207,8 +229,12 @@ int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pre
     (void)expected;
     if (cols.n == 0) return PCQ_OK;
     const uint64_t nblocks = (cols.n + TILE - 1) / TILE;
-    hipLaunchKernelGGL(k_emit_points, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials, d_out31,
-                       out_base);
+    if (pred.kind == PCQ_PRED_BOUNDS)
+        hipLaunchKernelGGL(k_emit_points<PCQ_PRED_BOUNDS>, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials, d_out31, out_base);
+    else if (pred.kind == PCQ_PRED_CLASS)
+        hipLaunchKernelGGL(k_emit_points<PCQ_PRED_CLASS>, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials, d_out31, out_base);
+    else
+        hipLaunchKernelGGL(k_emit_points<PCQ_PRED_BOUNDS_F64>, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, ctx->d_partials, d_out31, out_base);
     PCQ_HIP(hipGetLastError());
     return PCQ_OK;
 }

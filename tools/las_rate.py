@@ -23,7 +23,9 @@ with pkg.Context(0) as ctx:
     counter = torch.zeros(2, dtype=torch.int64, device=dev)
     cc = ctx.count_collector(device_counter=counter.data_ptr())
     out = {}
-    for rl in (20, 26, 28, 34):
+    bpcs = [int(b) for b in (sys.argv[2].split(",") if len(sys.argv) > 2 else ["2"])]
+    for rl, bpc in [(rl, b) for rl in (20, 26, 28, 34) for b in bpcs]:
+        ctx.set_option("blocks_per_cu", bpc)
         nfiles = 6  # rotate buffers: 6 x n x rl bytes > Infinity Cache
         recs = []
         for f in range(nfiles):
@@ -51,7 +53,7 @@ with pkg.Context(0) as ctx:
             times.sort()
             med = times[len(times) // 2]
             res[kind] = {"ms": med, "GBps": n * rl / med / 1e6, "Mpts_per_s": n / med / 1e3, "count": int(counter[0].item())}
-        out[rl] = res
-        print(rl, json.dumps(res), flush=True)
+        out[(rl, bpc)] = res
+        print(rl, f"blocks/CU={bpc}", json.dumps(res), flush=True)
         del recs
     cc.free()
