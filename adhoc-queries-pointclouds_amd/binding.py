@@ -347,6 +347,10 @@ class Context:
     def scan_host(self, cols: Columns, pred: Predicate, coll: Collector) -> None:
         _check(self.lib.pcq_scan_host(self.handle, C.byref(cols), C.byref(pred), coll.handle))
 
+    def scan_fd(self, fd: int, cols: Columns, pred: Predicate, coll: Collector) -> None:
+        """Like scan_host, with the column pointers given as byte offsets into the open file `fd`."""
+        _check(self.lib.pcq_scan_fd(self.handle, fd, C.byref(cols), C.byref(pred), coll.handle))
+
     def scan_dev_count_batch(self, cols: Sequence[Columns], preds: Sequence[Predicate], device_total: int,
                              stream: Optional[int] = None) -> None:
         n = len(cols)

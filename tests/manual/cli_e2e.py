@@ -39,7 +39,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--files", type=int, default=16)
     ap.add_argument("--points", type=int, default=20_000_000)
-    ap.add_argument("--threads-per-gpu", type=int, default=4)
+    ap.add_argument("--threads-per-gpu", type=int, default=1)
     args = ap.parse_args()
     o = _oracle.Oracle()
     d = tempfile.mkdtemp(prefix="pcq_e2e_", dir="/tmp")
@@ -54,10 +54,10 @@ def main():
         base = ["-i", d, "--optimized", "--parallel"] + q
         t_gpu, out_gpu = run(QUERY, base + ["--threads-per-gpu", str(args.threads_per_gpu)])
         t_gpu2, _ = run(QUERY, base + ["--threads-per-gpu", "2"])
-        t_gpu8, _ = run(QUERY, base + ["--threads-per-gpu", "8"])
+        t_gpu8, _ = run(QUERY, base + ["--threads-per-gpu", "4"])
         t_cpu, out_cpu = run(ORACLE, base, repeat=1)
         assert sorted(out_gpu) == sorted(out_cpu), (out_gpu, out_cpu)
-        res[name] = {"gpu_cli_s": t_gpu, "gpu_cli_s_2thr": t_gpu2, "gpu_cli_s_8thr": t_gpu8, "oracle_cli_s": t_cpu, "gpu_Mpts_per_s": total_pts / t_gpu / 1e6,
+        res[name] = {"gpu_cli_s": t_gpu, "gpu_cli_s_2thr": t_gpu2, "gpu_cli_s_4thr": t_gpu8, "oracle_cli_s": t_cpu, "gpu_Mpts_per_s": total_pts / t_gpu / 1e6,
                      "oracle_cli_Mpts_per_s": total_pts / t_cpu / 1e6, "stdout": out_gpu[-1] if out_gpu else ""}
         print(name, json.dumps(res[name]), flush=True)
     for f in os.listdir(d):
