@@ -7,6 +7,8 @@
 #pragma once
 
 #include <errno.h>
+#include <pthread.h>
+#include <sched.h>
 #include <string.h>
 #include <unistd.h>
 
@@ -20,8 +22,13 @@
 class CopyPool {
 public:
     // result of run(): 0, or 1 = short read (end of file), or -errno of a failed pread
-    explicit CopyPool(int helpers) {
-        for (int i = 0; i < helpers; i++) workers_.emplace_back([this] { loop(); });
+    // `cpus` (may be null): the CPUs the helpers are pinned to — the GPU's NUMA node, so that the pinned
+    // staging buffer they fill is written by local cores
+    explicit CopyPool(int helpers, const cpu_set_t *cpus = nullptr) {
+        for (int i = 0; i < helpers; i++) {
+            workers_.emplace_back([this] { loop(); });
+            if (cpus && CPU_COUNT(cpus) > 0) (void)pthread_setaffinity_np(workers_.back().native_handle(), sizeof(cpu_set_t), cpus);
+        }
     }
     ~CopyPool() {
         {

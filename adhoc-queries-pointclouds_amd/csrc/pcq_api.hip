@@ -8,6 +8,7 @@
 
 #include <unistd.h>
 
+#include <cctype>
 #include <cerrno>
 #include <cmath>
 #include <cstdlib>
@@ -32,6 +33,40 @@ extern "C" int pcq_abi_version(void) { return PCQ_ABI_VERSION; }
 // ---------------------------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------------------------
+// Which NUMA node is the GPU attached to, and which CPUs belong to it (Linux sysfs; silently unknown elsewhere).
+// DMA out of pinned host memory on the GPU's own socket runs at the PCIe rate; across the socket
+// interconnect it was measured at about two thirds of it (profiles/r01_file_path_rate.log).
+static void detect_numa_node(pcq_ctx *ctx) {
+    CPU_ZERO(&ctx->node_cpus);
+    ctx->numa_node = -1;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, ctx->device) != hipSuccess) return;
+    for (char *p = bus; *p; p++) *p = (char)tolower((unsigned char)*p);
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    int node = -1;
+    if (fscanf(f, "%d", &node) != 1) node = -1;
+    fclose(f);
+    if (node < 0) return;
+    snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    f = fopen(path, "r");
+    if (!f) return;
+    char list[1024] = {0};
+    if (fgets(list, sizeof list, f)) {
+        for (char *tok = strtok(list, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+            int a = 0, b = 0;
+            const int k = sscanf(tok, "%d-%d", &a, &b);
+            if (k == 1) b = a;
+            if (k >= 1)
+                for (int c = a; c <= b && c < CPU_SETSIZE; c++) CPU_SET(c, &ctx->node_cpus);
+        }
+    }
+    fclose(f);
+    if (CPU_COUNT(&ctx->node_cpus) > 0) ctx->numa_node = node;
+}
+
 extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
     if (!out_ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_init: out_ctx is null");
     *out_ctx = nullptr;
@@ -51,6 +86,7 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
         return pcq_fail(PCQ_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
     }
     ctx->num_cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+    detect_numa_node(ctx);
     if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking)) != hipSuccess) {
         pcq_shutdown(ctx);
@@ -78,6 +114,7 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
         const long long v = atoll(e);
         if (v >= 4) ctx->chunk_points = (uint64_t)v;
     }
+    if (const char *e = getenv("PCQ_NUMA_LOCAL")) ctx->numa_local = atoi(e) != 0;
     if (const char *e = getenv("PCQ_COPY_THREADS")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) ctx->copy_threads = v;
@@ -181,6 +218,21 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "batch_waves_per_cu")) {
         if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "batch_waves_per_cu must be 1..32");
         ctx->batch_waves_per_cu = (int)value;
+    } else if (!strcmp(key, "numa_local")) {
+        ctx->numa_local = value != 0;
+        delete ctx->copy_pool;  // helpers are re-created with or without the affinity
+        ctx->copy_pool = nullptr;
+        if (ctx->stage_bytes) {  // and the staging buffers re-allocated on the next scan
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipStreamSynchronize(ctx->copy_stream);
+            for (int i = 0; i < 2; i++) {
+                if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
+                if (ctx->d_stage[i]) (void)hipFree(ctx->d_stage[i]);
+                ctx->h_stage[i] = nullptr;
+                ctx->d_stage[i] = nullptr;
+            }
+            ctx->stage_bytes = 0;
+        }
     } else if (!strcmp(key, "copy_threads")) {
         if (value < 1 || value > 64) return pcq_fail(PCQ_ERR_ARG, "copy_threads must be 1..64");
         ctx->copy_threads = (int)value;
@@ -202,6 +254,8 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     else if (!strcmp(key, "blocks_per_cu")) *value = ctx->grid_blocks_per_cu;
     else if (!strcmp(key, "chunk_points")) *value = (int64_t)ctx->chunk_points;
     else if (!strcmp(key, "copy_threads")) *value = ctx->copy_threads;
+    else if (!strcmp(key, "numa_local")) *value = ctx->numa_local;
+    else if (!strcmp(key, "numa_node")) *value = ctx->numa_node;
     else return pcq_fail(PCQ_ERR_ARG, "unknown option '%s'", key);
     return PCQ_OK;
 }
@@ -599,10 +653,18 @@ static int ensure_stage(pcq_ctx *ctx, size_t bytes) {
         ctx->d_stage[i] = nullptr;
     }
     ctx->stage_bytes = 0;
-    for (int i = 0; i < 2; i++) {
-        PCQ_HIP(hipHostMalloc((void **)&ctx->h_stage[i], bytes, hipHostMallocDefault));
-        PCQ_HIP(hipMalloc((void **)&ctx->d_stage[i], bytes));
+    // pinned pages are allocated where the allocating thread runs (default "local" policy): run on the GPU's node for it
+    cpu_set_t saved;
+    const bool rebind = ctx->numa_local && ctx->numa_node >= 0 && sched_getaffinity(0, sizeof saved, &saved) == 0 &&
+                        sched_setaffinity(0, sizeof ctx->node_cpus, &ctx->node_cpus) == 0;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+        e = hipHostMalloc((void **)&ctx->h_stage[i], bytes, hipHostMallocDefault);
+        if (e == hipSuccess) memset(ctx->h_stage[i], 0, bytes);  // first touch, should the runtime not have done it
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stage[i], bytes);
     }
+    if (rebind) (void)sched_setaffinity(0, sizeof saved, &saved);
+    if (e != hipSuccess) return pcq_fail(PCQ_ERR_HIP, "staging allocation failed: %s", hipGetErrorString(e));
     ctx->stage_bytes = bytes;
     return PCQ_OK;
 }
@@ -651,7 +713,7 @@ static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 static int fetch(pcq_ctx *ctx, int fd, uint8_t *dst, const uint8_t *src, size_t bytes) {
     if (!ctx->copy_pool || ctx->copy_pool->helpers() != ctx->copy_threads - 1) {
         delete ctx->copy_pool;
-        ctx->copy_pool = new CopyPool(ctx->copy_threads - 1);
+        ctx->copy_pool = new CopyPool(ctx->copy_threads - 1, ctx->numa_local && ctx->numa_node >= 0 ? &ctx->node_cpus : nullptr);
     }
     const int r = ctx->copy_pool->run(fd, dst, src, bytes);
     if (r < 0) return pcq_fail(PCQ_ERR_IO, "pread failed: %s", strerror(-r));

@@ -1,6 +1,7 @@
 // pcq_internal.h — shared declarations of libpcq.so (not part of the public ABI; see include/pcq.h).
 #pragma once
 
+#include <sched.h>
 #include "copy_pool.h"
 #include <hip/hip_runtime.h>
 
@@ -145,6 +146,9 @@ struct pcq_ctx {
     int batch_waves_per_cu = 5;   // for batch_variant 1, 2: 5 x 9 KiB in flight per CU measured best and flat up to 8 (profiles/r01_k1_one_wave_blocks.log)
     int class_batch_loads = 4;        // batched K2: 0 = 256-thread kernel; 4 / 6 / 8 / 12 = one-wave workgroups with that many 1 KiB loads per step
     int class_batch_waves_per_cu = 8; // 8 x 4 KiB measured best (profiles/r01_k2_sweep.log)
+    int numa_node = -1;               // NUMA node the GPU hangs off (sysfs), -1 if unknown
+    cpu_set_t node_cpus;              // its CPUs (empty if unknown)
+    int numa_local = 1;               // option "numa_local": staging buffers and copy helpers on that node
     int copy_threads = 4;         // threads filling a staging buffer (caller + helpers); tools/host_path_rate.py
     CopyPool *copy_pool = nullptr;  // created on first use by pcq_scan_host / pcq_scan_fd
     uint64_t chunk_points = 2ull << 20;    // 24 MB of positions per staging chunk (profiles/r01_host_path_rate.json: 1-8 Mi equal)

@@ -27,9 +27,11 @@ with pkg.Context(0) as ctx, tempfile.TemporaryDirectory(dir="/tmp") as d:
     cols = binding.make_columns(xyz=256, n=n, scale=list(spec.scale), offset=list(spec.offset))
     pred = pkg.Predicate.bounds(lmin, lmax)
     out = {}
-    for threads, chunk in ((1, 2 << 20), (2, 2 << 20), (4, 2 << 20), (6, 2 << 20), (8, 2 << 20), (12, 2 << 20), (16, 2 << 20), (8, 8 << 20), (16, 8 << 20)):
+    print("GPU on NUMA node", ctx.get_option("numa_node"), flush=True)
+    for numa, threads, chunk in [(nl, t, 2 << 20) for t in (1, 2, 4, 8) for nl in (0, 1, 0, 1)]:
         ctx.set_option("chunk_points", chunk)
         ctx.set_option("copy_threads", threads)
+        ctx.set_option("numa_local", numa)
         times = []
         for _ in range(5):
             cc = ctx.count_collector()
@@ -41,7 +43,7 @@ with pkg.Context(0) as ctx, tempfile.TemporaryDirectory(dir="/tmp") as d:
         times = sorted(times[1:])
         med = times[len(times) // 2]
         assert cnt == n
-        out[f"threads_{threads}_chunk_{chunk}"] = {"seconds": med, "gb_per_s": 12 * n / med / 1e9}
-        print(f"copy threads {threads:2d}, chunk {chunk >> 20} Mi points: {12 * n / med / 1e9:6.1f} GB/s ({med * 1e3:.1f} ms)", flush=True)
+        out.setdefault(f"threads_{threads}_numa_local_{numa}", []).append(12 * n / med / 1e9)
+        print(f"copy threads {threads:2d}, staging + helpers on the GPU's node: {'yes' if numa else 'no '}  {12 * n / med / 1e9:6.1f} GB/s ({med * 1e3:.1f} ms)", flush=True)
     os.close(fd)
     print(json.dumps({"points": n, "path": "page cache -> parallel pread -> pinned staging -> hipMemcpyAsync -> K1", **out}))
