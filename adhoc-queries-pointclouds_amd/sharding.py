@@ -9,13 +9,27 @@ grids and per-file output files).
 """
 from __future__ import annotations
 
-from typing import List
+from typing import List, Optional, Sequence
 
 
-def assign_files(nfiles: int, world: int, rank: int) -> List[int]:
-    """Round-robin file -> rank map (all synthetic files have equal point counts; with unequal files
-    sort by header point count first — longest-processing-time order — then deal round-robin)."""
-    return [i for i in range(nfiles) if i % world == rank]
+def assign_files(nfiles: int, world: int, rank: int, points: Optional[Sequence[int]] = None) -> List[int]:
+    """The files of `rank`.  Without sizes: round-robin, file i -> rank i % world.  With the per-file point
+    counts from the headers (files skipped by the header-AABB early-out count as 0): greedy
+    longest-processing-time — files in descending size, each to the rank with the least points so far,
+    ties to the lowest rank — which is the same round-robin when all files are equal.  Deterministic, so
+    every rank computes the same map without talking to the others."""
+    if points is None:
+        return [i for i in range(nfiles) if i % world == rank]
+    if len(points) != nfiles:
+        raise ValueError("one point count per file")
+    load = [0] * world
+    mine: List[int] = []
+    for i in sorted(range(nfiles), key=lambda k: (-int(points[k]), k)):
+        r = min(range(world), key=lambda w: (load[w], w))
+        load[r] += int(points[i])
+        if r == rank:
+            mine.append(i)
+    return sorted(mine)
 
 
 def global_count(local_count, world: int):

@@ -125,7 +125,7 @@ def main():
     sharding = importlib.import_module("adhoc-queries-pointclouds_amd.sharding")
 
     all_specs = specs_mod.synth_ca13(points_per_file=args.points_per_file, files=args.files)
-    mine = sharding.assign_files(len(all_specs), world, rank)  # file i -> rank i % N
+    mine = sharding.assign_files(len(all_specs), world, rank, points=[int(s.n) for s in all_specs])  # LPT; equal files: i -> rank i % N
     bmin, bmax = specs_mod.box(args.query)
 
     tstream = torch.cuda.Stream(device=dev)

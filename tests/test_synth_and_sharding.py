@@ -78,6 +78,23 @@ def test_assign_files_round_robin():
     assert got == list(range(10))
 
 
+def test_assign_files_longest_processing_time():
+    """greedy LPT by header point count; equal files reduce to round-robin; every rank derives the
+    same partition on its own."""
+    eq = [163_000_000] * 16
+    for w in (1, 2, 4, 8):
+        for r in range(w):
+            assert sharding.assign_files(16, w, r, points=eq) == sharding.assign_files(16, w, r)
+    pts = [900, 100, 100, 100, 400, 400, 0, 0, 250, 50]
+    parts = [sharding.assign_files(len(pts), 3, r, points=pts) for r in range(3)]
+    assert sorted(i for p in parts for i in p) == list(range(len(pts)))
+    loads = [sum(pts[i] for i in p) for p in parts]
+    assert loads == [900, 700, 700]  # 900 | 400+250+50 (+ the empty files) | 400+100+100+100
+    assert max(loads) - min(loads) <= max(pts)
+    with pytest.raises(ValueError):
+        sharding.assign_files(3, 2, 0, points=[1, 2])
+
+
 def _worker(rank, world, port, per_file, out_q):
     import torch
     import torch.distributed as dist
