@@ -200,3 +200,74 @@ def test_config4_ca13_density_full_size(oracle, gpu_ctx, ca13):
     for f in ("x", "y", "z"):
         assert np.array_equal(got[f], want[f])
     og.free()
+
+
+def test_single_block_beyond_2_pow_32_points(gpu_ctx):
+    """Index arithmetic at 64 bits: ONE positions block of 4.4 G points (52.8 GB; the largest LAS 1.2 point count
+    is 2^32 - 1, LAS 1.4 goes beyond) through every count kernel.  Sized for the 288 GB of one MI355X."""
+    n = (1 << 32) + 100_000_123
+    spec = specs.synth_ca13(points_per_file=n, files=16)[5]
+    r = Resident(gpu_ctx, spec, want_cls=True)
+    try:
+        h = r.h
+        bmin, bmax = specs.box("ca13_XL")
+        lmin, lmax = pkg.box_to_local(bmin, bmax, h["scale"], h["offset"])
+        assert count_bounds(gpu_ctx, r, lmin, lmax) == n                       # the default one-wave kernel
+        assert count_bounds(gpu_ctx, r, lmin, lmax, variant=0) == n            # the 256-thread kernel
+        # a thin slab: x partition of the file's own extent (three disjoint pieces sum to n), per kernel family
+        x0, x1 = lmin[0], lmax[0]
+        lo, hi = int(h["min"][0] / h["scale"][0]), int(h["max"][0] / h["scale"][0])
+        cut1, cut2 = lo + (hi - lo) // 3, lo + 2 * (hi - lo) // 3
+        parts = [(x0, cut1), (cut1 + 1, cut2), (cut2 + 1, x1)]
+        got = [count_bounds(gpu_ctx, r, [a, lmin[1], lmin[2]], [b, lmax[1], lmax[2]]) for a, b in parts]
+        assert sum(got) == n and all(g > 0 for g in got)
+        total = gpu_ctx.alloc(16)
+        for bv in (0, 2):
+            gpu_ctx.set_option("batch_variant", bv)
+            gpu_ctx.memset(total, 0, 16)
+            gpu_ctx.scan_dev_count_batch([r.cols()] * 3, [pkg.Predicate.bounds([a, lmin[1], lmin[2]], [b, lmax[1], lmax[2]]) for a, b in parts], total)
+            host = np.zeros(1, dtype=np.uint64)
+            gpu_ctx.to_host(host, total)
+            assert int(host[0]) == n, bv
+        gpu_ctx.set_option("batch_variant", 2)
+        # the strided (generic) kernel: the same block addressed 4 bytes later with the last point dropped
+        shifted = binding.make_columns(xyz=r.xyz + 12, n=n - 1, scale=h["scale"], offset=h["offset"])
+        cc = gpu_ctx.count_collector()
+        gpu_ctx.scan_dev(shifted, pkg.Predicate.bounds(lmin, lmax), cc)
+        assert cc.point_count() == n - 1
+        cc.free()
+        # class histogram sums to n, per-file and batched kernels agree
+        per_class = {}
+        for c in (1, 2, 5, 6, 7, 9, 19):
+            cc = gpu_ctx.count_collector()
+            gpu_ctx.scan_dev(r.cols(), pkg.Predicate.classification(c), cc)
+            per_class[c] = cc.point_count()
+            cc.free()
+        assert sum(per_class.values()) == n and per_class[19] == 0
+        gpu_ctx.memset(total, 0, 16)
+        gpu_ctx.scan_dev_count_batch([r.cols()] * 2, [pkg.Predicate.classification(6), pkg.Predicate.classification(2)], total)
+        host = np.zeros(1, dtype=np.uint64)
+        gpu_ctx.to_host(host, total)
+        assert int(host[0]) == per_class[6] + per_class[2]
+        gpu_ctx.free(total)
+        # collectors that carry records: a very thin slab in the LAST quarter of the block (indices above 2^32)
+        tail_first = n - 40_000_000
+        tail = r.cols(first=tail_first)
+        thin = pkg.Predicate.bounds([cut1, lmin[1], lmin[2]], [cut1 + 300, lmax[1], lmax[2]])
+        cc, bc = gpu_ctx.count_collector(), gpu_ctx.buffer_collector()
+        gpu_ctx.scan_dev(tail, thin, cc)
+        gpu_ctx.scan_dev(tail, thin, bc)
+        pts = bc.points()
+        assert len(pts) == cc.point_count() > 0
+        xs = np.rint(pts["x"] / h["scale"][0]).astype(np.int64)
+        assert xs.min() >= cut1 and xs.max() <= cut1 + 300
+        gbox = ([cut1 * h["scale"][0], h["min"][1], h["min"][2]], [(cut1 + 300) * h["scale"][0], h["max"][1], h["max"][2]])
+        gc = gpu_ctx.grid_collector(gbox[0], gbox[1], 50.0)
+        gpu_ctx.scan_dev(tail, thin, gc)
+        cells = gc.point_count()
+        gp = gc.points()
+        assert 0 < cells <= len(pts) and len(gp) == cells
+        assert set(map(bytes, gp.view(np.uint8).reshape(-1, 31))) <= set(map(bytes, pts.view(np.uint8).reshape(-1, 31)))  # winners are matches
+        cc.free(), bc.free(), gc.free()
+    finally:
+        r.free()
