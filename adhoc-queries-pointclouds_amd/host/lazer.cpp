@@ -151,39 +151,78 @@ namespace {
 // Host copies of inflated columns, in the LAST layout.
 struct Columns {
     std::unique_ptr<uint8_t[]> xyz, cls, rgb;  // new[] without value-initialisation: first touched by the inflating threads
+    uint64_t cap = 0;
+    bool cap_colors = false;
+    // grow-only: a searcher thread keeps its buffers from file to file, so only the first (largest) file pays
+    // for the page faults of a few hundred MB and nothing is handed back to the kernel between files
     void alloc(uint64_t n, bool colors) {
-        xyz.reset(new uint8_t[n * 12]);
-        cls.reset(new uint8_t[n]);
-        if (colors) rgb.reset(new uint8_t[n * 6]);
+        if (n <= cap && (!colors || cap_colors)) return;
+        xyz.reset();
+        cls.reset();
+        rgb.reset();
+        const uint64_t want = n > cap ? n : cap;
+        xyz.reset(new uint8_t[want * 12]);
+        cls.reset(new uint8_t[want]);
+        cap_colors = colors || cap_colors;
+        if (cap_colors) rgb.reset(new uint8_t[want * 6]);
+        cap = want;
     }
 };
+Columns &thread_columns() {
+    static thread_local Columns c;
+    return c;
+}
 
-// Inflates blocks [first, last) on a few threads; `sink` receives each block's column slices.  The
-// error reported is the one of the lowest failing block, as a sequential reader would hit it.
+// Inflates blocks [first, last) on a few threads.  The unit of work is one column blob (positions 12 B,
+// classification 1 B, colour 6 B per point), largest first, so that a handful of blocks still spreads evenly
+// over the threads.  The error reported is the first one a sequential reader would hit: block by block —
+// its tables (:136-175), then positions, classifications, colours (:590-716).
 Status inflate_blocks(const LazerFile &lz, size_t first, size_t last, Columns *cols) {
     const size_t nb = last - first;
     if (nb == 0) return Status::Ok();
     const uint64_t base = (uint64_t)first * lz.block_size;
-    std::vector<Status> results(nb);
+    struct Task {
+        Blob blob;
+        uint64_t need;
+        size_t unit;
+        uint8_t *dst;
+        size_t order;  // position in the sequential reader's order
+    };
+    std::vector<Task> tasks;
+    Status walk_end = Status::Ok();
+    for (size_t b = first; b < last; b++) {
+        BlockBlobs bl;
+        Status st = lz.locate(b, &bl);
+        if (!st.ok()) {
+            walk_end = st;
+            break;
+        }
+        const uint64_t at = (uint64_t)b * lz.block_size - base, count = lz.points_in_block(b);
+        tasks.push_back({bl.positions, count * 12, 4, cols->xyz.get() + at * 12, tasks.size()});
+        tasks.push_back({bl.classifications, count, 1, cols->cls.get() + at, tasks.size()});
+        if (lz.has_colors) tasks.push_back({bl.colors, count * 6, 2, cols->rgb.get() + at * 6, tasks.size()});
+    }
+    std::vector<Status> results(tasks.size());
+    std::vector<size_t> by_size(tasks.size());
+    for (size_t i = 0; i < tasks.size(); i++) by_size[i] = i;
+    std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return tasks[x].need > tasks[y].need; });
     std::atomic<size_t> next{0};
     auto work = [&]() {
         for (;;) {
             const size_t k = next.fetch_add(1);
-            if (k >= nb) return;
-            const size_t b = first + k;
-            const uint64_t at = (uint64_t)b * lz.block_size - base;
-            results[k] = lz.inflate(b, lz.points_in_block(b), cols->xyz.get() + at * 12, cols->cls.get() + at,
-                                    lz.has_colors ? cols->rgb.get() + at * 6 : nullptr);
+            if (k >= by_size.size()) return;
+            const Task &t = tasks[by_size[k]];
+            results[t.order] = lz4_frame_decode_into(t.blob.p, t.blob.n, (size_t)t.need, t.unit, t.dst);
         }
     };
-    const size_t nthreads = std::min<size_t>({nb, 16, std::max(1u, std::thread::hardware_concurrency())});
+    const size_t nthreads = std::min<size_t>({tasks.size(), 16, std::max(1u, std::thread::hardware_concurrency())});
     std::vector<std::thread> pool;
     for (size_t t = 1; t < nthreads; t++) pool.emplace_back(work);
     work();
     for (auto &t : pool) t.join();
     for (auto &r : results)
         if (!r.ok()) return r;
-    return Status::Ok();
+    return walk_end;
 }
 
 // A header may claim far more points than the file can hold (LZ4 expands at most 255x).  The reference
@@ -347,7 +386,7 @@ Status search_lazer_file_by_bounds(const std::string &path, const AABB &bounds, 
     int r;
     if (inflate_on_host()) {
         const double t0 = now_ms();
-        Columns c;
+        Columns &c = thread_columns();
         c.alloc(n, lz.has_colors);
         st = inflate_blocks(lz, 0, lz.num_blocks, &c);
         if (!st.ok()) return st;
@@ -388,16 +427,10 @@ Status search_lazer_file_by_classification(const std::string &path, uint8_t cls,
     pcq_ctx *ctx = rc.context();
     DeviceColumns dc;
     if (inflate_on_host()) {
-        Columns c0;  // block 0
-        c0.alloc(n0, lz.has_colors);
-        st = inflate_blocks(lz, 0, 1, &c0);
+        Columns &c0 = thread_columns();  // every block is inflated by read_into (:101); only block 0, at the front, is looked at
+        c0.alloc(n, lz.has_colors);
+        st = inflate_blocks(lz, 0, lz.num_blocks, &c0);
         if (!st.ok()) return st;
-        if (lz.num_blocks > 1) {  // the other blocks: inflated by read_into (:101), their points never looked at
-            Columns rest;
-            rest.alloc(n - n0, lz.has_colors);
-            st = inflate_blocks(lz, 1, lz.num_blocks, &rest);
-            if (!st.ok()) return st;
-        }
         dc.ctx = ctx;
         int r = pcq_device_alloc(ctx, n0 * 12, &dc.xyz);
         if (!r) r = pcq_device_alloc(ctx, n0, &dc.cls);
