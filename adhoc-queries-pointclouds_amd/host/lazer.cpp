@@ -16,6 +16,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <new>
+#include <sys/mman.h>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -149,8 +151,29 @@ Status lazer_file_bounds(const std::string &path, AABB *out) {  // main.rs:102-1
 namespace {
 
 // Host copies of inflated columns, in the LAST layout.
+// Anonymous memory asking for transparent huge pages: a few hundred MB of inflate buffer are first touched by the
+// inflating threads, and 4 KiB faults (plus the munmap at the end) were measured to cost more than the inflate.
+struct HugeBuffer {
+    uint8_t *p = nullptr;
+    size_t bytes = 0;
+    ~HugeBuffer() { reset(); }
+    void reset(size_t n = 0) {
+        if (p) munmap(p, bytes);
+        p = nullptr;
+        bytes = 0;
+        if (!n) return;
+        const size_t len = (n + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+        void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (m == MAP_FAILED) throw std::bad_alloc();
+        (void)madvise(m, len, MADV_HUGEPAGE);
+        p = (uint8_t *)m;
+        bytes = len;
+    }
+    uint8_t *get() const { return p; }
+};
+
 struct Columns {
-    std::unique_ptr<uint8_t[]> xyz, cls, rgb;  // new[] without value-initialisation: first touched by the inflating threads
+    HugeBuffer xyz, cls, rgb;
     uint64_t cap = 0;
     bool cap_colors = false;
     // grow-only: a searcher thread keeps its buffers from file to file, so only the first (largest) file pays
@@ -161,10 +184,10 @@ struct Columns {
         cls.reset();
         rgb.reset();
         const uint64_t want = n > cap ? n : cap;
-        xyz.reset(new uint8_t[want * 12]);
-        cls.reset(new uint8_t[want]);
+        xyz.reset(want * 12);
+        cls.reset(want);
         cap_colors = colors || cap_colors;
-        if (cap_colors) rgb.reset(new uint8_t[want * 6]);
+        if (cap_colors) rgb.reset(want * 6);
         cap = want;
     }
 };
