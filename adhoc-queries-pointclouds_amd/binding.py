@@ -145,6 +145,7 @@ def load_library() -> C.CDLL:
         "pcq_scan_dev": (C.c_int, [vp, P(Columns), P(Predicate), vp, vp]),
         "pcq_scan_host": (C.c_int, [vp, P(Columns), P(Predicate), vp]),
         "pcq_scan_fd": (C.c_int, [vp, C.c_int, P(Columns), P(Predicate), vp]),
+        "pcq_scan_host_nowait": (C.c_int, [vp, P(Columns), P(Predicate), vp]),
         "pcq_scan_dev_count_batch": (C.c_int, [vp, P(Columns), P(Predicate), C.c_size_t, vp, vp]),
         "pcq_allreduce_sum_u64": (C.c_int, [P(vp), P(vp), C.c_int]),
         "pcq_index_new": (C.c_int, [vp, P(vp)]),
@@ -346,6 +347,10 @@ class Context:
 
     def scan_host(self, cols: Columns, pred: Predicate, coll: Collector) -> None:
         _check(self.lib.pcq_scan_host(self.handle, C.byref(cols), C.byref(pred), coll.handle))
+
+    def scan_host_nowait(self, cols: Columns, pred: Predicate, coll: Collector) -> None:
+        """scan_host that returns once the caller's columns have been read; results after synchronize() / accessors."""
+        _check(self.lib.pcq_scan_host_nowait(self.handle, C.byref(cols), C.byref(pred), coll.handle))
 
     def scan_fd(self, fd: int, cols: Columns, pred: Predicate, coll: Collector) -> None:
         """Like scan_host, with the column pointers given as byte offsets into the open file `fd`."""

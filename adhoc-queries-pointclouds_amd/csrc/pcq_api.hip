@@ -191,6 +191,7 @@ extern "C" int pcq_ctx_synchronize(pcq_ctx *ctx) {
     if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_ctx_synchronize: null context");
     PCQ_HIP(hipStreamSynchronize(ctx->stream));
     PCQ_HIP(hipStreamSynchronize(ctx->copy_stream));
+    ctx->stage_busy[0] = ctx->stage_busy[1] = false;
     return PCQ_OK;
 }
 
@@ -646,6 +647,7 @@ static int ensure_stage(pcq_ctx *ctx, size_t bytes) {
     if (ctx->stage_bytes >= bytes) return PCQ_OK;
     PCQ_HIP(hipStreamSynchronize(ctx->stream));
     PCQ_HIP(hipStreamSynchronize(ctx->copy_stream));
+    ctx->stage_busy[0] = ctx->stage_busy[1] = false;
     for (int i = 0; i < 2; i++) {
         if (ctx->h_stage[i]) PCQ_HIP(hipHostFree(ctx->h_stage[i]));
         if (ctx->d_stage[i]) PCQ_HIP(hipFree(ctx->d_stage[i]));
@@ -675,6 +677,10 @@ int pcq_stream_fd_to_device(pcq_ctx *ctx, int fd, uint64_t offset, uint64_t byte
     const size_t chunk = 32u << 20;
     int rc = ensure_stage(ctx, (bytes < chunk ? (size_t)bytes : chunk) + 64);
     if (rc) return rc;
+    if (ctx->stage_busy[0] || ctx->stage_busy[1]) {  // a nowait scan may still be reading the staging buffers
+        PCQ_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->stage_busy[0] = ctx->stage_busy[1] = false;
+    }
     hipStream_t cs = ctx->copy_stream;
     const uint64_t nchunks = (bytes + chunk - 1) / chunk;
     // events reused as "staging buffer b has been copied out"
@@ -721,7 +727,7 @@ static int fetch(pcq_ctx *ctx, int fd, uint8_t *dst, const uint8_t *src, size_t 
     return PCQ_OK;
 }
 
-static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
+static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c, bool wait) {
     if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_host: null context");
     int rc = validate_scan(cols, pred, c);
     if (rc) return rc;
@@ -786,7 +792,10 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
         const int b = (int)(k & 1);
         const uint64_t first = k * chunk;
         const uint64_t cnt = cols->n - first < chunk ? cols->n - first : chunk;
-        if (k >= 2) PCQ_HIP(hipEventSynchronize(ctx->consumed[b]));  // kernels of chunk k-2 are done with d_stage[b]
+        if (ctx->stage_busy[b]) {  // the kernels of the chunk that used staging pair b last (this call's or an earlier nowait call's) are done with it
+            PCQ_HIP(hipEventSynchronize(ctx->consumed[b]));
+            ctx->stage_busy[b] = false;
+        }
         uint8_t *h = ctx->h_stage[b];
         size_t bytes;
         if (pl.aos) {
@@ -814,6 +823,7 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
     auto fail = [&](int code) {
         (void)hipStreamSynchronize(cs);
         (void)hipStreamSynchronize(s);
+        ctx->stage_busy[0] = ctx->stage_busy[1] = false;
         return code;
     };
     rc = stage(0);
@@ -843,16 +853,24 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
         rc = scan_dev_impl(ctx, &dcols, pred, c, s);
         if (rc) return fail(rc);
         PCQ_HIP(hipEventRecord(ctx->consumed[b], s));
+        ctx->stage_busy[b] = true;
     }
-    PCQ_HIP(hipStreamSynchronize(s));
+    if (wait) {
+        PCQ_HIP(hipStreamSynchronize(s));
+        ctx->stage_busy[0] = ctx->stage_busy[1] = false;
+    }
     return PCQ_OK;
 }
 
 extern "C" int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
-    return scan_host_impl(ctx, -1, cols, pred, c);
+    return scan_host_impl(ctx, -1, cols, pred, c, true);
+}
+
+extern "C" int pcq_scan_host_nowait(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
+    return scan_host_impl(ctx, -1, cols, pred, c, false);
 }
 
 extern "C" int pcq_scan_fd(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
     if (fd < 0) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_fd: bad file descriptor");
-    return scan_host_impl(ctx, fd, cols, pred, c);
+    return scan_host_impl(ctx, fd, cols, pred, c, true);
 }

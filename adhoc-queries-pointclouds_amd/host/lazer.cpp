@@ -13,6 +13,9 @@
 // which have exactly the LAST layout.  No per-point work happens here.
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -158,7 +161,13 @@ struct HugeBuffer {
     size_t bytes = 0;
     ~HugeBuffer() { reset(); }
     void reset(size_t n = 0) {
-        if (p) munmap(p, bytes);
+        if (p) {
+            const auto t0 = std::chrono::steady_clock::now();
+            munmap(p, bytes);
+            if (getenv("PCQ_TIMING"))
+                fprintf(stderr, "[pcq] released %.0f MB of inflate buffer in %.1f ms\n", (double)bytes / 1e6,
+                        std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
         p = nullptr;
         bytes = 0;
         if (!n) return;
@@ -196,56 +205,86 @@ Columns &thread_columns() {
     return c;
 }
 
-// Inflates blocks [first, last) on a few threads.  The unit of work is one column blob (positions 12 B,
-// classification 1 B, colour 6 B per point), largest first, so that a handful of blocks still spreads evenly
-// over the threads.  The error reported is the first one a sequential reader would hit: block by block —
-// its tables (:136-175), then positions, classifications, colours (:590-716).
-Status inflate_blocks(const LazerFile &lz, size_t first, size_t last, Columns *cols) {
-    const size_t nb = last - first;
-    if (nb == 0) return Status::Ok();
-    const uint64_t base = (uint64_t)first * lz.block_size;
-    struct Task {
-        Blob blob;
-        uint64_t need;
-        size_t unit;
-        uint8_t *dst;
-        size_t order;  // position in the sequential reader's order
-    };
-    std::vector<Task> tasks;
-    Status walk_end = Status::Ok();
-    for (size_t b = first; b < last; b++) {
-        BlockBlobs bl;
-        Status st = lz.locate(b, &bl);
-        if (!st.ok()) {
-            walk_end = st;
-            break;
-        }
-        const uint64_t at = (uint64_t)b * lz.block_size - base, count = lz.points_in_block(b);
-        tasks.push_back({bl.positions, count * 12, 4, cols->xyz.get() + at * 12, tasks.size()});
-        tasks.push_back({bl.classifications, count, 1, cols->cls.get() + at, tasks.size()});
-        if (lz.has_colors) tasks.push_back({bl.colors, count * 6, 2, cols->rgb.get() + at * 6, tasks.size()});
-    }
-    std::vector<Status> results(tasks.size());
-    std::vector<size_t> by_size(tasks.size());
-    for (size_t i = 0; i < tasks.size(); i++) by_size[i] = i;
-    std::stable_sort(by_size.begin(), by_size.end(), [&](size_t x, size_t y) { return tasks[x].need > tasks[y].need; });
-    std::atomic<size_t> next{0};
-    auto work = [&]() {
+// Blocks are inflated by worker threads into a ring of block-sized slots (one contiguous
+// arena, so that consecutive finished blocks form one run) and handed to `consume` IN BLOCK ORDER on the calling
+// thread — the thread that owns the GPU context — while later blocks are still being inflated.  The ring bounds
+// the memory (and with it the page faults and the munmap) to a few blocks instead of the whole file.
+// consume(first_block, xyz, cls, rgb, points): the columns of a run of whole blocks starting at first_block.
+using ConsumeFn = std::function<Status(size_t, const uint8_t *, const uint8_t *, const uint8_t *, uint64_t)>;
+
+Status inflate_stream(const LazerFile &lz, const ConsumeFn &consume) {
+    const size_t nb = (size_t)lz.num_blocks;
+    const uint64_t n = lz.header.number_of_points;
+    const uint64_t slot_points = std::min<uint64_t>(lz.block_size, n);
+    const size_t nthreads = std::min<size_t>({nb, 16, std::max(1u, std::thread::hardware_concurrency())});
+    size_t slots = std::min<size_t>(nb, nthreads + 4);
+    const uint64_t budget = 1536ull << 20;  // bytes of ring: enough for 16 threads on 1 M-point blocks with room to spare
+    if ((uint64_t)slots * slot_points * 19 > budget) slots = (size_t)std::max<uint64_t>(1, budget / (slot_points * 19));
+    Columns &c = thread_columns();
+    c.alloc((uint64_t)slots * slot_points, lz.has_colors);
+
+    std::mutex m;
+    std::condition_variable cv_work, cv_done;
+    std::vector<char> done(nb, 0);
+    std::vector<Status> results(nb);
+    size_t next = 0, consumed = 0;
+    bool abort = false;
+    auto worker = [&]() {
         for (;;) {
-            const size_t k = next.fetch_add(1);
-            if (k >= by_size.size()) return;
-            const Task &t = tasks[by_size[k]];
-            results[t.order] = lz4_frame_decode_into(t.blob.p, t.blob.n, (size_t)t.need, t.unit, t.dst);
+            size_t b;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return abort || next >= nb || next < consumed + slots; });
+                if (abort || next >= nb) return;
+                b = next++;
+            }
+            const uint64_t at = (uint64_t)(b % slots) * slot_points;
+            Status st = lz.inflate(b, lz.points_in_block(b), c.xyz.get() + at * 12, c.cls.get() + at, lz.has_colors ? c.rgb.get() + at * 6 : nullptr);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                results[b] = std::move(st);
+                done[b] = 1;
+            }
+            cv_done.notify_one();
         }
     };
-    const size_t nthreads = std::min<size_t>({tasks.size(), 16, std::max(1u, std::thread::hardware_concurrency())});
     std::vector<std::thread> pool;
-    for (size_t t = 1; t < nthreads; t++) pool.emplace_back(work);
-    work();
-    for (auto &t : pool) t.join();
-    for (auto &r : results)
-        if (!r.ok()) return r;
-    return walk_end;
+    for (size_t t = 0; t < nthreads; t++) pool.emplace_back(worker);
+    auto stop = [&]() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            abort = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : pool) t.join();
+    };
+    Status out = Status::Ok();
+    for (size_t b = 0; b < nb && out.ok();) {
+        size_t e;
+        {
+            std::unique_lock<std::mutex> lk(m);
+            cv_done.wait(lk, [&] { return done[b] != 0; });
+            if (!results[b].ok()) {
+                out = results[b];
+                break;
+            }
+            // the run of finished, intact blocks behind b that is contiguous in the ring
+            e = b + 1;
+            while (e < nb && e % slots != 0 && done[e] && results[e].ok()) e++;
+        }
+        uint64_t points = 0;
+        for (size_t k = b; k < e; k++) points += lz.points_in_block(k);
+        const uint64_t at = (uint64_t)(b % slots) * slot_points;
+        out = consume(b, c.xyz.get() + at * 12, c.cls.get() + at, lz.has_colors ? c.rgb.get() + at * 6 : nullptr, points);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            consumed = e;
+        }
+        cv_work.notify_all();
+        b = e;
+    }
+    stop();
+    return out;
 }
 
 // A header may claim far more points than the file can hold (LZ4 expands at most 255x).  The reference
@@ -258,18 +297,6 @@ Status impossible_point_count(const LazerFile &lz) {
         if (!st.ok()) return st;
     }
     return Status::Panic("capacity overflow");
-}
-
-void fill_columns(const LazerFile &lz, const Columns &c, uint64_t n, pcq_columns *cols) {
-    *cols = pcq_columns{};
-    cols->xyz = c.xyz.get();
-    cols->xyz_stride = 12;
-    cols->cls = c.cls.get();
-    cols->cls_stride = 1;
-    cols->rgb = lz.has_colors ? c.rgb.get() : nullptr;  // no colour decoder: the record's colour stays 0 (:683-685)
-    cols->rgb_stride = 6;
-    cols->n = n;
-    for (int a = 0; a < 3; a++) cols->scale[a] = lz.header.scale[a], cols->offset[a] = lz.header.offset[a];  // :602-609
 }
 
 }  // namespace
@@ -409,17 +436,32 @@ Status search_lazer_file_by_bounds(const std::string &path, const AABB &bounds, 
     int r;
     if (inflate_on_host()) {
         const double t0 = now_ms();
-        Columns &c = thread_columns();
-        c.alloc(n, lz.has_colors);
-        st = inflate_blocks(lz, 0, lz.num_blocks, &c);
+        double scan_ms = 0;
+        const uint64_t first_index = rc.next_index;
+        st = inflate_stream(lz, [&](size_t b, const uint8_t *xyz, const uint8_t *cls, const uint8_t *rgb, uint64_t points) -> Status {
+            const double ts = now_ms();
+            pcq_columns run{};
+            run.xyz = xyz;
+            run.xyz_stride = 12;
+            run.cls = cls;
+            run.cls_stride = 1;
+            run.rgb = rgb;  // null without a colour decoder: the record's colour stays 0 (:683-685)
+            run.rgb_stride = 6;
+            run.n = points;
+            run.first_index = first_index + (uint64_t)b * lz.block_size;
+            for (int a = 0; a < 3; a++) run.scale[a] = lz.header.scale[a], run.offset[a] = lz.header.offset[a];  // :602-609
+            // the slot is free again as soon as its bytes sit in the staging buffers; transfer and kernels of this run
+            // overlap the staging copy of the next one
+            const int rr = pcq_scan_host_nowait(rc.context(), &run, &pred, rc.handle());
+            scan_ms += now_ms() - ts;
+            return Status::FromLib(rr);
+        });
+        const int sr = pcq_ctx_synchronize(rc.context());
         if (!st.ok()) return st;
-        const double t1 = now_ms();
-        fill_columns(lz, c, n, &cols);
-        cols.first_index = rc.next_index;
-        r = pcq_scan_host(rc.context(), &cols, &pred, rc.handle());
+        r = sr;
         if (getenv("PCQ_TIMING"))
-            fprintf(stderr, "[pcq] lazer host inflate: %.1f ms (%zu blocks), scan from host columns %.1f ms\n", t1 - t0, (size_t)lz.num_blocks,
-                    now_ms() - t1);
+            fprintf(stderr, "[pcq] lazer: %zu blocks inflated and scanned in %.1f ms (scans from host columns: %.1f ms of it)\n",
+                    (size_t)lz.num_blocks, now_ms() - t0, scan_ms);
     } else {
         DeviceColumns dc;
         st = inflate_on_device(lz, rc.context(), &dc);
@@ -443,25 +485,27 @@ Status search_lazer_file_by_classification(const std::string &path, uint8_t cls,
     LazerFile lz;
     Status st = lazer_open(path, &lz);  // :85-87
     if (!st.ok()) return st;
-    const uint64_t n = lz.header.number_of_points, n0 = lz.points_in_block(0);
+    const uint64_t n0 = lz.points_in_block(0);
     st = impossible_point_count(lz);
     if (!st.ok()) return st;
 
     pcq_ctx *ctx = rc.context();
     DeviceColumns dc;
     if (inflate_on_host()) {
-        Columns &c0 = thread_columns();  // every block is inflated by read_into (:101); only block 0, at the front, is looked at
-        c0.alloc(n, lz.has_colors);
-        st = inflate_blocks(lz, 0, lz.num_blocks, &c0);
-        if (!st.ok()) return st;
+        // every block is inflated by read_into (:101); only block 0 is ever looked at: it goes to the device as soon
+        // as it is there, the rest is inflated for the errors it may raise
         dc.ctx = ctx;
-        int r = pcq_device_alloc(ctx, n0 * 12, &dc.xyz);
-        if (!r) r = pcq_device_alloc(ctx, n0, &dc.cls);
-        if (!r && lz.has_colors) r = pcq_device_alloc(ctx, n0 * 6, &dc.rgb);
-        if (!r) r = pcq_copy_to_device(ctx, dc.xyz, c0.xyz.get(), n0 * 12);
-        if (!r) r = pcq_copy_to_device(ctx, dc.cls, c0.cls.get(), n0);
-        if (!r && lz.has_colors) r = pcq_copy_to_device(ctx, dc.rgb, c0.rgb.get(), n0 * 6);
-        if (r) return Status::FromLib(r);
+        st = inflate_stream(lz, [&](size_t b, const uint8_t *xyz, const uint8_t *cls_col, const uint8_t *rgb, uint64_t) -> Status {
+            if (b != 0) return Status::Ok();
+            int r = pcq_device_alloc(ctx, n0 * 12, &dc.xyz);
+            if (!r) r = pcq_device_alloc(ctx, n0, &dc.cls);
+            if (!r && lz.has_colors) r = pcq_device_alloc(ctx, n0 * 6, &dc.rgb);
+            if (!r) r = pcq_copy_to_device(ctx, dc.xyz, xyz, n0 * 12);
+            if (!r) r = pcq_copy_to_device(ctx, dc.cls, cls_col, n0);
+            if (!r && lz.has_colors) r = pcq_copy_to_device(ctx, dc.rgb, rgb, n0 * 6);
+            return Status::FromLib(r);
+        });
+        if (!st.ok()) return st;
     } else {
         st = inflate_on_device(lz, ctx, &dc);  // all blocks (:101 reads every chunk); block 0 sits at the front
         if (!st.ok()) return st;

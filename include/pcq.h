@@ -184,6 +184,10 @@ int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pr
  * buffers, which avoids the page-table work of reading through a fresh mmap (last.rs:27-34). */
 int pcq_scan_fd(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predicate *pred,
                 pcq_collector *c);
+/* pcq_scan_host that returns as soon as the caller's memory has been read (copied into the staging buffers):
+ * the caller may overwrite its columns at once and issue the next scan, whose staging copy then overlaps this
+ * scan's transfer and kernels.  Results are complete after pcq_ctx_synchronize or any collector accessor. */
+int pcq_scan_host_nowait(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c);
 
 /* Count-only scan of many device-resident LAST files in ONE launch (files = independent units,
  * main.rs:153-161): segment i is scanned with preds[i] (all bounds, over 16-byte aligned positions

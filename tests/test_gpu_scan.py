@@ -316,3 +316,45 @@ def test_accessor_waits_for_scans_enqueued_on_a_caller_stream(oracle, gpu_ctx):
         gb.free()
     finally:
         f.free()
+
+
+def test_scan_host_nowait_lets_the_caller_reuse_its_buffer(oracle, gpu_ctx):
+    """pcq_scan_host_nowait returns once the caller's columns have been copied out: the SAME host buffer is
+    overwritten with the next block right away; counts and the ordered result buffer must still be exact."""
+    gpu_ctx.set_option("chunk_points", 4096)  # several staging chunks per call, so both staging pairs stay busy across calls
+    try:
+        blocks = []
+        for i, n in enumerate([10_000, 3, 70_001, 4096, 8192 + 5, 1, 50_000]):
+            spec = small_spec(900 + i, n, fmt=1)  # no colour column
+            image = oracle.synth_image(spec, transposed=True)
+            hdr = oracle.parse_header(image[:400].tobytes())
+            blocks.append((image, hdr))
+        bmin, bmax = BOXES[0]
+        nmax = max(h.number_of_points for _, h in blocks)
+        xyz = np.zeros(nmax * 12, dtype=np.uint8)
+        cls = np.zeros(nmax, dtype=np.uint8)
+        cc, bc = gpu_ctx.count_collector(), gpu_ctx.buffer_collector()
+        expect_pts, first = [], 0
+        for image, hdr in blocks:
+            n, otp = hdr.number_of_points, hdr.offset_to_point_data
+            lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+            pred = pkg.Predicate.bounds(lmin, lmax)
+            for coll in (cc, bc):
+                xyz[:12 * n] = image[otp:otp + 12 * n]  # overwrite the shared buffer: the previous call has let go of it
+                cls[:n] = image[otp + 15 * n: otp + 16 * n]
+                cols = binding.make_columns(xyz=xyz.ctypes.data, cls=cls.ctypes.data, n=n, first_index=first,
+                                            scale=list(hdr.scale), offset=list(hdr.offset))
+                gpu_ctx.scan_host_nowait(cols, pred, coll)
+                xyz[:12 * n] = 0xEE  # scribble at once
+            first += n
+            ob = oracle.buffer_collector()
+            assert oracle.search_last_bounds(image, bmin, bmax, ob) == 0
+            assert oracle.aabb_intersects(list(hdr.min), list(hdr.max), bmin, bmax)  # (the column scan has no header early-out)
+            expect_pts.append(ob.points())
+            ob.free()
+        want = np.concatenate(expect_pts)
+        assert cc.point_count() == len(want) > 0
+        assert bc.points().tobytes() == want.tobytes()
+        cc.free(), bc.free()
+    finally:
+        gpu_ctx.set_option("chunk_points", 2 << 20)
