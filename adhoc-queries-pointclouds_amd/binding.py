@@ -159,6 +159,7 @@ def load_library() -> C.CDLL:
         "pcq_device_memset": (C.c_int, [vp, vp, C.c_int, u64, vp]),
         "pcq_set_option": (C.c_int, [vp, C.c_char_p, i64]),
         "pcq_get_option": (C.c_int, [vp, C.c_char_p, P(i64)]),
+        "pcq_bind_thread_near_device": (C.c_int, [vp]),
         "pcq_lz4_inflate_dev": (C.c_int, [vp, P(Lz4Job), C.c_size_t, vp]),
         "pcq_read_fd_to_device": (C.c_int, [vp, C.c_int, u64, u64, vp]),
         "pcq_synth_fill_dev": (C.c_int, [vp, P(SynthSpec), u64, u64, vp, vp, vp]),

@@ -195,6 +195,12 @@ extern "C" int pcq_ctx_synchronize(pcq_ctx *ctx) {
     return PCQ_OK;
 }
 
+extern "C" int pcq_bind_thread_near_device(pcq_ctx *ctx) {
+    if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_bind_thread_near_device: null context");
+    if (ctx->numa_local && ctx->numa_node >= 0) (void)sched_setaffinity(0, sizeof ctx->node_cpus, &ctx->node_cpus);
+    return PCQ_OK;
+}
+
 extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return pcq_fail(PCQ_ERR_ARG, "pcq_set_option: null argument");
     if (!strcmp(key, "k1_variant")) {

@@ -212,7 +212,7 @@ Columns &thread_columns() {
 // consume(first_block, xyz, cls, rgb, points): the columns of a run of whole blocks starting at first_block.
 using ConsumeFn = std::function<Status(size_t, const uint8_t *, const uint8_t *, const uint8_t *, uint64_t)>;
 
-Status inflate_stream(const LazerFile &lz, const ConsumeFn &consume) {
+Status inflate_stream(const LazerFile &lz, pcq_ctx *ctx, const ConsumeFn &consume) {
     const size_t nb = (size_t)lz.num_blocks;
     const uint64_t n = lz.header.number_of_points;
     const uint64_t slot_points = std::min<uint64_t>(lz.block_size, n);
@@ -230,6 +230,7 @@ Status inflate_stream(const LazerFile &lz, const ConsumeFn &consume) {
     size_t next = 0, consumed = 0;
     bool abort = false;
     auto worker = [&]() {
+        (void)pcq_bind_thread_near_device(ctx);  // the ring is first touched here and read by the staging copy next to the GPU
         for (;;) {
             size_t b;
             {
@@ -438,7 +439,7 @@ Status search_lazer_file_by_bounds(const std::string &path, const AABB &bounds, 
         const double t0 = now_ms();
         double scan_ms = 0;
         const uint64_t first_index = rc.next_index;
-        st = inflate_stream(lz, [&](size_t b, const uint8_t *xyz, const uint8_t *cls, const uint8_t *rgb, uint64_t points) -> Status {
+        st = inflate_stream(lz, rc.context(), [&](size_t b, const uint8_t *xyz, const uint8_t *cls, const uint8_t *rgb, uint64_t points) -> Status {
             const double ts = now_ms();
             pcq_columns run{};
             run.xyz = xyz;
@@ -495,7 +496,7 @@ Status search_lazer_file_by_classification(const std::string &path, uint8_t cls,
         // every block is inflated by read_into (:101); only block 0 is ever looked at: it goes to the device as soon
         // as it is there, the rest is inflated for the errors it may raise
         dc.ctx = ctx;
-        st = inflate_stream(lz, [&](size_t b, const uint8_t *xyz, const uint8_t *cls_col, const uint8_t *rgb, uint64_t) -> Status {
+        st = inflate_stream(lz, ctx, [&](size_t b, const uint8_t *xyz, const uint8_t *cls_col, const uint8_t *rgb, uint64_t) -> Status {
             if (b != 0) return Status::Ok();
             int r = pcq_device_alloc(ctx, n0 * 12, &dc.xyz);
             if (!r) r = pcq_device_alloc(ctx, n0, &dc.cls);

@@ -256,6 +256,11 @@ int pcq_lz4_inflate_dev(pcq_ctx *ctx, pcq_lz4_job *jobs, size_t njobs, void *str
  * block path (pinned double buffering, parallel pread).  Synchronous. */
 int pcq_read_fd_to_device(pcq_ctx *ctx, int fd, uint64_t file_offset, uint64_t bytes, void *d_dst);
 
+/* Restricts the CALLING thread to the CPUs of the NUMA node the context's GPU is attached to (no-op when the
+ * node is unknown or option "numa_local" is 0).  For caller threads that produce the bytes a scan will read —
+ * memory they touch first then sits next to the GPU's staging buffers. */
+int pcq_bind_thread_near_device(pcq_ctx *ctx);
+
 /* Tuning knobs: "k1_variant" (bounds-count kernel variant 0..11), "k1_waves_per_cu", "batch_variant" (0..2),
  * "batch_waves_per_cu", "blocks_per_cu" (the 256-thread kernels), "chunk_points" (points per staging chunk of
  * the host paths), "copy_threads" (threads filling a staging chunk, default 4). */
