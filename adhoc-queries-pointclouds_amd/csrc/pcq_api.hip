@@ -365,6 +365,7 @@ int pcq_make_dev_pred(const pcq_predicate *p, DevPred *out) {
 static int new_collector(pcq_ctx *ctx, int kind, pcq_collector **out) {
     if (!ctx || !out) return pcq_fail(PCQ_ERR_ARG, "collector: null argument");
     *out = nullptr;
+    PCQ_HIP(hipSetDevice(ctx->device));  // the collector's memory belongs to the context's device, whatever the thread used before
     pcq_collector *c = new (std::nothrow) pcq_collector();
     if (!c) return pcq_fail(PCQ_ERR_NOMEM, "collector: out of memory");
     c->kind = kind;
@@ -451,7 +452,11 @@ extern "C" int pcq_collector_new_grid(pcq_ctx *ctx, const double bmin[3], const 
 
 extern "C" int pcq_collector_free(pcq_collector *c) {
     if (!c) return PCQ_OK;
-    if (c->ctx) (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->ctx) {
+        (void)hipSetDevice(c->ctx->device);
+        (void)hipStreamSynchronize(c->ctx->stream);
+        if (c->last_stream && c->last_stream != c->ctx->stream) (void)hipStreamSynchronize(c->last_stream);  // scans enqueued on a caller's stream
+    }
     if (c->owns_count && c->d_count) (void)hipFree(c->d_count);
     if (c->d_points) (void)hipFree(c->d_points);
     if (c->kind == COLL_GRID) pcq_grid_release(c);
