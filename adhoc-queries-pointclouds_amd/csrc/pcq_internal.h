@@ -150,7 +150,8 @@ struct pcq_ctx {
     int numa_node = -1;               // NUMA node the GPU hangs off (sysfs), -1 if unknown
     cpu_set_t node_cpus;              // its CPUs (empty if unknown)
     int numa_local = 1;               // option "numa_local": staging buffers and copy helpers on that node
-    int copy_threads = 4;         // threads filling a staging buffer (caller + helpers); tools/host_path_rate.py
+    int copy_threads = 8;         // threads filling a staging buffer (caller + helpers): 2-4 reach the PCIe rate from memory next to the
+                                  // GPU, page-cache pages on the other socket need 8 (profiles/r01_cli_probe_timing.log)
     CopyPool *copy_pool = nullptr;  // created on first use by pcq_scan_host / pcq_scan_fd
     uint64_t chunk_points = 2ull << 20;    // 24 MB of positions per staging chunk (profiles/r01_host_path_rate.json: 1-8 Mi equal)
 };

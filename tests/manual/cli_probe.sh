@@ -12,9 +12,12 @@ o = _oracle.Oracle()
 for i, s in enumerate(specs.synth_ca13(points_per_file=20_000_000, files=16)):
     o.synth_write(s, os.path.join(sys.argv[1], f"tile{i:02d}.last"), threads=32)
 PY
+sync  # let the write-back of the freshly generated files finish: the queries are meant to read files at rest
 XL="643431.76;3883547.565;-46194.145;736910.93;3977026.735;47285.025"
-for T in 2 4; do
-  echo "== threads-per-gpu $T"
-  time env PCQ_TIMING=1 "$ROOT/adhoc-queries-pointclouds_amd/host/query" -i "$D" --bounds "$XL" --optimized --parallel --threads-per-gpu $T 2>&1 | tail -30
+for C in 4 8 12 16; do
+  for N in 1 0; do
+    echo "== copy threads $C, numa_local $N (one host thread per GPU)"
+    env PCQ_TIMING=1 PCQ_COPY_THREADS=$C PCQ_NUMA_LOCAL=$N "$ROOT/adhoc-queries-pointclouds_amd/host/query" -i "$D" --bounds "$XL" --optimized --parallel 2>&1 | grep -E "searched in|total in-process" | awk '{ if ($2=="file") {s+=$6; n++; if ($6>m) m=$6} else print "  files: mean " s/n " ms, max " m " ms;", $0 }'
+  done
 done
 rm -rf "$D"
