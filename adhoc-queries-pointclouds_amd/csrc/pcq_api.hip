@@ -121,11 +121,19 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
     }
     if (const char *e = getenv("PCQ_BATCH_VARIANT")) {
         const int v = atoi(e);
-        if (v >= 0 && v <= 2) ctx->batch_variant = v;
+        if (v >= 0 && v <= 3) ctx->batch_variant = v;
+    }
+    if (const char *e = getenv("PCQ_BATCH_WAVES_PER_CU")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 32) ctx->batch_waves_per_cu = v;
+    }
+    if (const char *e = getenv("PCQ_K1_WAVES_PER_CU")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 32) ctx->k1_waves_per_cu = v;
     }
     if (const char *e = getenv("PCQ_K1_VARIANT")) {
         const int v = atoi(e);
-        if (v >= 0 && v <= 11) ctx->k1_variant = v;
+        if (v >= 0 && v <= 14) ctx->k1_variant = v;
     }
     *out_ctx = ctx;
     return PCQ_OK;
@@ -204,7 +212,7 @@ extern "C" int pcq_bind_thread_near_device(pcq_ctx *ctx) {
 extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     if (!ctx || !key) return pcq_fail(PCQ_ERR_ARG, "pcq_set_option: null argument");
     if (!strcmp(key, "k1_variant")) {
-        if (value < 0 || value > 11) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..11");
+        if (value < 0 || value > 14) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..14");
         ctx->k1_variant = (int)value;
     } else if (!strcmp(key, "blocks_per_cu")) {
         if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "blocks_per_cu must be 1..32");
@@ -220,7 +228,7 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
         if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "k1_waves_per_cu must be 1..32");
         ctx->k1_waves_per_cu = (int)value;
     } else if (!strcmp(key, "batch_variant")) {
-        if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "batch_variant must be 0..2");
+        if (value < 0 || value > 3) return pcq_fail(PCQ_ERR_ARG, "batch_variant must be 0..3");
         ctx->batch_variant = (int)value;
     } else if (!strcmp(key, "batch_waves_per_cu")) {
         if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "batch_waves_per_cu must be 1..32");

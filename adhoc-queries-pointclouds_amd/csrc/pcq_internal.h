@@ -139,12 +139,13 @@ struct pcq_ctx {
     // measured to stall for seconds (profiles/r01_grid_timeline.txt)
     DevGridTable grid_cache = {};
     // options
-    int k1_variant = 9;           // per-file K1: one wave per workgroup, two adjacent 3 KiB tiles per step (profiles/r01_k1_one_wave_blocks.log)
-    int k1_waves_per_cu = 8;      // workgroups (= waves) per CU for the one-wave variants 8..11
+    int k1_variant = 12;          // per-file K1: one wave per workgroup, two adjacent 3 KiB tiles per step, software-pipelined (profiles/r01_k1_one_wave_blocks.log)
+    int k1_waves_per_cu = 3;      // workgroups (= waves) per CU for the one-wave variants 8..14: 3 for the pipelined 12 (6-12 KiB outstanding per wave), 8 for 9
     int grid_blocks_per_cu = 2;   // persistent blocks per CU of the streaming count kernels: 8 waves x 3 KiB in flight per CU measured best (profiles/r01_k1_variant_sweep_interleaved.log)
     int batch_blocks_per_cu = 3;  // the batched K1 measured best at 3 (same log)
-    int batch_variant = 2;        // batched K1: 0 = 256-thread blocks, one tile per wave step; 1 / 2 = one wave per workgroup, 2 / 3 tiles per step
-    int batch_waves_per_cu = 5;   // for batch_variant 1, 2: 5 x 9 KiB in flight per CU measured best and flat up to 8 (profiles/r01_k1_one_wave_blocks.log)
+    int batch_variant = 3;        // batched K1: 0 = 256-thread blocks, one tile per wave step; 1 / 2 = one wave per workgroup, 2 / 3 tiles per step;
+                                  // 3 = one wave per workgroup, 2 tiles per step, software-pipelined
+    int batch_waves_per_cu = 3;   // 3 for batch_variant 3 (7.07 TB/s in the bench); variant 2 is flat from 5 to 8 (6.93-7.03) (profiles/r01_k1_one_wave_blocks.log)
     int class_batch_loads = 4;        // batched K2: 0 = 256-thread kernel; 4 / 6 / 8 / 12 = one-wave workgroups with that many 1 KiB loads per step
     int class_batch_waves_per_cu = 8; // 8 x 4 KiB measured best (profiles/r01_k2_sweep.log)
     int numa_node = -1;               // NUMA node the GPU hangs off (sysfs), -1 if unknown

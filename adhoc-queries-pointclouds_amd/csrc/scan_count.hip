@@ -369,6 +369,83 @@ __global__ __launch_bounds__(BLOCK) void k_bounds_count_batch(const DevSegment *
     block_store_partial(total, partials);
 }
 
+// Variants 12..14: one wave per workgroup, TILES adjacent tiles per step (12: 2, 13: 1, 14: 3), software-pipelined
+// with inline-asm loads and counted waits (as variant 7): the loads of step i+1 are in flight while step i is
+// evaluated, so a wave never has fewer than TILES x 3 KiB outstanding.  asm volatile statements keep their order;
+// the empty asm behind each s_waitcnt re-defines the registers it guards, so no use can be hoisted above the wait.
+template <int TILES>
+struct PipeRegs {
+    v4i r[TILES][3];
+};
+template <int TILES>
+__device__ __forceinline__ void pipe_load(PipeRegs<TILES> &R, const v4i *base, uint64_t step, int lane) {
+#pragma unroll
+    for (int t = 0; t < TILES; t++) {
+        const v4i *q = base + (step * TILES + t) * 192 + lane;
+        asm volatile("global_load_dwordx4 %0, %3, off nt\n\tglobal_load_dwordx4 %1, %3, off offset:1024 nt\n\t"
+                     "global_load_dwordx4 %2, %3, off offset:2048 nt"
+                     : "=&v"(R.r[t][0]), "=&v"(R.r[t][1]), "=&v"(R.r[t][2])
+                     : "v"(q)
+                     : "memory");
+    }
+}
+template <int TILES, int PENDING>
+__device__ __forceinline__ void pipe_wait(PipeRegs<TILES> &R) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory");
+#pragma unroll
+    for (int t = 0; t < TILES; t++) asm volatile("" : "+v"(R.r[t][0]), "+v"(R.r[t][1]), "+v"(R.r[t][2])::"memory");
+}
+template <int TILES>
+__device__ __forceinline__ uint64_t pipe_eval(const PipeRegs<TILES> &R, const LaneBox &lb) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int t = 0; t < TILES; t++) c += tile_count_regs(R.r[t], lb);
+    return c;
+}
+
+template <int TILES>
+__global__ __launch_bounds__(64) void k_bounds_count_w1_pipe(const v4i *__restrict__ base, uint64_t n, DevPred pred,
+                                                             uint64_t *__restrict__ partials) {
+    const int lane = threadIdx.x;
+    const uint64_t tiles = n / TILE_POINTS, steps = tiles / TILES, stride = gridDim.x;
+    const LaneBox lb = rotate_box(pred.lo, pred.width, lane);
+    uint64_t total = 0;
+    if (blockIdx.x < steps) {
+        PipeRegs<TILES> A, B;
+        uint64_t g = blockIdx.x;
+        pipe_load<TILES>(A, base, g, lane);
+        for (;;) {
+            const uint64_t g1 = g + stride;
+            pipe_load<TILES>(B, base, g1 < steps ? g1 : g, lane);  // clamped at the tail: a re-read that hits L2
+            pipe_wait<TILES, 3 * TILES>(A);                       // A has landed, B's loads stay in flight
+            total += pipe_eval<TILES>(A, lb);
+            if (g1 >= steps) break;
+            const uint64_t g2 = g1 + stride;
+            pipe_load<TILES>(A, base, g2 < steps ? g2 : g1, lane);
+            pipe_wait<TILES, 3 * TILES>(B);
+            total += pipe_eval<TILES>(B, lb);
+            if (g2 >= steps) break;
+            g = g2;
+        }
+        pipe_wait<TILES, 0>(A);  // the clamped tail prefetch is still in flight: land it before the registers die
+        pipe_wait<TILES, 0>(B);
+    }
+    if (blockIdx.x == 0) {
+        for (uint64_t t = steps * TILES; t < tiles; t++) total += tile_count_masks(base + t * 192, lane, lb);
+        for (int k = 0; k < 4; k++) {
+            const uint64_t p = tiles * TILE_POINTS + (uint64_t)(64 * k + lane);
+            bool pass = false;
+            if (p < n) {
+                const int *q = reinterpret_cast<const int *>(base) + 3 * p;
+                pass = ((uint32_t)(q[0] - pred.lo[0]) <= pred.width[0]) & ((uint32_t)(q[1] - pred.lo[1]) <= pred.width[1]) &
+                       ((uint32_t)(q[2] - pred.lo[2]) <= pred.width[2]);
+            }
+            total += (uint64_t)__popcll(__ballot(pass));
+        }
+    }
+    if (lane == 0) partials[blockIdx.x] = total;
+}
+
 // Batched K1 with one wave per workgroup and TILES adjacent tiles per step (the shape variants 8..11
 // measure on one file).  Here `tile_begin` of the segment table counts steps (TILES * 256 points), and the
 // fewer-than-a-step leftover of segment i is handled point by point by block i % gridDim.x.
@@ -403,6 +480,88 @@ __global__ __launch_bounds__(64) void k_bounds_count_batch_w1(const DevSegment *
         for (int t = 0; t < TILES; t++) total += tile_count_regs(v[t], lb);
     }
     for (int i = blockIdx.x; i < nseg; i += gridDim.x) {
+        if (segs[i].empty) continue;
+        const uint64_t n = segs[i].n;
+        const int *q0 = reinterpret_cast<const int *>(segs[i].xyz);
+        for (uint64_t p = (n / STEP_POINTS) * STEP_POINTS + lane; p < ((n + 63) & ~63ull); p += 64) {
+            bool pass = false;
+            if (p < n) {
+                const int *q = q0 + 3 * p;
+                pass = ((uint32_t)(q[0] - segs[i].lo[0]) <= segs[i].width[0]) &
+                       ((uint32_t)(q[1] - segs[i].lo[1]) <= segs[i].width[1]) &
+                       ((uint32_t)(q[2] - segs[i].lo[2]) <= segs[i].width[2]);
+            }
+            total += (uint64_t)__popcll(__ballot(pass));
+        }
+    }
+    if (lane == 0) partials[blockIdx.x] = total;
+}
+
+// Batched K1, one wave per workgroup, TILES tiles per step, software-pipelined like variants 12..14: while the
+// tiles of step u are evaluated the loads of step u + stride are in flight.  Steps are numbered across all
+// segments (tile_begin counts steps); each of the two register sets remembers the segment its step came from.
+struct SegCursor {
+    int s;
+    uint64_t begin, end;
+    const v4i *base;
+    LaneBox lb;
+    bool empty;
+};
+template <int TILES>
+__device__ __forceinline__ void seg_seek(SegCursor &c, const DevSegment *__restrict__ segs, int nseg, uint64_t u, int lane) {
+    if (u < c.end) return;
+    while (c.s + 1 < nseg && u >= segs[c.s + 1].tile_begin) c.s++;
+    c.begin = segs[c.s].tile_begin;
+    c.end = c.begin + segs[c.s].n / ((uint64_t)TILES * TILE_POINTS);
+    c.base = reinterpret_cast<const v4i *>(segs[c.s].xyz);
+    c.empty = segs[c.s].empty != 0;
+    // the box through SGPRs: left to itself the compiler turns "select of table entries" into a per-lane address and
+    // a VECTOR load, and the s_waitcnt vmcnt(0) behind that load would drain the prefetched tiles
+    int32_t lo[3];
+    uint32_t w[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        lo[k] = segs[c.s].lo[k];
+        w[k] = segs[c.s].width[k];
+        asm volatile("" : "+s"(lo[k]), "+s"(w[k]));
+    }
+    c.lb = rotate_box(lo, w, lane);
+}
+
+template <int TILES>
+__global__ __launch_bounds__(64) void k_bounds_count_batch_pipe(const DevSegment *__restrict__ segs, int nseg,
+                                                               uint64_t total_steps, uint64_t *__restrict__ partials) {
+    constexpr uint64_t STEP_POINTS = (uint64_t)TILES * TILE_POINTS;
+    const int lane = threadIdx.x;
+    const uint64_t stride = gridDim.x;
+    uint64_t total = 0;
+    if (blockIdx.x < total_steps) {
+        PipeRegs<TILES> A, B;
+        SegCursor ca = {0, 0, 0, nullptr, {}, true}, cb;
+        uint64_t u = blockIdx.x;
+        seg_seek<TILES>(ca, segs, nseg, u, lane);
+        pipe_load<TILES>(A, ca.base, u - ca.begin, lane);
+        for (;;) {
+            const uint64_t u1 = u + stride;
+            cb = ca;
+            if (u1 < total_steps) seg_seek<TILES>(cb, segs, nseg, u1, lane);
+            pipe_load<TILES>(B, cb.base, (u1 < total_steps ? u1 : u) - cb.begin, lane);  // clamped at the tail: an L2 hit
+            pipe_wait<TILES, 3 * TILES>(A);
+            if (!ca.empty) total += pipe_eval<TILES>(A, ca.lb);
+            if (u1 >= total_steps) break;
+            const uint64_t u2 = u1 + stride;
+            ca = cb;
+            if (u2 < total_steps) seg_seek<TILES>(ca, segs, nseg, u2, lane);
+            pipe_load<TILES>(A, ca.base, (u2 < total_steps ? u2 : u1) - ca.begin, lane);
+            pipe_wait<TILES, 3 * TILES>(B);
+            if (!cb.empty) total += pipe_eval<TILES>(B, cb.lb);
+            if (u2 >= total_steps) break;
+            u = u2;
+        }
+        pipe_wait<TILES, 0>(A);
+        pipe_wait<TILES, 0>(B);
+    }
+    for (int i = blockIdx.x; i < nseg; i += gridDim.x) {  // fewer-than-a-step leftovers of segment i
         if (segs[i].empty) continue;
         const uint64_t n = segs[i].n;
         const int *q0 = reinterpret_cast<const int *>(segs[i].xyz);
@@ -611,6 +770,20 @@ int pcq_launch_bounds_count_xyz12(pcq_ctx *ctx, const void *d_xyz, uint64_t n, c
     int rc = pcq_ensure_partials(ctx, (size_t)grid);
     if (rc) return rc;
     const v4i *base = reinterpret_cast<const v4i *>(d_xyz);
+    if (ctx->k1_variant >= 12 && ctx->k1_variant <= 14) {  // one wave per workgroup, software-pipelined; 12: 2 tiles per step, 13: 1, 14: 3
+        const int tps = ctx->k1_variant == 12 ? 2 : (ctx->k1_variant == 13 ? 1 : 3);
+        const uint64_t units = n / ((uint64_t)tps * TILE_POINTS) + 1;
+        uint64_t g = (uint64_t)ctx->num_cus * ctx->k1_waves_per_cu;
+        if (g > units) g = units;
+        rc = pcq_ensure_partials(ctx, (size_t)g);
+        if (rc) return rc;
+        if (tps == 1) hipLaunchKernelGGL(k_bounds_count_w1_pipe<1>, dim3((unsigned)g), dim3(64), 0, s, base, n, pred, ctx->d_partials);
+        else if (tps == 2) hipLaunchKernelGGL(k_bounds_count_w1_pipe<2>, dim3((unsigned)g), dim3(64), 0, s, base, n, pred, ctx->d_partials);
+        else hipLaunchKernelGGL(k_bounds_count_w1_pipe<3>, dim3((unsigned)g), dim3(64), 0, s, base, n, pred, ctx->d_partials);
+        hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, (int)g, d_count);
+        PCQ_HIP(hipGetLastError());
+        return PCQ_OK;
+    }
     if (ctx->k1_variant >= 8 && ctx->k1_variant <= 11) {  // one wave per workgroup, TILES tiles per step
         const int tiles_per_step = ctx->k1_variant - 7;
         const uint64_t units = n / ((uint64_t)tiles_per_step * TILE_POINTS) + 1;
@@ -659,6 +832,10 @@ int pcq_launch_class_count_u8(pcq_ctx *ctx, const void *d_cls, uint64_t n, uint8
     PCQ_HIP(hipGetLastError());
     return PCQ_OK;
 }
+
+// batch_variant: 0 = 256-thread blocks (1 tile per wave step) · 1, 2 = one-wave workgroups with 2, 3 tiles per step ·
+// 3 = one-wave workgroups, 2 tiles per step, software-pipelined
+static int batch_tiles_per_step(int v) { return v == 0 ? 1 : (v == 2 ? 3 : 2); }
 
 extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *preds,
                                         size_t nsegments, uint64_t *device_total, void *stream) {
@@ -716,7 +893,7 @@ extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, c
         g.tile_begin = tiles;
         for (int a = 0; a < 3; a++) g.lo[a] = dp.lo[a], g.width[a] = dp.width[a];
         g.empty = dp.empty;
-        tiles += cols[i].n / ((uint64_t)(ctx->batch_variant ? ctx->batch_variant + 1 : 1) * TILE_POINTS);
+        tiles += cols[i].n / ((uint64_t)batch_tiles_per_step(ctx->batch_variant) * TILE_POINTS);
         points += cols[i].n;
     }
     if (ctx->segments_uploaded != nsegments || ctx->segments_kind != kind ||
@@ -758,7 +935,10 @@ extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, c
         if (g > tiles + nsegments) g = tiles + nsegments;
         int wrc = pcq_ensure_partials(ctx, (size_t)g);
         if (wrc) return wrc;
-        if (ctx->batch_variant == 1)
+        if (ctx->batch_variant == 3)
+            hipLaunchKernelGGL(k_bounds_count_batch_pipe<2>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles,
+                               ctx->d_partials);
+        else if (ctx->batch_variant == 1)
             hipLaunchKernelGGL(k_bounds_count_batch_w1<2>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles,
                                ctx->d_partials);
         else

@@ -261,7 +261,7 @@ int pcq_read_fd_to_device(pcq_ctx *ctx, int fd, uint64_t file_offset, uint64_t b
  * memory they touch first then sits next to the GPU's staging buffers. */
 int pcq_bind_thread_near_device(pcq_ctx *ctx);
 
-/* Tuning knobs: "k1_variant" (bounds-count kernel variant 0..11), "k1_waves_per_cu", "batch_variant" (0..2),
+/* Tuning knobs: "k1_variant" (bounds-count kernel variant 0..14), "k1_waves_per_cu", "batch_variant" (0..3),
  * "batch_waves_per_cu", "blocks_per_cu" (the 256-thread kernels), "chunk_points" (points per staging chunk of
  * the host paths), "copy_threads" (threads filling a staging chunk, default 8). */
 int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value);

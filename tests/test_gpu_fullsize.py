@@ -47,7 +47,7 @@ def count_bounds(ctx, r, lmin, lmax, variant=None):
     n = cc.point_count()
     cc.free()
     if variant is not None:
-        ctx.set_option("k1_variant", 9)  # the default (csrc/pcq_internal.h)
+        ctx.set_option("k1_variant", 12)  # the default (csrc/pcq_internal.h)
     return n
 
 
@@ -222,14 +222,14 @@ def test_single_block_beyond_2_pow_32_points(gpu_ctx):
         got = [count_bounds(gpu_ctx, r, [a, lmin[1], lmin[2]], [b, lmax[1], lmax[2]]) for a, b in parts]
         assert sum(got) == n and all(g > 0 for g in got)
         total = gpu_ctx.alloc(16)
-        for bv in (0, 2):
+        for bv in (0, 2, 3):
             gpu_ctx.set_option("batch_variant", bv)
             gpu_ctx.memset(total, 0, 16)
             gpu_ctx.scan_dev_count_batch([r.cols()] * 3, [pkg.Predicate.bounds([a, lmin[1], lmin[2]], [b, lmax[1], lmax[2]]) for a, b in parts], total)
             host = np.zeros(1, dtype=np.uint64)
             gpu_ctx.to_host(host, total)
             assert int(host[0]) == n, bv
-        gpu_ctx.set_option("batch_variant", 2)
+        gpu_ctx.set_option("batch_variant", 3)  # the default
         # the strided (generic) kernel: the same block addressed 4 bytes later with the last point dropped
         shifted = binding.make_columns(xyz=r.xyz + 12, n=n - 1, scale=h["scale"], offset=h["offset"])
         cc = gpu_ctx.count_collector()

@@ -56,11 +56,11 @@ BOXES = [
 ]
 
 
-K1_DEFAULT, BATCH_DEFAULT = 9, 2  # csrc/pcq_internal.h
+K1_DEFAULT, BATCH_DEFAULT = 12, 3  # csrc/pcq_internal.h
 
 
 @pytest.mark.parametrize("n", [0, 1, 3, 255, 256, 257, 511, 512, 513, 1000, 4099, 100_003, 1_000_003])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
 def test_bounds_count_dev_matches_oracle(oracle, gpu_ctx, n, variant):
     spec = small_spec(1234 + n, n)
     image = oracle.synth_image(spec, transposed=True)
@@ -135,7 +135,7 @@ def test_count_collector_accumulates_and_external_counter(oracle, gpu_ctx):
         f.free()
 
 
-@pytest.mark.parametrize("batch_variant", [0, 1, 2])
+@pytest.mark.parametrize("batch_variant", [0, 1, 2, 3])
 def test_count_batch_matches_sum_of_files(oracle, gpu_ctx, batch_variant):
     files, cols, preds, expect = [], [], [], 0
     bmin, bmax = (-20.0, -30.0, -3.0), (15.0, 45.0, 4.0)

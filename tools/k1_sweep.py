@@ -60,7 +60,7 @@ def main():
         pc = pkg.Predicate.classification(6)
         cpreds = [pc] * args.files
         variants = [int(v) for v in args.variants.split(",")]
-        configs = [(bpc, v) for bpc in [int(b) for b in args.blocks.split(",")] for v in variants + ["batch", "batchw1", "batchw1x3", "class", "cbatch"]]
+        configs = [(bpc, v) for bpc in [int(b) for b in args.blocks.split(",")] for v in variants + ["batch", "batchw1", "batchw1x3", "batchpipe", "class", "cbatch"]]
         times = {c: [] for c in configs}
         k = 0
         for r in range(args.rounds + 2):  # interleaved rounds in one process (cdna guide rule 24)
@@ -69,10 +69,10 @@ def main():
                 ctx.set_option("k1_waves_per_cu", bpc)  # variants 8..11: single-wave workgroups per CU
                 ctx.set_option("k1_variant", variant if isinstance(variant, int) else 0)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                ctx.set_option("batch_variant", {"batchw1": 1, "batchw1x3": 2}.get(variant, 0))
-                if variant in ("batchw1", "batchw1x3"):  # one wave per workgroup, 2 / 3 tiles per step; blocks/cu = waves per CU here
+                ctx.set_option("batch_variant", {"batchw1": 1, "batchw1x3": 2, "batchpipe": 3}.get(variant, 0))
+                if variant in ("batchw1", "batchw1x3", "batchpipe"):  # one wave per workgroup, 2 / 3 tiles per step; blocks/cu = waves per CU here
                     ctx.set_option("batch_waves_per_cu", bpc)
-                if variant in ("batch", "batchw1", "batchw1x3"):
+                if variant in ("batch", "batchw1", "batchw1x3", "batchpipe"):
                     e0.record()
                     ctx.scan_dev_count_batch(cols, preds, counter.data_ptr(), stream)
                     e1.record()
@@ -92,7 +92,7 @@ def main():
         for (bpc, variant), t in times.items():
             t.sort()
             med = t[len(t) // 2]
-            nbytes = n * (1 if variant in ("class", "cbatch") else 12) * (args.files if variant in ("batch", "batchw1", "batchw1x3", "cbatch") else 1)
+            nbytes = n * (1 if variant in ("class", "cbatch") else 12) * (args.files if variant in ("batch", "batchw1", "batchw1x3", "batchpipe", "cbatch") else 1)
             print(f"blocks/cu={bpc:2d} variant={variant!s:9} median {med:8.4f} ms  min {t[0]:8.4f} ms  "
                   f"{nbytes / med / 1e6:9.1f} GB/s (min-time: {nbytes / t[0] / 1e6:9.1f})", flush=True)
         print("count check:", int(counter[0].item()))
