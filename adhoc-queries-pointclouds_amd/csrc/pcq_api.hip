@@ -221,6 +221,8 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "class_batch_loads")) {
         if (value != 0 && value != 4 && value != 6 && value != 8 && value != 12) return pcq_fail(PCQ_ERR_ARG, "class_batch_loads must be 0, 4, 6, 8 or 12");
         ctx->class_batch_loads = (int)value;
+    } else if (!strcmp(key, "class_batch_pipe")) {
+        ctx->class_batch_pipe = value != 0;
     } else if (!strcmp(key, "class_batch_waves_per_cu")) {
         if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "class_batch_waves_per_cu must be 1..32");
         ctx->class_batch_waves_per_cu = (int)value;

@@ -147,7 +147,8 @@ struct pcq_ctx {
                                   // 3 = one wave per workgroup, 2 tiles per step, software-pipelined
     int batch_waves_per_cu = 3;   // 3 for batch_variant 3 (7.07 TB/s in the bench); variant 2 is flat from 5 to 8 (6.93-7.03) (profiles/r01_k1_one_wave_blocks.log)
     int class_batch_loads = 4;        // batched K2: 0 = 256-thread kernel; 4 / 6 / 8 / 12 = one-wave workgroups with that many 1 KiB loads per step
-    int class_batch_waves_per_cu = 8; // 8 x 4 KiB measured best (profiles/r01_k2_sweep.log)
+    int class_batch_waves_per_cu = 4; // pipelined: 4 waves x 4-8 KiB outstanding measured best, 7.15 TB/s; not pipelined: 8 x 4 KiB, 7.0 (profiles/r01_k2_sweep.log)
+    int class_batch_pipe = 1;         // 1: the software-pipelined form of the one-wave batched K2
     int numa_node = -1;               // NUMA node the GPU hangs off (sysfs), -1 if unknown
     cpu_set_t node_cpus;              // its CPUs (empty if unknown)
     int numa_local = 1;               // option "numa_local": staging buffers and copy helpers on that node

@@ -739,6 +739,106 @@ __global__ __launch_bounds__(64) void k_class_count_batch_w1(const DevSegment *_
     if (lane == 0) partials[blockIdx.x] = w;
 }
 
+// Batched K2, one wave per workgroup, LOADS 1 KiB loads per step, software-pipelined like k_bounds_count_batch_pipe.
+template <int LOADS>
+struct ClassRegs {
+    v4i r[LOADS];
+};
+template <int LOADS>
+__device__ __forceinline__ void class_load(ClassRegs<LOADS> &R, const v4i *tile, int lane) {
+#pragma unroll
+    for (int k = 0; k < LOADS; k++) {
+        const v4i *q = tile + 64 * k + lane;
+        asm volatile("global_load_dwordx4 %0, %1, off nt" : "=&v"(R.r[k]) : "v"(q) : "memory");
+    }
+}
+template <int LOADS, int PENDING>
+__device__ __forceinline__ void class_wait(ClassRegs<LOADS> &R) {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PENDING) : "memory");
+#pragma unroll
+    for (int k = 0; k < LOADS; k++) asm volatile("" : "+v"(R.r[k])::"memory");
+}
+template <int LOADS>
+__device__ __forceinline__ uint32_t class_eval(const ClassRegs<LOADS> &R, uint32_t pat) {
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < LOADS; k++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) c += __popc(zero_bytes((uint32_t)R.r[k][j] ^ pat));
+    return c;
+}
+struct ClassCursor {
+    int s;
+    uint64_t begin, end;
+    const v4i *body;
+    uint32_t pat;
+};
+template <int LOADS>
+__device__ __forceinline__ void class_seek(ClassCursor &c, const DevSegment *__restrict__ raw, int nseg, uint64_t u) {
+    if (u < c.end) return;
+    while (c.s + 1 < nseg && u >= cseg(raw, c.s + 1).tile_begin) c.s++;
+    c.begin = cseg(raw, c.s).tile_begin;
+    c.end = c.begin + cseg(raw, c.s).nvec / (64ull * LOADS);
+    c.body = reinterpret_cast<const v4i *>(cseg(raw, c.s).cls + cseg(raw, c.s).head);
+    c.pat = cseg(raw, c.s).pat;
+}
+
+template <int LOADS>
+__global__ __launch_bounds__(64) void k_class_count_batch_pipe(const DevSegment *__restrict__ raw, int nseg, uint64_t total_steps,
+                                                              uint64_t *__restrict__ partials) {
+    constexpr uint64_t STEP_VEC = 64 * LOADS;
+    const int lane = threadIdx.x;
+    const uint64_t stride = gridDim.x;
+    uint32_t cnt = 0;
+    if (blockIdx.x < total_steps) {
+        ClassRegs<LOADS> A, B;
+        ClassCursor ca = {0, 0, 0, nullptr, 0}, cb;
+        uint64_t u = blockIdx.x;
+        class_seek<LOADS>(ca, raw, nseg, u);
+        class_load<LOADS>(A, ca.body + (u - ca.begin) * STEP_VEC, lane);
+        for (;;) {
+            const uint64_t u1 = u + stride;
+            cb = ca;
+            if (u1 < total_steps) class_seek<LOADS>(cb, raw, nseg, u1);
+            class_load<LOADS>(B, cb.body + ((u1 < total_steps ? u1 : u) - cb.begin) * STEP_VEC, lane);
+            class_wait<LOADS, LOADS>(A);
+            cnt += class_eval<LOADS>(A, ca.pat);
+            if (u1 >= total_steps) break;
+            const uint64_t u2 = u1 + stride;
+            ca = cb;
+            if (u2 < total_steps) class_seek<LOADS>(ca, raw, nseg, u2);
+            class_load<LOADS>(A, ca.body + ((u2 < total_steps ? u2 : u1) - ca.begin) * STEP_VEC, lane);
+            class_wait<LOADS, LOADS>(B);
+            cnt += class_eval<LOADS>(B, cb.pat);
+            if (u2 >= total_steps) break;
+            u = u2;
+        }
+        class_wait<LOADS, 0>(A);
+        class_wait<LOADS, 0>(B);
+    }
+    for (int i = blockIdx.x; i < nseg; i += gridDim.x) {
+        const DevClassSegment g = cseg(raw, i);
+        const uint8_t c8 = (uint8_t)(g.pat & 0xff);
+        const v4i *bd = reinterpret_cast<const v4i *>(g.cls + g.head);
+        for (uint64_t v = (g.nvec / STEP_VEC) * STEP_VEC + lane; v < g.nvec; v += 64) {
+            const v4i a = bd[v];
+#pragma unroll
+            for (int j = 0; j < 4; j++) cnt += __popc(zero_bytes((uint32_t)a[j] ^ g.pat));
+        }
+        if (lane < 16) {
+            const uint64_t p = lane;
+            if (p < g.head && g.cls[p] == c8) cnt++;
+        } else if (lane < 32) {
+            const uint64_t p = g.head + 16 * g.nvec + (lane - 16);
+            if (p < g.n && g.cls[p] == c8) cnt++;
+        }
+    }
+    uint64_t w = cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down((unsigned long long)w, off, 64);
+    if (lane == 0) partials[blockIdx.x] = w;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_finish_count(const uint64_t *__restrict__ partials, int nblocks,
                                                         uint64_t *__restrict__ d_count) {
     __shared__ uint64_t s[BLOCK];
@@ -909,6 +1009,17 @@ extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, c
         if (g > tiles + nsegments) g = tiles + nsegments;
         int crc = pcq_ensure_partials(ctx, (size_t)g);
         if (crc) return crc;
+        if (ctx->class_batch_pipe) {
+            switch (ctx->class_batch_loads) {
+            case 4: hipLaunchKernelGGL(k_class_count_batch_pipe<4>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles, ctx->d_partials); break;
+            case 6: hipLaunchKernelGGL(k_class_count_batch_pipe<6>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles, ctx->d_partials); break;
+            case 8: hipLaunchKernelGGL(k_class_count_batch_pipe<8>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles, ctx->d_partials); break;
+            default: hipLaunchKernelGGL(k_class_count_batch_pipe<12>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles, ctx->d_partials); break;
+            }
+            hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, (int)g, device_total);
+            PCQ_HIP(hipGetLastError());
+            return PCQ_OK;
+        }
         switch (ctx->class_batch_loads) {
         case 4: hipLaunchKernelGGL(k_class_count_batch_w1<4>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles, ctx->d_partials); break;
         case 6: hipLaunchKernelGGL(k_class_count_batch_w1<6>, dim3((unsigned)g), dim3(64), 0, s, ctx->d_segments, (int)nsegments, tiles, ctx->d_partials); break;

@@ -253,10 +253,12 @@ def test_allreduce_entry_point_single_rank(gpu_ctx):
     assert int(out[0]) == 12345678901234567
 
 
+@pytest.mark.parametrize("pipe", [0, 1])
 @pytest.mark.parametrize("loads", [0, 4, 6, 8, 12])
-def test_class_count_batch_matches_sum_of_files(oracle, gpu_ctx, loads):
+def test_class_count_batch_matches_sum_of_files(oracle, gpu_ctx, loads, pipe):
     files, cols, preds, expect = [], [], [], 0
     gpu_ctx.set_option("class_batch_loads", loads)
+    gpu_ctx.set_option("class_batch_pipe", pipe)
     try:
         for i, (n, pad) in enumerate([(100_003, 0), (0, 3), (15, 7), (4096 + 17, 1), (70_001, 13), (1_000_003, 5), (6143, 2), (6144 + 16, 9),
                                       (12_288 + 31, 4)]):
@@ -284,7 +286,8 @@ def test_class_count_batch_matches_sum_of_files(oracle, gpu_ctx, loads):
             gpu_ctx.scan_dev_count_batch(cols[:2], [preds[0], pkg.Predicate.bounds([0, 0, 0], [1, 1, 1])], total)
         gpu_ctx.free(total)
     finally:
-        gpu_ctx.set_option("class_batch_loads", 4)  # the default (csrc/pcq_internal.h)
+        gpu_ctx.set_option("class_batch_loads", 4)  # the defaults (csrc/pcq_internal.h)
+        gpu_ctx.set_option("class_batch_pipe", 1)
         for f in files:
             f.free()
 

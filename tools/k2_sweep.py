@@ -21,11 +21,13 @@ with pkg.Context(0) as ctx:
     torch.cuda.synchronize()
     preds = [pkg.Predicate.classification(6)] * files
     counter = torch.zeros(2, dtype=torch.int64, device=dev)
-    configs = [(0, b) for b in (2, 3, 4, 6)] + [(l, w) for l in (4, 6, 8, 12) for w in (4, 5, 6, 8, 10, 12, 16)]
+    configs = [(0, b, 0) for b in (2, 3, 4, 6)] + [(l, w, 0) for l in (4, 6, 8, 12) for w in (4, 5, 6, 8, 10, 12, 16)] + \
+              [(l, w, 1) for l in (4, 6, 8, 12) for w in (2, 3, 4, 5, 6, 8)]
     times = {c: [] for c in configs}
     for r in range(12):
-        for loads, w in configs:
+        for loads, w, pipe in configs:
             ctx.set_option("class_batch_loads", loads)
+            ctx.set_option("class_batch_pipe", pipe)
             if loads:
                 ctx.set_option("class_batch_waves_per_cu", w)
             else:
@@ -36,13 +38,13 @@ with pkg.Context(0) as ctx:
             ctx.scan_dev_count_batch(cols, preds, counter.data_ptr(), stream)
             e1.record(); e1.synchronize()
             if r >= 2:
-                times[(loads, w)].append(e0.elapsed_time(e1))
+                times[(loads, w, pipe)].append(e0.elapsed_time(e1))
         if r == 0:
             first = int(counter[0].item())
         assert int(counter[0].item()) == first
-    for (loads, w), t in times.items():
+    for (loads, w, pipe), t in times.items():
         t.sort()
         med = t[len(t) // 2]
-        what = f"one-wave workgroups, {loads:2d} KiB per step, {w:2d} waves/CU ({loads * w:3d} KiB in flight/CU)" if loads else f"256-thread kernel, blocks_per_cu option {w}"
+        what = f"one-wave workgroups{', pipelined' if pipe else ''}, {loads:2d} KiB per step, {w:2d} waves/CU ({loads * w:3d}{'+' if pipe else ''} KiB in flight/CU)" if loads else f"256-thread kernel, blocks_per_cu option {w}"
         print(f"{n * files / med / 1e6:8.1f} GB/s  median {med:.4f} ms  {what}", flush=True)
     print("count", first)
