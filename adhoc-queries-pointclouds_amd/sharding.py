@@ -32,10 +32,14 @@ def assign_files(nfiles: int, world: int, rank: int, points: Optional[Sequence[i
     return sorted(mine)
 
 
-def global_count(local_count, world: int):
+def global_count(local_count, world: int, async_op: bool = False):
     """Sum of the per-rank match counts, in place on `local_count` (a 1-element int64 tensor living
-    where the backend needs it: HBM for nccl/RCCL, host for gloo)."""
+    where the backend needs it: HBM for nccl/RCCL, host for gloo).  With async_op the collective is only
+    enqueued (it waits for the kernels that produce `local_count`, then runs on the backend's own stream, so
+    the next query's scan overlaps it); the returned work handle must be waited on before the value is read.
+    Returns `local_count` (async_op False) or the work handle / None (async_op True)."""
+    work = None
     if world > 1:
         import torch.distributed as dist
-        dist.all_reduce(local_count, op=dist.ReduceOp.SUM)
-    return local_count
+        work = dist.all_reduce(local_count, op=dist.ReduceOp.SUM, async_op=async_op)
+    return work if async_op else local_count

@@ -151,6 +151,8 @@ def main():
     local_points = sum(h["n"] for h in headers)
     global_points = sum(int(s.n) for s in all_specs)
 
+    pending = []  # all-reduces enqueued by streamed queries
+
     def query_step(slot, record=None, sync=True):
         """One `--bounds XL --optimized --parallel` count query over the dataset."""
         total = answers[slot]
@@ -182,7 +184,11 @@ def main():
                 if record is not None:
                     e1.record(tstream)
                     record.append((e0, e1, scanned))
-        sharding.global_count(total, world if not use_dist else max(world, 2))  # main.rs:164-180: one RCCL all-reduce
+        # main.rs:164-180: one RCCL all-reduce of the count.  In the streamed mode it is only enqueued: it runs on the
+        # communicator's stream behind this query's kernels while the next query's scan already occupies the GPU
+        work = sharding.global_count(total, world if not use_dist else max(world, 2), async_op=not sync)
+        if not sync and work is not None:
+            pending.append(work)
         return (int(total[0].item()) if sync else None), scanned
 
     def barrier():
@@ -194,11 +200,17 @@ def main():
     expected, _ = query_step(args.warmup + args.steps)  # the answer, read back once (untimed)
     for k in range(args.warmup):
         query_step(k, sync=args.sync_each_step)
+    for w in pending:
+        w.wait()
+    pending.clear()
     barrier()
     events = []
     t0 = time.perf_counter()
     for k in range(args.steps):
         _, scanned_local = query_step(args.warmup + k, events, sync=args.sync_each_step)
+    for w in pending:  # every all-reduce of the timed queries has completed before the clock stops
+        w.wait()
+    pending.clear()
     barrier()
     elapsed = time.perf_counter() - t0
     # every timed query produced the answer (nothing was skipped or cached: each query wrote its own slot)
