@@ -226,6 +226,9 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "class_batch_waves_per_cu")) {
         if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "class_batch_waves_per_cu must be 1..32");
         ctx->class_batch_waves_per_cu = (int)value;
+    } else if (!strcmp(key, "k1_grid")) {
+        if (value < 0 || value > (1 << 20)) return pcq_fail(PCQ_ERR_ARG, "k1_grid must be 0..2^20");
+        ctx->k1_grid = (int)value;
     } else if (!strcmp(key, "k1_waves_per_cu")) {
         if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "k1_waves_per_cu must be 1..32");
         ctx->k1_waves_per_cu = (int)value;

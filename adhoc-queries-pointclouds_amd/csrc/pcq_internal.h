@@ -143,6 +143,7 @@ struct pcq_ctx {
     int k1_waves_per_cu = 3;      // workgroups (= waves) per CU for the one-wave variants 8..14: 3 for the pipelined 12 (6-12 KiB outstanding per wave), 8 for 9
     int grid_blocks_per_cu = 2;   // persistent blocks per CU of the streaming count kernels: 8 waves x 3 KiB in flight per CU measured best (profiles/r01_k1_variant_sweep_interleaved.log)
     int batch_blocks_per_cu = 3;  // the batched K1 measured best at 3 (same log)
+    int k1_grid = 0;              // experiments: absolute number of workgroups for the one-wave per-file kernels (0 = num_cus x k1_waves_per_cu)
     int batch_variant = 3;        // batched K1: 0 = 256-thread blocks, one tile per wave step; 1 / 2 = one wave per workgroup, 2 / 3 tiles per step;
                                   // 3 = one wave per workgroup, 2 tiles per step, software-pipelined
     int batch_waves_per_cu = 3;   // 3 for batch_variant 3 (7.07 TB/s in the bench); variant 2 is flat from 5 to 8 (6.93-7.03) (profiles/r01_k1_one_wave_blocks.log)

@@ -873,7 +873,7 @@ int pcq_launch_bounds_count_xyz12(pcq_ctx *ctx, const void *d_xyz, uint64_t n, c
     if (ctx->k1_variant >= 12 && ctx->k1_variant <= 14) {  // one wave per workgroup, software-pipelined; 12: 2 tiles per step, 13: 1, 14: 3
         const int tps = ctx->k1_variant == 12 ? 2 : (ctx->k1_variant == 13 ? 1 : 3);
         const uint64_t units = n / ((uint64_t)tps * TILE_POINTS) + 1;
-        uint64_t g = (uint64_t)ctx->num_cus * ctx->k1_waves_per_cu;
+        uint64_t g = ctx->k1_grid > 0 ? (uint64_t)ctx->k1_grid : (uint64_t)ctx->num_cus * ctx->k1_waves_per_cu;
         if (g > units) g = units;
         rc = pcq_ensure_partials(ctx, (size_t)g);
         if (rc) return rc;
