@@ -793,7 +793,11 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
         pl.bytes_per_point = (pl.need_xyz ? 12 : 0) + (pl.need_cls ? 1 : 0) + (pl.need_rgb ? 6 : 0);
     }
 
-    uint64_t chunk = ctx->chunk_points;
+    // "chunk_points" is given in points of a positions column (12 B each); what matters to the pipeline is the BYTES per
+    // chunk, so a class-only scan (1 B per point) takes 12 x as many points per chunk and a record scan of a wide LAS
+    // format fewer — otherwise a class query would move 2 MB per chunk and drown in per-chunk overhead
+    uint64_t chunk = ctx->chunk_points * 12 / (pl.bytes_per_point ? pl.bytes_per_point : 1);
+    if (chunk < 4) chunk = 4;
     if (chunk > cols->n) chunk = cols->n;
     // keep each staging buffer <= 512 MiB
     const uint64_t max_stage = 512ull << 20;
