@@ -839,6 +839,56 @@ __global__ __launch_bounds__(64) void k_class_count_batch_pipe(const DevSegment 
     if (lane == 0) partials[blockIdx.x] = w;
 }
 
+// Per-file K2 in the same shape: one wave per workgroup, LOADS KiB per step, software-pipelined.
+template <int LOADS>
+__global__ __launch_bounds__(64) void k_class_count_pipe(const uint8_t *__restrict__ cls, uint64_t n, uint32_t pat, uint64_t head,
+                                                        uint64_t nvec, uint64_t *__restrict__ partials) {
+    constexpr uint64_t STEP_VEC = 64 * LOADS;
+    const int lane = threadIdx.x;
+    const v4i *body = reinterpret_cast<const v4i *>(cls + head);
+    const uint64_t steps = nvec / STEP_VEC, stride = gridDim.x;
+    uint32_t cnt = 0;
+    if (blockIdx.x < steps) {
+        ClassRegs<LOADS> A, B;
+        uint64_t u = blockIdx.x;
+        class_load<LOADS>(A, body + u * STEP_VEC, lane);
+        for (;;) {
+            const uint64_t u1 = u + stride;
+            class_load<LOADS>(B, body + (u1 < steps ? u1 : u) * STEP_VEC, lane);
+            class_wait<LOADS, LOADS>(A);
+            cnt += class_eval<LOADS>(A, pat);
+            if (u1 >= steps) break;
+            const uint64_t u2 = u1 + stride;
+            class_load<LOADS>(A, body + (u2 < steps ? u2 : u1) * STEP_VEC, lane);
+            class_wait<LOADS, LOADS>(B);
+            cnt += class_eval<LOADS>(B, pat);
+            if (u2 >= steps) break;
+            u = u2;
+        }
+        class_wait<LOADS, 0>(A);
+        class_wait<LOADS, 0>(B);
+    }
+    if (blockIdx.x == 0) {
+        const uint8_t c8 = (uint8_t)(pat & 0xff);
+        for (uint64_t v = steps * STEP_VEC + lane; v < nvec; v += 64) {  // fewer than a step of leftover vectors
+            const v4i a = body[v];
+#pragma unroll
+            for (int j = 0; j < 4; j++) cnt += __popc(zero_bytes((uint32_t)a[j] ^ pat));
+        }
+        if (lane < 16) {  // head: [0, head)   tail: [head + 16*nvec, n)   (each < 16 bytes)
+            const uint64_t p = lane;
+            if (p < head && cls[p] == c8) cnt++;
+        } else if (lane < 32) {
+            const uint64_t p = head + 16 * nvec + (lane - 16);
+            if (p < n && cls[p] == c8) cnt++;
+        }
+    }
+    uint64_t w = cnt;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) w += __shfl_down((unsigned long long)w, off, 64);
+    if (lane == 0) partials[blockIdx.x] = w;
+}
+
 __global__ __launch_bounds__(BLOCK) void k_finish_count(const uint64_t *__restrict__ partials, int nblocks,
                                                         uint64_t *__restrict__ d_count) {
     __shared__ uint64_t s[BLOCK];
@@ -922,10 +972,22 @@ int pcq_launch_class_count_u8(pcq_ctx *ctx, const void *d_cls, uint64_t n, uint8
     uint64_t head = (uint64_t)((16 - ((uintptr_t)d_cls & 15)) & 15);
     if (head > n) head = n;
     const uint64_t nvec = (n - head) / 16;
+    const uint32_t pat = 0x01010101u * (uint32_t)cls;
+    if (ctx->class_batch_pipe) {  // the same one-wave pipelined shape as the batched K2
+        uint64_t g = (uint64_t)ctx->num_cus * ctx->class_batch_waves_per_cu;
+        const uint64_t steps = nvec / 256 + 1;
+        if (g > steps) g = steps;
+        int prc = pcq_ensure_partials(ctx, (size_t)g);
+        if (prc) return prc;
+        hipLaunchKernelGGL(k_class_count_pipe<4>, dim3((unsigned)g), dim3(64), 0, s, reinterpret_cast<const uint8_t *>(d_cls), n, pat, head,
+                           nvec, ctx->d_partials);
+        hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, (int)g, d_count);
+        PCQ_HIP(hipGetLastError());
+        return PCQ_OK;
+    }
     const int grid = grid_for(ctx, (uint64_t)BLOCK * 4, nvec ? nvec : 1);
     int rc = pcq_ensure_partials(ctx, (size_t)grid);
     if (rc) return rc;
-    const uint32_t pat = 0x01010101u * (uint32_t)cls;
     hipLaunchKernelGGL(k_class_count_u8, dim3(grid), dim3(BLOCK), 0, s, reinterpret_cast<const uint8_t *>(d_cls), n, pat,
                        head, nvec, ctx->d_partials);
     hipLaunchKernelGGL(k_finish_count, dim3(1), dim3(BLOCK), 0, s, ctx->d_partials, grid, d_count);

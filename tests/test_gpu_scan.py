@@ -100,12 +100,15 @@ def test_class_count_dev_matches_oracle(oracle, gpu_ctx, n):
             for cls in (1, 2, 6, 19, 0, 255):
                 oc = oracle.count_collector()
                 assert oracle.search_last_class(image, cls, oc) == 0
-                cc = gpu_ctx.count_collector()
-                gpu_ctx.scan_dev(f.columns(True), pkg.Predicate.classification(cls), cc)
-                assert cc.point_count() == oc.point_count(), (n, pad, cls)
-                cc.free()
+                for pipe in (1, 0):  # the one-wave pipelined kernel (default) and the 256-thread one
+                    gpu_ctx.set_option("class_batch_pipe", pipe)
+                    cc = gpu_ctx.count_collector()
+                    gpu_ctx.scan_dev(f.columns(True), pkg.Predicate.classification(cls), cc)
+                    assert cc.point_count() == oc.point_count(), (n, pad, cls, pipe)
+                    cc.free()
                 oc.free()
         finally:
+            gpu_ctx.set_option("class_batch_pipe", 1)
             f.free()
 
 
