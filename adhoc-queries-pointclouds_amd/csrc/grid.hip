@@ -75,17 +75,31 @@ __device__ __forceinline__ double centre_dist(const DevGrid &g, const uint64_t (
     return (a + b) + c;
 }
 
-__device__ __forceinline__ uint64_t find_or_insert(const DevGridTable &t, uint64_t key) {
+// A table sized from a guess (see pcq_grid_scan) may fill up.  An insert that finds its occupancy shard beyond
+// `shard_limit` (the shards fill evenly, so this is "load factor beyond ~0.6"), or that has probed `probe_limit`
+// slots, or sees that another insert has given up, raises the overflow word (n_alias[2]) and gives up — the host
+// then re-runs the pass against a table of the guaranteed size (both limits 2^64-1 there: never gives up).
+__device__ __forceinline__ uint64_t find_or_insert(const DevGridTable &t, uint64_t key, uint64_t probe_limit, uint64_t shard_limit) {
     const uint64_t m = t.cap - 1;
     uint64_t h = hash64(key) & m;
+    uint64_t probes = 0;
     for (;;) {
+        if ((++probes & 63) == 0 &&
+            (probes >= probe_limit || __hip_atomic_load(t.n_alias + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+            __hip_atomic_store(t.n_alias + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return PCQ_NO_INDEX;
+        }
         uint64_t k = __hip_atomic_load(&t.slots[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (k == key) return h;
         if (k == PCQ_EMPTY_KEY) {
             const uint64_t prev = atomicCAS((unsigned long long *)&t.slots[h].key, (unsigned long long)PCQ_EMPTY_KEY,
                                             (unsigned long long)key);
             if (prev == PCQ_EMPTY_KEY) {
-                atomicAdd((unsigned long long *)&t.occupied[(blockIdx.x & (OCC_SHARDS - 1)) * OCC_STRIDE], 1ull);
+                const uint64_t in_shard = atomicAdd((unsigned long long *)&t.occupied[(blockIdx.x & (OCC_SHARDS - 1)) * OCC_STRIDE], 1ull);
+                if (in_shard >= shard_limit) {
+                    __hip_atomic_store(t.n_alias + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return PCQ_NO_INDEX;  // the key stays inserted; the re-run finds it
+                }
                 return h;
             }
             if (prev == key) return h;
@@ -124,68 +138,146 @@ __device__ __forceinline__ Matched match_point(const DevCols &c, const DevPred &
     return m;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_grid_pass_a(DevCols c, DevPred pr, DevGrid g, DevGridTable t) {
-    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < c.n; i += nthreads) {
-        const Matched m = match_point(c, pr, i);
-        if (!m.pass) continue;
-        const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
-        const uint64_t h = find_or_insert(t, ci.key);
-        const double d = centre_dist(g, ci.cell, m.px, m.py, m.pz);
-        const uint64_t db = (uint64_t)__double_as_longlong(d);
-        const uint64_t old = atomicMin((unsigned long long *)&t.slots[h].dist, (unsigned long long)db);
-        if (db < old) t.slots[h].widx = PCQ_NO_INDEX;
-        if (ci.alias) {
-            t.slots[h].nflags &= ~F_ALIAS;  // racing writers all clear the same bit; bit0 is not written in pass A
-            atomicAdd((unsigned long long *)t.n_alias, 1ull);
+// The three passes stream the whole scan range but usually work on few of its points, so each thread takes
+// GRID_BATCH points per step: the predicate inputs of all of them are loaded together (kind fixed at compile
+// time: straight-line code), then the matches are folded one by one.
+constexpr int GRID_BATCH = 4;
+
+template <int KIND, typename F>
+__device__ __forceinline__ void for_each_match(const DevCols &c, const DevPred &pr, F &&body) {
+    const uint64_t step = (uint64_t)gridDim.x * BLOCK * GRID_BATCH;
+    for (uint64_t base = (uint64_t)blockIdx.x * BLOCK * GRID_BATCH + threadIdx.x; base < c.n; base += step) {
+        RawPoint rps[GRID_BATCH];
+        bool passes[GRID_BATCH];
+#pragma unroll
+        for (int j = 0; j < GRID_BATCH; j++) {
+            const uint64_t i = base + (uint64_t)j * BLOCK;
+            passes[j] = eval_pred_kind<KIND>(c, pr, i < c.n ? i : c.n - 1, rps[j]) & (i < c.n);
+        }
+#pragma unroll
+        for (int j = 0; j < GRID_BATCH; j++) {
+            if (!passes[j]) continue;
+            const uint64_t i = base + (uint64_t)j * BLOCK;
+            if (KIND == PCQ_PRED_CLASS) rps[j] = ld_xyz(c, i);
+            if (!body(i, rps[j])) return;
         }
     }
 }
 
-// Pass B also materialises: the FIRST candidate of a cell in this scan (atomicMin found "no index")
-// writes its record right away — for almost every cell it is the only point at the minimum distance.
-// A second candidate (an exact distance tie, or a tie with the winner of an earlier scan) only bumps
-// `ties`; pass C, which re-derives the winners from the final indices, then runs for that scan only.
-__global__ __launch_bounds__(BLOCK) void k_grid_pass_b(DevCols c, DevPred pr, DevGrid g, DevGridTable t) {
-    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < c.n; i += nthreads) {
-        const Matched m = match_point(c, pr, i);
-        if (!m.pass) continue;
-        const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
-        const uint64_t h = find_slot(t, ci.key);
-        if (h == PCQ_NO_INDEX) continue;
-        const double d = centre_dist(g, ci.cell, m.px, m.py, m.pz);
-        if ((uint64_t)__double_as_longlong(d) != t.slots[h].dist) continue;
-        const uint64_t prev = atomicMin((unsigned long long *)&t.slots[h].widx, (unsigned long long)(c.first_index + i));
-        if (prev == PCQ_NO_INDEX) {
-            if (t.slots[h].nflags & F_ALIAS) {  // inverted flag: set = NOT aliased (aliased keys belong to pass R)
-                pcq_point pt;
-                make_point(c, i, m.rp, pt);
-                store_point_slot32(t.pts + h * 32, pt);
-                t.slots[h].nflags &= ~F_HAS_POINT;
+// Pass A.  Besides folding the distances it writes the scan's CANDIDATE bitmap (bit i%64 of word i/64): a matched
+// point whose distance was <= the slot minimum it saw.  The minimum only falls, so every point that ends at the
+// final minimum is a candidate; for a coarse grid that is a few points per cell (the harmonic number of the cell's
+// population), and pass B reads only those.
+template <int KIND>
+__global__ __launch_bounds__(BLOCK) void k_grid_pass_a(DevCols c, DevPred pr, DevGrid g, DevGridTable t, uint64_t probe_limit,
+                                                       uint64_t shard_limit, uint64_t *__restrict__ cand) {
+    const uint64_t step = (uint64_t)gridDim.x * BLOCK * GRID_BATCH;
+    const int lane = threadIdx.x & 63;
+    // wave-uniform trip count (the wave's first index decides): the ballots below need the whole wave
+    for (uint64_t base = (uint64_t)blockIdx.x * BLOCK * GRID_BATCH + threadIdx.x; base - lane < c.n; base += step) {
+        RawPoint rps[GRID_BATCH];
+        bool passes[GRID_BATCH];
+#pragma unroll
+        for (int j = 0; j < GRID_BATCH; j++) {
+            const uint64_t i = base + (uint64_t)j * BLOCK;
+            passes[j] = eval_pred_kind<KIND>(c, pr, i < c.n ? i : c.n - 1, rps[j]) & (i < c.n);
+        }
+#pragma unroll
+        for (int j = 0; j < GRID_BATCH; j++) {
+            const uint64_t i = base + (uint64_t)j * BLOCK;
+            bool candidate = false;
+            if (passes[j]) {
+                if (KIND == PCQ_PRED_CLASS) rps[j] = ld_xyz(c, i);
+                const RawPoint rp = rps[j];
+                const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]),
+                             pz = world(rp.z, c.scale[2], c.offset[2]);
+                const CellInfo ci = cell_of(g, px, py, pz);
+                const uint64_t h = find_or_insert(t, ci.key, probe_limit, shard_limit);
+                if (h == PCQ_NO_INDEX) return;  // table full: the pass is re-run (bitmap included) after the table has grown
+                const double d = centre_dist(g, ci.cell, px, py, pz);
+                const uint64_t db = (uint64_t)__double_as_longlong(d);
+                // the slot's line was just read for the key; a point that cannot lower the minimum (most points of a
+                // coarse grid) skips the atomic.  A stale value can only be too large: an atomic more, never a miss.
+                const uint64_t seen = __hip_atomic_load(&t.slots[h].dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                candidate = db <= seen;
+                if (db < seen) {
+                    const uint64_t old = atomicMin((unsigned long long *)&t.slots[h].dist, (unsigned long long)db);
+                    if (db < old) t.slots[h].widx = PCQ_NO_INDEX;
+                }
+                if (ci.alias) {
+                    t.slots[h].nflags &= ~F_ALIAS;  // racing writers all clear the same bit; bit0 is not written in pass A
+                    atomicAdd((unsigned long long *)t.n_alias, 1ull);
+                }
             }
-        } else {
-            atomicAdd((unsigned long long *)(t.n_alias + 1), 1ull);
+            const uint64_t word = __ballot(candidate);
+            if (lane == 0 && i < c.n) cand[i >> 6] = word;  // i of lane 0 is the wave's first index, a multiple of 64
         }
     }
 }
 
+// Pass B: the candidates whose distance equals the slot's final minimum race for the lowest file-order index.  It
+// also materialises: the FIRST such point of a cell in this scan (atomicMin found "no index") writes its record
+// right away — for almost every cell it is the only point at the minimum distance.  A second one (an exact
+// distance tie, or a tie with the winner of an earlier scan) only bumps `ties`; pass C, which re-derives the
+// winners from the final indices, then runs for that scan only.  One wave per bitmap word, GRID_BATCH words a step.
+__global__ __launch_bounds__(BLOCK) void k_grid_pass_b(DevCols c, DevGrid g, DevGridTable t, const uint64_t *__restrict__ cand) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t words = (c.n + 63) >> 6;
+    const uint64_t wave = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * WAVES;
+    for (uint64_t w0 = wave * GRID_BATCH; w0 < words; w0 += nwaves * GRID_BATCH) {
+        uint64_t bits[GRID_BATCH];
+#pragma unroll
+        for (int j = 0; j < GRID_BATCH; j++) bits[j] = w0 + j < words ? cand[w0 + j] : 0;
+        RawPoint rps[GRID_BATCH];
+#pragma unroll
+        for (int j = 0; j < GRID_BATCH; j++) {  // lanes that are not candidates re-read the word's first point
+            const bool on = (bits[j] >> lane) & 1;
+            rps[j] = ld_xyz(c, on ? (w0 + j) * 64 + lane : (w0 + j < words ? (w0 + j) * 64 : 0));
+        }
+#pragma unroll
+        for (int j = 0; j < GRID_BATCH; j++) {
+            if (!((bits[j] >> lane) & 1)) continue;
+            const uint64_t i = (w0 + j) * 64 + lane;
+            const RawPoint rp = rps[j];
+            const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]),
+                         pz = world(rp.z, c.scale[2], c.offset[2]);
+            const CellInfo ci = cell_of(g, px, py, pz);
+            const uint64_t h = find_slot(t, ci.key);
+            if (h == PCQ_NO_INDEX) continue;
+            const double d = centre_dist(g, ci.cell, px, py, pz);
+            if ((uint64_t)__double_as_longlong(d) != t.slots[h].dist) continue;
+            const uint64_t prev = atomicMin((unsigned long long *)&t.slots[h].widx, (unsigned long long)(c.first_index + i));
+            if (prev == PCQ_NO_INDEX) {
+                if (t.slots[h].nflags & F_ALIAS) {  // inverted flag: set = NOT aliased (aliased keys belong to pass R)
+                    pcq_point pt;
+                    make_point(c, i, rp, pt);
+                    store_point_slot32(t.pts + h * 32, pt);
+                    t.slots[h].nflags &= ~F_HAS_POINT;
+                }
+            } else {
+                atomicAdd((unsigned long long *)(t.n_alias + 1), 1ull);
+            }
+        }
+    }
+}
+
+template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_grid_pass_c(DevCols c, DevPred pr, DevGrid g, DevGridTable t) {
-    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < c.n; i += nthreads) {
-        const Matched m = match_point(c, pr, i);
-        if (!m.pass) continue;
-        const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
+    for_each_match<KIND>(c, pr, [&](uint64_t i, const RawPoint &rp) {
+        const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]),
+                     pz = world(rp.z, c.scale[2], c.offset[2]);
+        const CellInfo ci = cell_of(g, px, py, pz);
         const uint64_t h = find_slot(t, ci.key);
-        if (h == PCQ_NO_INDEX) continue;
-        if (!(t.slots[h].nflags & F_ALIAS)) continue;  // aliased key: resolved by pass R
+        if (h == PCQ_NO_INDEX) return true;
+        if (!(t.slots[h].nflags & F_ALIAS)) return true;  // aliased key: resolved by pass R
         if (t.slots[h].widx == c.first_index + i) {
             pcq_point pt;
-            make_point(c, i, m.rp, pt);
+            make_point(c, i, rp, pt);
             store_point_slot32(t.pts + h * 32, pt);
             t.slots[h].nflags &= ~F_HAS_POINT;
         }
-    }
+        return true;
+    });
 }
 
 // Pass R: exact sequential fold for aliased keys.  `list` / `lkeys` hold, in file order, the local
@@ -325,7 +417,8 @@ __global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *__restrict__ counts
     if (threadIdx.x == 0) *total_out = s_carry;
 }
 
-// out[0] = occupied slots (sum of the shards), out[1] = aliased points, out[2] = distance ties of the last scan.
+// out[0] = occupied slots (sum of the shards), out[1] = aliased points, out[2] = distance ties of the last scan,
+// out[3] = overflow word of the last pass A.
 __global__ __launch_bounds__(OCC_SHARDS) void k_sum_occupied(const uint64_t *__restrict__ occ, const uint64_t *__restrict__ n_alias,
                                                              uint64_t *__restrict__ out) {
     __shared__ uint64_t s[OCC_SHARDS];
@@ -339,6 +432,7 @@ __global__ __launch_bounds__(OCC_SHARDS) void k_sum_occupied(const uint64_t *__r
         out[0] = s[0];
         out[1] = n_alias[0];
         out[2] = n_alias[1];  // distance ties seen by pass B
+        out[3] = n_alias[2];  // pass A gave up: table full
     }
 }
 
@@ -468,7 +562,7 @@ static uint64_t next_pow2(uint64_t v) {
 }
 
 static int grid_blocks(pcq_ctx *ctx, uint64_t n) {
-    uint64_t want = (n + BLOCK - 1) / BLOCK;
+    uint64_t want = (n + BLOCK * GRID_BATCH - 1) / (BLOCK * GRID_BATCH);
     const uint64_t cap = (uint64_t)ctx->num_cus * 16;
     if (want < 1) want = 1;
     return (int)(want < cap ? want : cap);
@@ -503,22 +597,66 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const Dev
         const uint64_t room = keyspace > c->table_used_bound ? keyspace - c->table_used_bound : 0;
         if (additional > room) additional = room;
     }
-    int rc = grid_reserve(ctx, c, additional, s);
+    // Table size.  `additional` is the guaranteed bound, but a coarse grid (the paper's 100 m cells: one cell per
+    // ~90 points) would then spread a few million cells over a table of gigabytes: every probe an HBM miss and a
+    // memset of the whole table per file.  So the first size is a guess — an eighth of the bound — unless this
+    // collector, or the previous scan of this context, has shown the grid to be dense; pass A raises the overflow
+    // word if the guess was too small and is then re-run (it is idempotent) on a table of the guaranteed size.
+    const uint64_t used_before = c->table_used_bound;
+    bool guessing = ctx->grid_guess && !c->grid_dense && !ctx->grid_dense_hint && additional > (1ull << 20);
+    int rc = grid_reserve(ctx, c, guessing ? additional / 8 : additional, s);
     if (rc) return rc;
     const int grid = grid_blocks(ctx, cols.n);
     const DevGrid &g = c->grid;
+    const uint64_t cand_words = (cols.n + 63) / 64;  // candidate bitmap of this scan (context scratch, grow-only)
+    if (cand_words > ctx->cand_words) {
+        PCQ_HIP(hipStreamSynchronize(s));
+        if (ctx->d_cand) PCQ_HIP(hipFree(ctx->d_cand));
+        ctx->d_cand = nullptr;
+        ctx->cand_words = 0;
+        if (hipMalloc((void **)&ctx->d_cand, cand_words * 8) != hipSuccess) {
+            (void)hipGetLastError();
+            return pcq_fail(PCQ_ERR_NOMEM, "grid candidate bitmap: %llu bytes", (unsigned long long)(cand_words * 8));
+        }
+        ctx->cand_words = cand_words;
+    }
+    for (;;) {
+        PCQ_HIP(hipMemsetAsync(c->table.n_alias, 0, 24, s));  // per scan: aliased points, distance ties, overflow
+        const uint64_t shard_limit = guessing ? c->table.cap / OCC_SHARDS * 5 / 8 : ~0ull;
+        const uint64_t probe_limit = guessing ? 1024ull : ~0ull;
+        if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_grid_pass_a<PCQ_PRED_BOUNDS>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, c->table, probe_limit, shard_limit, ctx->d_cand);
+        else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_grid_pass_a<PCQ_PRED_CLASS>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, c->table, probe_limit, shard_limit, ctx->d_cand);
+        else hipLaunchKernelGGL(k_grid_pass_a<PCQ_PRED_BOUNDS_F64>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, c->table, probe_limit, shard_limit, ctx->d_cand);
+        PCQ_HIP(hipGetLastError());
+        hipLaunchKernelGGL(k_sum_occupied, dim3(1), dim3(OCC_SHARDS), 0, s, c->table.occupied, c->table.n_alias, ctx->d_scalars + 16);
+        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars + 16, 32, hipMemcpyDeviceToHost, s));
+        PCQ_HIP(hipStreamSynchronize(s));
+        if (!ctx->h_scalars[3]) break;
+        if (!guessing) return pcq_fail(PCQ_ERR_HIP, "grid table of the guaranteed size overflowed");
+        guessing = false;
+        ctx->grid_overflows++;
+        c->grid_dense = true;
+        c->table_used_bound = ctx->h_scalars[0];  // the cells inserted so far stay (re-inserting finds them)
+        const uint64_t still = additional > ctx->h_scalars[0] - used_before ? additional - (ctx->h_scalars[0] - used_before) : 0;
+        rc = grid_reserve(ctx, c, still, s);
+        if (rc) return rc;
+    }
+    c->table_used_bound = ctx->h_scalars[0];
+    if (ctx->h_scalars[1]) c->grid_has_alias = true;  // sticky: flagged keys stay flagged
+    // the next scan of this context starts from a guess again only if this one would have fitted it
+    ctx->grid_dense_hint = (c->table_used_bound - used_before) > additional / 8;
+    if (2 * c->table_used_bound >= c->table.cap) {  // only after a guess: back to a load factor <= 1/2 for the lookups
+        ctx->grid_regrows++;
+        rc = grid_reserve(ctx, c, 0, s);
+        if (rc) return rc;
+    }
     DevGridTable &t = c->table;
-    // alias counter is per scan
-    PCQ_HIP(hipMemsetAsync(t.n_alias, 0, 16, s));  // aliased points, distance ties
-    hipLaunchKernelGGL(k_grid_pass_a, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
-    hipLaunchKernelGGL(k_grid_pass_b, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
+    hipLaunchKernelGGL(k_grid_pass_b, dim3(grid), dim3(BLOCK), 0, s, cols, g, t, ctx->d_cand);
     PCQ_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_sum_occupied, dim3(1), dim3(OCC_SHARDS), 0, s, t.occupied, t.n_alias, ctx->d_scalars + 16);
-    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars + 16, 24, hipMemcpyDeviceToHost, s));
+    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars + 16, 32, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipStreamSynchronize(s));
-    c->table_used_bound = ctx->h_scalars[0];
     const uint64_t n_ties = ctx->h_scalars[2];
-    if (ctx->h_scalars[1]) c->grid_has_alias = true;  // sticky: flagged keys stay flagged
     if (c->grid_has_alias) {
         const uint64_t nblocks = (cols.n + TILE - 1) / TILE;
         rc = pcq_ensure_partials(ctx, (size_t)nblocks);
@@ -541,7 +679,11 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const Dev
             if (e != hipSuccess) return pcq_fail(PCQ_ERR_HIP, "grid pass R failed: %s", hipGetErrorString(e));
         }
     }
-    if (n_ties) hipLaunchKernelGGL(k_grid_pass_c, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
+    if (n_ties) {
+        if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_grid_pass_c<PCQ_PRED_BOUNDS>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
+        else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_grid_pass_c<PCQ_PRED_CLASS>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
+        else hipLaunchKernelGGL(k_grid_pass_c<PCQ_PRED_BOUNDS_F64>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
+    }
     PCQ_HIP(hipGetLastError());
     return PCQ_OK;
 }

@@ -154,6 +154,7 @@ extern "C" int pcq_shutdown(pcq_ctx *ctx) {
     ctx->copy_pool = nullptr;
     pcq_grid_cache_clear(ctx);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+    if (ctx->d_cand) (void)hipFree(ctx->d_cand);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     if (ctx->d_segments) (void)hipFree(ctx->d_segments);
@@ -238,6 +239,9 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "batch_waves_per_cu")) {
         if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "batch_waves_per_cu must be 1..32");
         ctx->batch_waves_per_cu = (int)value;
+    } else if (!strcmp(key, "grid_guess")) {
+        ctx->grid_guess = value != 0;
+        ctx->grid_dense_hint = false;
     } else if (!strcmp(key, "numa_local")) {
         ctx->numa_local = value != 0;
         delete ctx->copy_pool;  // helpers are re-created with or without the affinity
@@ -276,6 +280,10 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     else if (!strcmp(key, "copy_threads")) *value = ctx->copy_threads;
     else if (!strcmp(key, "numa_local")) *value = ctx->numa_local;
     else if (!strcmp(key, "numa_node")) *value = ctx->numa_node;
+    else if (!strcmp(key, "grid_guess")) *value = ctx->grid_guess;
+    else if (!strcmp(key, "grid_dense_hint")) *value = ctx->grid_dense_hint;
+    else if (!strcmp(key, "grid_overflows")) *value = ctx->grid_overflows;
+    else if (!strcmp(key, "grid_regrows")) *value = ctx->grid_regrows;
     else return pcq_fail(PCQ_ERR_ARG, "unknown option '%s'", key);
     return PCQ_OK;
 }

@@ -138,6 +138,11 @@ struct pcq_ctx {
     // hipMalloc/hipFree tens of GB per file, and a fresh 30 GB allocation right after a free was
     // measured to stall for seconds (profiles/r01_grid_timeline.txt)
     DevGridTable grid_cache = {};
+    uint64_t *d_cand = nullptr;         // grid pass A -> B candidate bitmap (grid.hip)
+    uint64_t cand_words = 0;
+    int grid_guess = 1;                 // option: size grid tables from a guess first (grid.hip)
+    int64_t grid_overflows = 0, grid_regrows = 0;  // diagnostics: guesses that overflowed / were enlarged after pass A
+    bool grid_dense_hint = false;       // the last grid scan filled more than a sixteenth of its guaranteed bound (grid.hip)
     // options
     int k1_variant = 12;          // per-file K1: one wave per workgroup, two adjacent 3 KiB tiles per step, software-pipelined (profiles/r01_k1_one_wave_blocks.log)
     int k1_waves_per_cu = 3;      // workgroups (= waves) per CU for the one-wave variants 8..14: 3 for the pipelined 12 (6-12 KiB outstanding per wave), 8 for 9
@@ -179,6 +184,7 @@ struct pcq_collector {
     DevGrid grid;
     DevGridTable table;
     uint64_t table_used_bound = 0;      // host-side count of occupied slots after the last scan
+    bool grid_dense = false;            // sticky: a guessed table size overflowed; this collector uses the guaranteed size
     bool grid_has_alias = false;        // sticky: some key has seen an aliased cell (grid.hip pass R)
     uint64_t next_index = 0;            // file-order index the next scan starts at
     hipStream_t last_stream = nullptr;  // stream of the most recent scan: accessors wait on it

@@ -227,6 +227,53 @@ def test_grid_collector_dev_matches_oracle(oracle, gpu_ctx, n, cell):
         f.free()
 
 
+def test_grid_table_guess_growth_and_overflow(oracle):
+    """The grid table is first sized from a guess (an eighth of the guaranteed bound, csrc/grid.hip pcq_grid_scan):
+    a coarse grid fits it, a medium one is enlarged after pass A, a dense one overflows and pass A is re-run on the
+    guaranteed size — after which the context starts the next grid at the guaranteed size.  Same cells and winners
+    as the oracle in every case, and with the guess switched off."""
+    n = 3_000_000
+    spec = small_spec(424242, n, fmt=2)
+    image = oracle.synth_image(spec, transposed=True)
+    hdr = oracle.parse_header(image[:400].tobytes())
+    bmin, bmax = (-500.0, -500.0, -100.0), (500.0, 500.0, 100.0)  # wider than the data: the key space does not cap the bound
+    lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+    expect = {}
+    for cell in (1.0, 0.72, 0.25):
+        og = oracle.grid_collector(bmin, bmax, cell)
+        assert oracle.search_last_bounds(image, bmin, bmax, og) == 0
+        expect[cell] = (og.point_count(), og.grid_cells().copy(), og.points().tobytes())
+        og.free()
+    assert expect[1.0][0] <= n // 8 and 2**19 <= expect[0.72][0] < 2**20 * 5 // 8 < expect[0.25][0]  # the three regimes
+    with pkg.Context(0) as ctx:
+        f = DevFile(ctx, image, hdr)
+        try:
+            def run(cell):
+                gg = ctx.grid_collector(bmin, bmax, cell)
+                ctx.scan_dev(f.columns(True), pkg.Predicate.bounds(lmin, lmax), gg)
+                cnt, cells, pts = expect[cell]
+                assert gg.point_count() == cnt
+                gp, gk = gg.points(), gg.grid_cells()
+                order = np.argsort(gk, kind="stable")
+                assert np.array_equal(gk[order], cells)
+                assert gp[order].tobytes() == pts
+                gg.free()
+                return ctx.get_option("grid_overflows"), ctx.get_option("grid_regrows"), ctx.get_option("grid_dense_hint")
+
+            assert run(1.0) == (0, 0, 0)       # ~0.2 M cells in a table guessed for 0.375 M
+            assert run(0.72) == (0, 1, 1)      # ~0.56 M cells: past load 1/2 of the guessed 2^20 slots, enlarged before pass B
+            ctx.set_option("grid_guess", 1)    # clears the hint
+            assert run(0.25) == (1, 1, 1)      # ~2.7 M cells: overflow, pass A re-run on the guaranteed size
+            assert run(0.25) == (1, 1, 1)      # the hint: no second overflow
+            assert run(1.0) == (1, 1, 0)       # guaranteed size, but it would have fitted: guessing again from here
+            assert run(1.0) == (1, 1, 0)
+            ctx.set_option("grid_guess", 0)
+            for cell in (1.0, 0.72, 0.25):
+                assert run(cell)[:2] == (1, 1)
+        finally:
+            f.free()
+
+
 def test_synth_device_generator_is_bit_identical(oracle, gpu_ctx):
     for spec in (small_spec(1, 100_003, zo=(3000, -9000, 18001)), specs.synth_ca13(50_001)[5], specs.synth_doc(40_000)[3],
                  specs.synth_navvis(30_011)[0]):

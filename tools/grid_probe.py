@@ -1,4 +1,5 @@
-"""Developer probe: one grid-collector scan (for rocprofv3 --kernel-trace)."""
+"""Developer probe: grid-collector scans of one resident file (for rocprofv3 --kernel-trace).
+usage: grid_probe.py QUERY CELL [POINTS] [REPEATS]; GRID_GUESS=0 switches the guessed table size off."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -14,7 +15,8 @@ with pkg.Context(0) as ctx:
     cols = binding.make_columns(xyz=xyz, cls=cls, n=n, scale=list(spec.scale), offset=list(spec.offset))
     bmin, bmax = specs.box(q)
     lmin, lmax = pkg.box_to_local(bmin, bmax, list(spec.scale), list(spec.offset))
-    for _ in range(2):
+    ctx.set_option("grid_guess", int(os.environ.get("GRID_GUESS", "1")))
+    for _ in range(int(sys.argv[4]) if len(sys.argv) > 4 else 2):
         t0 = time.perf_counter()
         g = ctx.grid_collector(bmin, bmax, cell)
         t1 = time.perf_counter()
@@ -25,4 +27,5 @@ with pkg.Context(0) as ctx:
         t3 = time.perf_counter()
         g.free()
         t4 = time.perf_counter()
-        print(q, cell, "cells", k, "new %.1f scan %.1f count %.1f free %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3), flush=True)
+        print(q, cell, "cells", k, "new %.1f scan %.1f count %.1f free %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3),
+              "overflows", ctx.get_option("grid_overflows"), "regrows", ctx.get_option("grid_regrows"), flush=True)
