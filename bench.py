@@ -31,6 +31,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL across processes needs on this driver
 
 import torch  # noqa: E402  (device memory, streams, torch.distributed — plumbing only)
 import torch.distributed as dist  # noqa: E402
