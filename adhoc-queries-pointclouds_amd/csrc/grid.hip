@@ -185,17 +185,17 @@ __global__ __launch_bounds__(BLOCK) void k_grid_pass_a(DevCols c, DevPred pr, De
 #pragma unroll
         for (int j = 0; j < GRID_BATCH; j++) {
             const uint64_t i = base + (uint64_t)j * BLOCK;
+            const bool pass = passes[j];
             bool candidate = false;
-            if (passes[j]) {
+            if (pass) {
                 if (KIND == PCQ_PRED_CLASS) rps[j] = ld_xyz(c, i);
                 const RawPoint rp = rps[j];
                 const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]),
                              pz = world(rp.z, c.scale[2], c.offset[2]);
                 const CellInfo ci = cell_of(g, px, py, pz);
+                const uint64_t db = (uint64_t)__double_as_longlong(centre_dist(g, ci.cell, px, py, pz));
                 const uint64_t h = find_or_insert(t, ci.key, probe_limit, shard_limit);
                 if (h == PCQ_NO_INDEX) return;  // table full: the pass is re-run (bitmap included) after the table has grown
-                const double d = centre_dist(g, ci.cell, px, py, pz);
-                const uint64_t db = (uint64_t)__double_as_longlong(d);
                 // the slot's line was just read for the key; a point that cannot lower the minimum (most points of a
                 // coarse grid) skips the atomic.  A stale value can only be too large: an atomic more, never a miss.
                 const uint64_t seen = __hip_atomic_load(&t.slots[h].dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

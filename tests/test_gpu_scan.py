@@ -227,6 +227,45 @@ def test_grid_collector_dev_matches_oracle(oracle, gpu_ctx, n, cell):
         f.free()
 
 
+@pytest.mark.parametrize("cell", [0.7, 2.5, 20.0])
+def test_grid_collector_on_spatially_coherent_files(oracle, gpu_ctx, cell):
+    """The seeded files are in random order: neighbouring lanes never share a cell.  Real tiles are written along
+    scan lines; here the points are sorted along x/y strips, a third of them snapped to a lattice (exact duplicates:
+    same-address atomics and distance ties inside a wave, first in file order wins), and a class query interleaves
+    lanes that do not match."""
+    n = 150_001
+    spec = small_spec(777, n, fmt=2)
+    image = oracle.synth_image(spec, transposed=True).copy()
+    hdr = oracle.parse_header(image[:400].tobytes())
+    otp = hdr.offset_to_point_data
+    xyz = image[otp:otp + 12 * n].view("<i4").reshape(n, 3).copy()
+    rng = np.random.default_rng(5)
+    snap = rng.random(n) < 0.33
+    xyz[snap] = xyz[snap] // 64 * 64
+    strip = xyz[:, 1] // 300
+    order = np.lexsort((np.where(strip % 2 == 0, xyz[:, 0], -xyz[:, 0]), strip))  # boustrophedon strips
+    image[otp:otp + 12 * n] = np.frombuffer(np.ascontiguousarray(xyz[order]).tobytes(), dtype=np.uint8)
+    f = DevFile(gpu_ctx, image, hdr)
+    try:
+        for bmin, bmax in [((-20.0, -20.0, -5.0), (20.0, 20.0, 5.0)), ((-50.0, -50.0, -10.0), (50.0, 50.0, 10.0))]:
+            lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+            for pred, search in ((pkg.Predicate.bounds(lmin, lmax), lambda og: oracle.search_last_bounds(image, bmin, bmax, og)),
+                                 (pkg.Predicate.classification(2), lambda og: oracle.search_last_class(image, 2, og))):
+                og = oracle.grid_collector(bmin, bmax, cell)
+                assert search(og) == 0
+                gg = gpu_ctx.grid_collector(bmin, bmax, cell)
+                gpu_ctx.scan_dev(f.columns(True), pred, gg)
+                assert gg.point_count() == og.point_count()
+                gp, gk = gg.points(), gg.grid_cells()
+                order_k = np.argsort(gk, kind="stable")
+                assert np.array_equal(gk[order_k], og.grid_cells())
+                assert gp[order_k].tobytes() == og.points().tobytes()
+                gg.free()
+                og.free()
+    finally:
+        f.free()
+
+
 def test_grid_table_guess_growth_and_overflow(oracle):
     """The grid table is first sized from a guess (an eighth of the guaranteed bound, csrc/grid.hip pcq_grid_scan):
     a coarse grid fits it, a medium one is enlarged after pass A, a dense one overflows and pass A is re-run on the

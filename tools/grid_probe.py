@@ -1,5 +1,7 @@
 """Developer probe: grid-collector scans of one resident file (for rocprofv3 --kernel-trace).
-usage: grid_probe.py QUERY CELL [POINTS] [REPEATS]; GRID_GUESS=0 switches the guessed table size off."""
+usage: grid_probe.py QUERY CELL [POINTS] [REPEATS]; GRID_GUESS=0 switches the guessed table size off;
+COHERENT=<metres> reorders the file into x/y strips of that width (points sorted along each strip, like scan
+lines) instead of the generator's random order."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -7,11 +9,26 @@ pkg = importlib.import_module("adhoc-queries-pointclouds_amd")
 binding = importlib.import_module("adhoc-queries-pointclouds_amd.binding")
 specs = importlib.import_module("adhoc-queries-pointclouds_amd.synth_specs")
 q, cell, n = sys.argv[1], float(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 163_000_000
+if os.environ.get("COHERENT"):
+    import torch  # plumbing for the device sort; initialised before the context
+    torch.cuda.init()
 with pkg.Context(0) as ctx:
     spec = specs.synth_ca13(points_per_file=n)[5]
     xyz, cls = ctx.alloc(12 * n), ctx.alloc(n)
     ctx.synth_fill(spec, 0, n, xyz, cls)
     ctx.synchronize()
+    if os.environ.get("COHERENT"):
+        import numpy as np
+        import torch
+        width = int(float(os.environ["COHERENT"]) / spec.scale[1])
+        host = np.zeros((n, 3), dtype=np.int32)
+        ctx.to_host(host, xyz)
+        t = torch.from_numpy(host).cuda()
+        zwidth = int(float(os.environ["COHERENT"]) / spec.scale[2])
+        key = ((t[:, 1].long() // width) * 4096 + (t[:, 2].long() // zwidth + 2048)) * (1 << 32) + (t[:, 0].long() + (1 << 31))
+        t = t[torch.argsort(key)].contiguous().cpu().numpy()
+        ctx.to_device(xyz, t)
+        del key
     cols = binding.make_columns(xyz=xyz, cls=cls, n=n, scale=list(spec.scale), offset=list(spec.offset))
     bmin, bmax = specs.box(q)
     lmin, lmax = pkg.box_to_local(bmin, bmax, list(spec.scale), list(spec.offset))
