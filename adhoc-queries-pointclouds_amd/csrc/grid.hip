@@ -522,26 +522,44 @@ static void table_free(DevGridTable &t) {
     t = DevGridTable{};
 }
 
-void pcq_grid_cache_clear(pcq_ctx *ctx) { table_free(ctx->grid_cache); }
+void pcq_grid_cache_clear(pcq_ctx *ctx) {
+    for (DevGridTable &e : ctx->grid_cache) table_free(e);
+}
 
-// Retires the collector's table: the largest retired table stays cached in the context.
+// Retires the collector's table.  The context keeps up to two retired tables (device allocations of this size cost
+// from tens of milliseconds to more than a second): a process that alternates coarse and dense grids finds both
+// its small and its large table again.  A third size replaces the smaller of the two if it is larger.
 void pcq_grid_release(pcq_collector *c) {
     DevGridTable &t = c->table;
     pcq_ctx *ctx = c->ctx;
-    if (t.slots && ctx && t.cap > ctx->grid_cache.cap) {
-        table_free(ctx->grid_cache);
-        ctx->grid_cache = t;
-        t = DevGridTable{};
-        return;
+    if (!t.slots) return;
+    if (ctx) {
+        DevGridTable *victim = nullptr;
+        for (DevGridTable &e : ctx->grid_cache) {
+            if (!e.slots) {
+                victim = &e;
+                break;
+            }
+            if (!victim || e.cap < victim->cap) victim = &e;
+        }
+        if (!victim->slots || victim->cap < t.cap) {
+            table_free(*victim);
+            *victim = t;
+            t = DevGridTable{};
+            return;
+        }
     }
     table_free(t);
 }
 
 static int table_alloc(pcq_ctx *ctx, DevGridTable *t, uint64_t cap, hipStream_t s) {
     *t = DevGridTable{};
-    if (ctx->grid_cache.slots && ctx->grid_cache.cap >= cap && ctx->grid_cache.cap <= 4 * cap) {
-        *t = ctx->grid_cache;  // reuse (a larger table only lowers the load factor)
-        ctx->grid_cache = DevGridTable{};
+    DevGridTable *hit = nullptr;  // the smallest retired table that is large enough, and not wastefully larger
+    for (DevGridTable &e : ctx->grid_cache)
+        if (e.slots && e.cap >= cap && e.cap <= 4 * cap && (!hit || e.cap < hit->cap)) hit = &e;
+    if (hit) {
+        *t = *hit;  // reuse (a larger table only lowers the load factor)
+        *hit = DevGridTable{};
         cap = t->cap;
     } else {
         t->cap = cap;

@@ -137,7 +137,7 @@ struct pcq_ctx {
     // one retired grid hash table kept for reuse: per-file grids (main.rs:156) would otherwise
     // hipMalloc/hipFree tens of GB per file, and a fresh 30 GB allocation right after a free was
     // measured to stall for seconds (profiles/r01_grid_timeline.txt)
-    DevGridTable grid_cache = {};
+    DevGridTable grid_cache[2] = {};    // retired grid tables, reused by later grids (grid.hip)
     uint64_t *d_cand = nullptr;         // grid pass A -> B candidate bitmap (grid.hip)
     uint64_t cand_words = 0;
     int grid_guess = 1;                 // option: size grid tables from a guess first (grid.hip)

@@ -74,7 +74,7 @@ def main():
                     k = g.point_count()
                     g.free()
                     return k
-                t_g, cells = timed(grid, rounds=2)
+                t_g, cells = timed(grid, rounds=3)
                 entry[f"grid_{int(cell)}_ms"] = t_g * 1e3
                 entry[f"grid_{int(cell)}_cells"] = cells
                 entry[f"grid_{int(cell)}_Mpts_per_s"] = n / t_g / 1e6
