@@ -300,15 +300,19 @@ def test_grid_table_guess_growth_and_overflow(oracle):
                 return ctx.get_option("grid_overflows"), ctx.get_option("grid_regrows"), ctx.get_option("grid_dense_hint")
 
             assert run(1.0) == (0, 0, 0)       # ~0.2 M cells in a table guessed for 0.375 M
-            assert run(0.72) == (0, 1, 1)      # ~0.56 M cells: past load 1/2 of the guessed 2^20 slots, enlarged before pass B
+            # ~0.56 M cells: past load 1/2 of the guessed 2^20 slots -> enlarged before pass B; the overflow limit (load
+            # ~0.6, estimated from one occupancy shard) is close enough that an uneven run may take that road instead
+            o, r, hint = run(0.72)
+            assert o + r == 1 and hint == 1
             ctx.set_option("grid_guess", 1)    # clears the hint
-            assert run(0.25) == (1, 1, 1)      # ~2.7 M cells: overflow, pass A re-run on the guaranteed size
-            assert run(0.25) == (1, 1, 1)      # the hint: no second overflow
-            assert run(1.0) == (1, 1, 0)       # guaranteed size, but it would have fitted: guessing again from here
-            assert run(1.0) == (1, 1, 0)
+            o2, r2, hint = run(0.25)           # ~2.7 M cells: overflow, pass A re-run on the guaranteed size
+            assert (o2, r2, hint) == (o + 1, r, 1)
+            assert run(0.25) == (o2, r2, 1)    # the hint: no second overflow
+            assert run(1.0) == (o2, r2, 0)     # guaranteed size, but it would have fitted: guessing again from here
+            assert run(1.0) == (o2, r2, 0)
             ctx.set_option("grid_guess", 0)
             for cell in (1.0, 0.72, 0.25):
-                assert run(cell)[:2] == (1, 1)
+                assert run(cell)[:2] == (o2, r2)
         finally:
             f.free()
 
