@@ -50,7 +50,8 @@ def main():
     res = {"files": args.files, "points": total_pts, "bytes": sum(os.path.getsize(os.path.join(d, f)) for f in os.listdir(d))}
     xl = "643431.76;3883547.565;-46194.145;736910.93;3977026.735;47285.025"
     for name, q in (("bounds_XL", ["--bounds", xl]), ("bounds_S", ["--bounds", "665000;3910000;0;705000;3950000;480"]),
-                    ("class_6", ["--class", "6"]), ("bounds_XL_density_100", ["--bounds", xl, "--density", "100"])):
+                    ("class_6", ["--class", "6"]), ("bounds_XL_density_100", ["--bounds", xl, "--density", "100"]),
+                    ("bounds_XL_density_10", ["--bounds", xl, "--density", "10"])):
         base = ["-i", d, "--optimized", "--parallel"] + q
         t_gpu, out_gpu = run(QUERY, base + ["--threads-per-gpu", str(args.threads_per_gpu)])
         t_gpu2, _ = run(QUERY, base + ["--threads-per-gpu", "2"])
