@@ -50,6 +50,21 @@ def test_bench_under_torch_distributed_run_exercises_rccl():
     assert d["cpu_baseline"] is None
 
 
+def test_bench_two_rank_rehearsal_shards_files_and_sums_counts():
+    """The N > 1 code path of bench.py (file sharding, one all-reduce per query enqueued asynchronously, max-over-ranks
+    timing) with two ranks sharing the one GPU of the test box; gloo carries the all-reduce there (RCCL refuses two ranks
+    on one device), everything else is the path the driver launches on 2/4/8 GPUs."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+                        "--warmup", "1", "--files", "5", "--points-per-file", "300007", "--no-cpu-baseline",
+                        "--rehearse-on-one-gpu"], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = _check(lines[0], 2)
+    assert d["config"]["points"] == 5 * 300007 and d["scaling"] == "strong"
+
+
 def test_smoke_entry_point():
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], capture_output=True, text=True, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
