@@ -15,9 +15,13 @@
 //    and the 64-bit compare masks (wave64: v_cmp writes an SGPR pair) are combined with scalar
 //    shifts/ANDs into "three consecutive dwords pass" bits, popcounted with s_bcnt1 — the VALU sees
 //    two instructions per dword, everything else runs on the scalar unit;
-//  * persistent grid (blocks_per_cu x 256 CUs, 256 threads) with a tile-stride loop; per-block
-//    partial counts are written with plain stores and folded by a 1-block finishing kernel, so no
-//    same-address atomic storm at the tail.
+//  * persistent grid with a tile-stride loop; per-block partial counts are written with plain stores and
+//    folded by a 1-block finishing kernel, so no same-address atomic storm at the tail;
+//  * the kernels that run by default (k_bounds_count_w1_pipe, k_bounds_count_batch_pipe,
+//    k_class_count_pipe, k_class_count_batch_pipe) are ONE-WAVE workgroups, three (class: four) per CU,
+//    software-pipelined by hand: the loads of the next step are in flight (inline-asm global_load_dwordx4
+//    nt + counted s_waitcnt) while the current step is evaluated.  The 256-thread kernels they replaced
+//    stay selectable (options k1_variant / batch_variant / class_batch_pipe) for the sweeps in tools/.
 #include <vector>
 
 #include "pcq_internal.h"
@@ -157,7 +161,7 @@ __device__ __forceinline__ void block_store_partial(uint64_t wave_total, uint64_
     }
 }
 
-// K1.  VARIANT 0: mask algebra (default) · 1: dwordx3 per lane · 2: 48-byte lane stride
+// K1, 256-thread kernels (k1_variant 0..7).  VARIANT 0: mask algebra · 1: dwordx3 per lane · 2: 48-byte lane stride
 //      · 3: mask algebra, two tiles in flight per wave · 4: mask algebra, plain (temporal) loads
 //      · 5: mask algebra, each wave owns two ADJACENT tiles (6 KiB contiguous), six loads in flight
 //      · 6: mask algebra with software prefetch of the wave's next tile (compiler-scheduled)
