@@ -317,6 +317,46 @@ def test_grid_table_guess_growth_and_overflow(oracle):
             f.free()
 
 
+@pytest.mark.parametrize("cell", [1.0, 0.72, 0.25])
+def test_grid_shared_by_several_scans_with_guessed_tables(oracle, cell):
+    """Sequential mode (main.rs:129-133): ONE grid folds several files, first seen wins across them.  Large enough
+    scans for the guessed table size to be in play in every scan: the table carries cells over while it is enlarged
+    after a pass, re-hashed on overflow, or found large enough."""
+    n = 1_400_000
+    bmin, bmax = (-500.0, -500.0, -100.0), (500.0, 500.0, 100.0)
+    images, hdrs = [], []
+    for k in range(3):
+        img = oracle.synth_image(small_spec(9000 + k, n, fmt=2), transposed=True)
+        images.append(img)
+        hdrs.append(oracle.parse_header(img[:400].tobytes()))
+    og = oracle.grid_collector(bmin, bmax, cell)
+    for img in images:
+        assert oracle.search_last_bounds(img, bmin, bmax, og) == 0
+    with pkg.Context(0) as ctx:
+        gg = ctx.grid_collector(bmin, bmax, cell)
+        files = []
+        try:
+            first = 0
+            for img, hdr in zip(images, hdrs):
+                f = DevFile(ctx, img, hdr)
+                files.append(f)
+                lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+                cols = f.columns(True)
+                cols.first_index = first
+                ctx.scan_dev(cols, pkg.Predicate.bounds(lmin, lmax), gg)
+                first += n
+            assert gg.point_count() == og.point_count()
+            gp, gk = gg.points(), gg.grid_cells()
+            order = np.argsort(gk, kind="stable")
+            assert np.array_equal(gk[order], og.grid_cells())
+            assert gp[order].tobytes() == og.points().tobytes()
+        finally:
+            gg.free()
+            for f in files:
+                f.free()
+    og.free()
+
+
 def test_synth_device_generator_is_bit_identical(oracle, gpu_ctx):
     for spec in (small_spec(1, 100_003, zo=(3000, -9000, 18001)), specs.synth_ca13(50_001)[5], specs.synth_doc(40_000)[3],
                  specs.synth_navvis(30_011)[0]):
