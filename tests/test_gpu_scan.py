@@ -357,6 +357,36 @@ def test_grid_shared_by_several_scans_with_guessed_tables(oracle, cell):
     og.free()
 
 
+@pytest.mark.parametrize("cell", [1.0, 0.25])
+def test_grid_through_the_host_path_in_large_chunks(oracle, cell):
+    """pcq_scan_host of a 4 M-point file in staging chunks of 1.3 M points: every chunk is a scan of its own into the
+    same grid, each large enough for the guessed table size (the CLI's path for files on disk)."""
+    n = 4_000_003
+    bmin, bmax = (-500.0, -500.0, -100.0), (500.0, 500.0, 100.0)
+    image = oracle.synth_image(small_spec(31, n, fmt=2), transposed=True)
+    hdr = oracle.parse_header(image[:400].tobytes())
+    otp = hdr.offset_to_point_data
+    og = oracle.grid_collector(bmin, bmax, cell)
+    assert oracle.search_last_bounds(image, bmin, bmax, og) == 0
+    with pkg.Context(0) as ctx:
+        ctx.set_option("chunk_points", 1_300_000)
+        gg = ctx.grid_collector(bmin, bmax, cell)
+        try:
+            base = image.ctypes.data + otp
+            cols = binding.make_columns(xyz=base, cls=base + 15 * n, rgb=base + 20 * n, n=n, scale=list(hdr.scale),
+                                        offset=list(hdr.offset))
+            lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+            ctx.scan_host(cols, pkg.Predicate.bounds(lmin, lmax), gg)
+            assert gg.point_count() == og.point_count()
+            gp, gk = gg.points(), gg.grid_cells()
+            order = np.argsort(gk, kind="stable")
+            assert np.array_equal(gk[order], og.grid_cells())
+            assert gp[order].tobytes() == og.points().tobytes()
+        finally:
+            gg.free()
+    og.free()
+
+
 def test_synth_device_generator_is_bit_identical(oracle, gpu_ctx):
     for spec in (small_spec(1, 100_003, zo=(3000, -9000, 18001)), specs.synth_ca13(50_001)[5], specs.synth_doc(40_000)[3],
                  specs.synth_navvis(30_011)[0]):
