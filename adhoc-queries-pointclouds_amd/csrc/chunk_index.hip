@@ -260,6 +260,7 @@ struct pcq_index {
 };
 
 extern "C" int pcq_index_new(pcq_ctx *ctx, pcq_index **out) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx || !out) return pcq_fail(PCQ_ERR_ARG, "pcq_index_new: null argument");
     *out = nullptr;
     pcq_index *ix = new (std::nothrow) pcq_index();
@@ -276,6 +277,7 @@ extern "C" int pcq_index_new(pcq_ctx *ctx, pcq_index **out) {
 
 extern "C" int pcq_index_free(pcq_index *ix) {
     if (!ix) return PCQ_OK;
+    PCQ_ON_DEVICE_OF_CTX(ix->ctx);
     (void)hipDeviceSynchronize();
     if (ix->d_boxes) (void)hipFree(ix->d_boxes);
     if (ix->d_hist) (void)hipFree(ix->d_hist);
@@ -286,6 +288,7 @@ extern "C" int pcq_index_free(pcq_index *ix) {
 
 extern "C" int pcq_index_get_stats(pcq_index *ix, pcq_index_stats *out) {
     if (!ix || !out) return pcq_fail(PCQ_ERR_ARG, "pcq_index_get_stats: null argument");
+    PCQ_ON_DEVICE_OF_CTX(ix->ctx);
     if (ix->stats_stream) {  // the counters of the last indexed bounds scan are still on the device
         unsigned long long h[3] = {0, 0, 0};
         PCQ_HIP(hipStreamSynchronize(ix->stats_stream));
@@ -301,6 +304,7 @@ extern "C" int pcq_index_get_stats(pcq_index *ix, pcq_index_stats *out) {
 
 extern "C" int pcq_scan_dev_indexed(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_index *ix,
                                     pcq_collector *c, void *stream) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx || !cols || !pred || !ix || !c) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_dev_indexed: null argument");
     if (c->kind != COLL_COUNT) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_dev_indexed: count collectors only");
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;

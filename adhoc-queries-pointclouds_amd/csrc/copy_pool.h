@@ -48,28 +48,35 @@ public:
         size_t parts = bytes / kMinSlice;
         if (parts > workers_.size() + 1) parts = workers_.size() + 1;
         if (parts <= 1) return copy(fd, dst, src, bytes);
-        const size_t slice = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+        Job job;
+        job.fd = fd, job.dst = dst, job.src = src, job.bytes = bytes;
+        job.slice = ((bytes + parts - 1) / parts + 4095) & ~(size_t)4095;
+        job.nslices = (bytes + job.slice - 1) / job.slice;
         {
-            std::lock_guard<std::mutex> g(m_);
-            fd_ = fd;
-            dst_ = dst;
-            src_ = src;
-            bytes_ = bytes;
-            slice_ = slice;
-            nslices_ = (bytes + slice - 1) / slice;
+            // A job is published only while no helper is inside work(): a helper still spinning on the tickets of
+            // the previous job would otherwise draw a ticket of this one and copy it with the old job's geometry.
+            std::unique_lock<std::mutex> g(m_);
+            idle_.wait(g, [this] { return active_ == 0; });
+            job_ = job;
             next_.store(0, std::memory_order_relaxed);
-            pending_ = nslices_;
+            pending_ = job.nslices;
             result_ = 0;
             generation_++;
         }
         wake_.notify_all();
-        work();
+        work(job);
         std::unique_lock<std::mutex> g(m_);
         done_.wait(g, [this] { return pending_ == 0; });
         return result_;
     }
 
 private:
+    struct Job {
+        int fd = -1;
+        uint8_t *dst = nullptr;
+        const uint8_t *src = nullptr;
+        size_t bytes = 0, slice = 0, nslices = 0;
+    };
     static int copy(int fd, uint8_t *dst, const uint8_t *src, size_t bytes) {
         if (fd < 0) {
             memcpy(dst, src, bytes);
@@ -89,13 +96,14 @@ private:
         }
         return 0;
     }
-    void work() {
+    // `job` is the caller's own copy of the descriptor, taken under the mutex in the generation it belongs to
+    void work(const Job &job) {
         for (;;) {
             const size_t k = next_.fetch_add(1, std::memory_order_relaxed);
-            if (k >= nslices_) return;
-            const size_t at = k * slice_;
-            const size_t len = bytes_ - at < slice_ ? bytes_ - at : slice_;
-            const int r = copy(fd_, dst_ + at, src_ + at, len);
+            if (k >= job.nslices) return;
+            const size_t at = k * job.slice;
+            const size_t len = job.bytes - at < job.slice ? job.bytes - at : job.slice;
+            const int r = copy(job.fd, job.dst + at, job.src + at, len);
             std::lock_guard<std::mutex> g(m_);
             if (r && !result_) result_ = r;
             if (--pending_ == 0) done_.notify_all();
@@ -104,25 +112,29 @@ private:
     void loop() {
         uint64_t seen = 0;
         for (;;) {
+            Job job;
             {
                 std::unique_lock<std::mutex> g(m_);
                 wake_.wait(g, [&] { return stop_ || generation_ != seen; });
                 if (stop_) return;
                 seen = generation_;
+                job = job_;
+                active_++;
             }
-            work();
+            work(job);
+            std::lock_guard<std::mutex> g(m_);
+            if (--active_ == 0) idle_.notify_all();
         }
     }
 
     std::vector<std::thread> workers_;
     std::mutex m_;
-    std::condition_variable wake_, done_;
+    std::condition_variable wake_, done_, idle_;
     bool stop_ = false;
     uint64_t generation_ = 0;
-    int fd_ = -1;
-    uint8_t *dst_ = nullptr;
-    const uint8_t *src_ = nullptr;
-    size_t bytes_ = 0, slice_ = 0, nslices_ = 0, pending_ = 0;
+    Job job_;
+    size_t pending_ = 0;
+    int active_ = 0;  // helpers inside work()
     std::atomic<size_t> next_{0};
     int result_ = 0;
 };

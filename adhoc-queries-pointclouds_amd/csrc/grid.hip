@@ -1,43 +1,94 @@
-// grid.hip — GridSampledCollector / SparseGrid on the device (kernel K4).
+// grid.hip — GridSampledCollector / SparseGrid on the device (kernel K4): partition by cell key, fold in LDS.
 //
-// Restates query/src/grid_sampling.rs:49-105 (SparseGrid::insert_point) for a massively parallel
-// device.  The reference folds points sequentially into a HashMap<u64, Point>: a cell keeps the point
-// closest to the cell centre, replaced only when a later point is STRICTLY closer, so the earliest
-// point in file order wins ties.  For every cell key whose points all fall into the same unmasked
-// cell (always, except the mask-aliasing case below) that fold is the lexicographic arg-min of
-// (squared distance, file-order index), computed here in three order-independent passes over the
-// matched points against an open-addressing hash table in HBM:
-// (one 32-byte slot per cell: key, distance, winner index, flags — one random access per probe):
-//   A  insert key; atomicMin of the f64 distance bits (monotone for d >= 0); a slot whose minimum
-//      was lowered in this scan has its winner index reset;
-//   B  points whose distance equals the slot minimum: atomicMin of the file-order index; the first
-//      such point of a cell materialises its 31-byte Point at once (it is almost always the only one);
-//   C  only when pass B saw an exact distance tie: the winners are re-derived from the final indices.
-// Scans into one collector are issued in file order with increasing `first_index`, which keeps
-// "first seen wins" across chunks and across files (sequential mode, main.rs:129-133).
+// Restates query/src/grid_sampling.rs:49-105 (SparseGrid::insert_point).  The reference folds points sequentially
+// into a HashMap<u64, Point>: a cell keeps the point closest to the cell centre, replaced only when a later point is
+// STRICTLY closer, so the earliest point in file order wins ties.  For every cell key whose points all fall into the
+// same unmasked cell (always, except the mask-aliasing case below) that fold is the lexicographic arg-min of
+// (squared distance, file-order index).
 //
-// Mask aliasing (grid_sampling.rs:62-82): the key masks each axis to `bits`, but the cell centre
-// uses the UNMASKED cell, so a cell >= 2^bits folds onto another key while comparing against a
-// different centre.  For such keys the result depends on the visiting order; they are flagged in
-// pass A and re-folded exactly, in file order, by pass R (one thread per flagged key).
+// A hash table in HBM costs one random 128-byte line per matched point (round 1: 29 ms per 163 M-point file at 10 m,
+// ~40 x the algorithmic bytes).  Here the random access happens in LDS instead:
+//   pass 0  (per scan, asynchronous)  a counting-sort partition of the matched points by the high bits of hash(key)
+//           into F1 = 512 bins: k_p0_hist counts per (workgroup, bin), two small scan kernels turn the counts into
+//           exact offsets, and k_p0_scatter writes one 24-byte tuple {x, y, z, index, class | entry | colour} per
+//           match into its bin.  Every workgroup owns a private, contiguous piece of every bin — no global atomics, no
+//           slack, no overflow — and a tile's tuples are sorted by bin in LDS first, so that they leave as contiguous
+//           runs (scattered 24-byte stores were measured at 1.2 TB/s: profiles/r02_grid_first_cut_kernel_stats.txt).
+//   fold    (lazy: when a result is asked for, or when too much is pending)  one workgroup per partition folds its
+//           tuples into an open-addressing table in LDS — atomicMin on the f64 distance bits, then on the file-order
+//           index among the tuples at the minimum, then the winner parks its payload — and writes one 32-byte record
+//           + key per cell, coalesced.  A coarse grid folds its level-1 bins directly (k_fold<BIG>: a CU's whole LDS
+//           as one 6400-slot table); a denser grid first gets a second partition level (k_level2, fan-out chosen from
+//           a measured estimate of the distinct cells per bin) and folds the small partitions three to a CU
+//           (k_fold<SMALL>).
+// The folded winners are kept grouped by partition, so a later fold (more scans into the same collector: sequential
+// mode shares one grid, main.rs:129-133; a file streamed in chunks) merges them with the new tuples partition by
+// partition: an old winner is earlier in file order than every new tuple and its distance is recomputed from its
+// record, bit for bit.
 //
-// HBM-bound random access (one 8-byte atomic + probes per matched point); not reshaped into GEMMs.
+// Mask aliasing (grid_sampling.rs:62-82): the key masks each axis to `bits`, but the cell centre uses the UNMASKED
+// cell, so a cell >= 2^bits folds onto another key while comparing against a different centre.  For such keys the
+// result depends on the visiting order; their slots are flagged during the fold and the key is re-folded exactly,
+// in file order, from its tuples (k_alias_*: gather, rank sort, sequential replay of insert_point).
+//
+// Integer / f64 work bound by HBM streaming (tuples written once and read once or twice); not reshaped into GEMMs.
+#include <algorithm>
+#include <cmath>
+
 #include "dev_common.h"
 
 using namespace pcqdev;
 
-int pcq_emit_prepare(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint64_t *matches, hipStream_t s);
-
 namespace {
 
-// The count of occupied slots is kept in OCC_SHARDS counters on separate 128-byte lines (one
-// same-address atomic per inserting wave would serialise at ~88 atomics/us: 122 M new cells = 2 M waves).
-constexpr int OCC_SHARDS = 256;
-constexpr int OCC_STRIDE = 16;  // u64 units between shards
-constexpr size_t OCC_WORDS = (size_t)OCC_SHARDS * OCC_STRIDE + 16;  // + n_alias and padding
+constexpr int F1_BITS = 9;
+constexpr int F1 = 1 << F1_BITS;       // level-1 bins: the top F1_BITS bits of hash(key)
+constexpr int F2_MAX = 4096;           // largest second-level fan-out
+constexpr int P0_NT = 512;             // pass 0: threads per workgroup
+constexpr int P0_ITEMS = 5;            // pass 0: points per thread and tile
+constexpr int P0_TILE = P0_NT * P0_ITEMS;  // 2560 points: their tuples (60 KB) are staged in LDS, two workgroups per CU
+constexpr int P0_MAX_BLOCKS = 1024;    // pass 0: at most this many workgroups (rows of the count table)
+// The fold comes in two shapes.  BIG: one 1024-thread workgroup owns a CU's whole LDS — 6400 slots of {key, distance,
+// file order}, the winner's payload parked in HBM scratch — and folds a level-1 bin directly (coarse grids: few cells,
+// many tuples per cell).  SMALL: 1024 slots with the payload in LDS, three 256-thread workgroups per CU, for the
+// partitions a second level cuts out of a dense grid (about one tuple per cell: many small partitions, latency-bound).
+constexpr int BIG_SLOTS = 6400, BIG_NT = 1024, BIG_LIMIT = 5440, BIG_DIRECT = 4700;
+constexpr int SMALL_SLOTS = 1024, SMALL_NT = 256, SMALL_LIMIT = 870, SMALL_TARGET = 600;
+constexpr int FOLD_K = 4;              // fold: tuples per thread and chunk
+constexpr int L2_NT = 512;             // second level: threads per workgroup (one workgroup per level-1 bin)
+constexpr int PROBE_BINS = 2;          // bins whose distinct cells are counted to estimate the grid's density
+constexpr int MAX_RUNS = 1024;         // pending pass-0 runs per collector before a fold is forced
+constexpr uint64_t RUN_POINTS = 1ull << 30;  // points per pass-0 run (tuple offsets are 32-bit)
 
-constexpr uint8_t F_HAS_POINT = 1;  // pts[slot] holds a materialised winner
-constexpr uint8_t F_ALIAS = 2;      // key has seen a point whose unmasked cell differs from the masked one
+constexpr uint8_t R_HAS = 1;    // byte 31 of a winner record: the record holds a point
+constexpr uint8_t R_ALIAS = 2;  // the key has seen a point whose unmasked cell differs from the masked one (sticky)
+
+// One matched point on its way to the fold.  `idx` is the file-order index relative to its entry's base index.
+struct __attribute__((aligned(8))) GridTuple {
+    int32_t x, y, z;
+    uint32_t idx;
+    uint32_t w0;  // classification | entry << 8 | red << 16
+    uint32_t w1;  // green | blue << 16
+};
+static_assert(sizeof(GridTuple) == 24, "tuple layout");
+
+// What turns a tuple's integers back into a position: the header scale / offset of the file it came from
+// (last.rs:156-160).  Consecutive scans with the same scale and offset share one entry.
+struct GridEntryDev {
+    double scale[3], offset[3];
+};
+
+// A list of tuples cut into partitions: partition p is tuples[off[p] .. off[p + 1]).
+struct GridSeg {
+    const GridTuple *tuples;
+    const uint32_t *off;
+};
+
+struct AliasItem {  // a tuple of an aliased key, for the exact replay
+    uint64_t key, ord;
+    int32_t x, y, z;
+    uint32_t w0, w1, _pad;
+};
 
 struct CellInfo {
     uint64_t key;
@@ -65,8 +116,7 @@ __device__ __forceinline__ CellInfo cell_of(const DevGrid &g, double px, double 
 }
 
 // grid_sampling.rs:78-95 — squared distance of (px,py,pz) to the centre of the unmasked cell.
-__device__ __forceinline__ double centre_dist(const DevGrid &g, const uint64_t (&cell)[3], double px, double py,
-                                              double pz) {
+__device__ __forceinline__ double centre_dist(const DevGrid &g, const uint64_t (&cell)[3], double px, double py, double pz) {
     const double cx = ((double)cell[0] + 0.5) * g.cell_size + g.bmin[0];
     const double cy = ((double)cell[1] + 0.5) * g.cell_size + g.bmin[1];
     const double cz = ((double)cell[2] + 0.5) * g.cell_size + g.bmin[2];
@@ -75,634 +125,1204 @@ __device__ __forceinline__ double centre_dist(const DevGrid &g, const uint64_t (
     return (a + b) + c;
 }
 
-// A table sized from a guess (see pcq_grid_scan) may fill up.  An insert that finds its occupancy shard beyond
-// `shard_limit` (the shards fill evenly, so this is "load factor beyond ~0.6"), or that has probed `probe_limit`
-// slots, or sees that another insert has given up, raises the overflow word (n_alias[2]) and gives up — the host
-// then re-runs the pass against a table of the guaranteed size (both limits 2^64-1 there: never gives up).
-__device__ __forceinline__ uint64_t find_or_insert(const DevGridTable &t, uint64_t key, uint64_t probe_limit, uint64_t shard_limit) {
-    const uint64_t m = t.cap - 1;
-    uint64_t h = hash64(key) & m;
-    uint64_t probes = 0;
-    for (;;) {
-        if ((++probes & 63) == 0 &&
-            (probes >= probe_limit || __hip_atomic_load(t.n_alias + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-            __hip_atomic_store(t.n_alias + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return PCQ_NO_INDEX;
+// hash(key) picks the level-1 bin (bits 63..53), the second-level partition (bits 52..21) and the first LDS slot (bits 20..0)
+__device__ __forceinline__ uint32_t bin_of(uint64_t h) { return (uint32_t)(h >> (64 - F1_BITS)); }
+__device__ __forceinline__ uint32_t sub_of(uint64_t h, uint32_t f2) { return (uint32_t)((((h >> 21) & 0xffffffffull) * f2) >> 32); }
+template <int NSLOT>
+__device__ __forceinline__ uint32_t slot_of(uint64_t h) { return (uint32_t)(((h & 0x1fffffull) * NSLOT) >> 21); }
+
+__device__ __forceinline__ GridTuple ld_tuple(const GridTuple *p) {
+    const uint2 *q = reinterpret_cast<const uint2 *>(p);
+    const uint2 a = q[0], b = q[1], c = q[2];
+    GridTuple t;
+    t.x = (int32_t)a.x, t.y = (int32_t)a.y, t.z = (int32_t)b.x, t.idx = b.y, t.w0 = c.x, t.w1 = c.y;
+    return t;
+}
+__device__ __forceinline__ void st_tuple(GridTuple *p, const GridTuple &t) {
+    uint2 *q = reinterpret_cast<uint2 *>(p);
+    q[0] = make_uint2((uint32_t)t.x, (uint32_t)t.y);
+    q[1] = make_uint2((uint32_t)t.z, t.idx);
+    q[2] = make_uint2(t.w0, t.w1);
+}
+
+struct TupleEval {
+    uint64_t key, dbits;
+    bool alias;
+};
+__device__ __forceinline__ TupleEval eval_tuple(const DevGrid &g, const GridEntryDev *__restrict__ entries, const GridTuple &t) {
+    const GridEntryDev &e = entries[(t.w0 >> 8) & 0xff];
+    const double px = world(t.x, e.scale[0], e.offset[0]), py = world(t.y, e.scale[1], e.offset[1]), pz = world(t.z, e.scale[2], e.offset[2]);
+    const CellInfo ci = cell_of(g, px, py, pz);
+    TupleEval r;
+    r.key = ci.key;
+    r.alias = ci.alias;
+    r.dbits = (uint64_t)__double_as_longlong(centre_dist(g, ci.cell, px, py, pz));
+    return r;
+}
+// file order among tuples: entries are numbered in scan order; 0 is reserved for an earlier fold's winner
+__device__ __forceinline__ uint64_t ord_of(const GridTuple &t) { return ((uint64_t)((t.w0 >> 8) & 0xff) << 32 | t.idx) + 1; }
+
+// The 32-byte winner record: pcq_point (31 bytes) + flag byte.
+__device__ __forceinline__ void st_record(uint8_t *dst32, const GridEntryDev &e, int32_t x, int32_t y, int32_t z, uint32_t w0, uint32_t w1,
+                                          uint8_t flags) {
+    const uint64_t bx = (uint64_t)__double_as_longlong(world(x, e.scale[0], e.offset[0])),
+                   by = (uint64_t)__double_as_longlong(world(y, e.scale[1], e.offset[1])),
+                   bz = (uint64_t)__double_as_longlong(world(z, e.scale[2], e.offset[2]));
+    uint4 a, b;
+    a.x = (uint32_t)bx, a.y = (uint32_t)(bx >> 32), a.z = (uint32_t)by, a.w = (uint32_t)(by >> 32);
+    b.x = (uint32_t)bz, b.y = (uint32_t)(bz >> 32);
+    b.z = (w0 >> 16) | (w1 << 16);                                          // red, green
+    b.w = (w1 >> 16) | ((w0 & 0xffu) << 16) | ((uint32_t)flags << 24);      // blue, classification, flags
+    uint4 *d = reinterpret_cast<uint4 *>(dst32);
+    d[0] = a;
+    d[1] = b;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 0: counting-sort partition of the matched points of one scan
+// ---------------------------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ uint64_t point_hash(const DevCols &c, const DevGrid &g, const RawPoint &rp) {
+    const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]), pz = world(rp.z, c.scale[2], c.offset[2]);
+    return hash64(cell_of(g, px, py, pz).key);
+}
+
+// Workgroup b owns the points [b * per_block, (b + 1) * per_block): cnt[b][bin] = its matches per level-1 bin.
+template <int KIND>
+__global__ __launch_bounds__(P0_NT) void k_p0_hist(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, uint32_t *__restrict__ cnt) {
+    __shared__ uint32_t hist[F1];
+    for (int t = threadIdx.x; t < F1; t += P0_NT) hist[t] = 0;
+    __syncthreads();
+    const uint64_t begin = (uint64_t)blockIdx.x * per_block;
+    const uint64_t end = begin + per_block < c.n ? begin + per_block : c.n;
+    for (uint64_t base = begin; base < end; base += P0_TILE) {
+        RawPoint rps[P0_ITEMS];
+        bool passes[P0_ITEMS];
+#pragma unroll
+        for (int j = 0; j < P0_ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
+            passes[j] = eval_pred_kind<KIND>(c, pr, i < end ? i : end - 1, rps[j]) & (i < end);
         }
-        uint64_t k = __hip_atomic_load(&t.slots[h].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k == key) return h;
-        if (k == PCQ_EMPTY_KEY) {
-            const uint64_t prev = atomicCAS((unsigned long long *)&t.slots[h].key, (unsigned long long)PCQ_EMPTY_KEY,
-                                            (unsigned long long)key);
-            if (prev == PCQ_EMPTY_KEY) {
-                const uint64_t in_shard = atomicAdd((unsigned long long *)&t.occupied[(blockIdx.x & (OCC_SHARDS - 1)) * OCC_STRIDE], 1ull);
-                if (in_shard >= shard_limit) {
-                    __hip_atomic_store(t.n_alias + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return PCQ_NO_INDEX;  // the key stays inserted; the re-run finds it
-                }
-                return h;
+#pragma unroll
+        for (int j = 0; j < P0_ITEMS; j++) {
+            if (!passes[j]) continue;
+            if (KIND == PCQ_PRED_CLASS) rps[j] = ld_xyz(c, base + (uint64_t)j * P0_NT + threadIdx.x);
+            atomicAdd(&hist[bin_of(point_hash<KIND>(c, g, rps[j]))], 1u);
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < F1; t += P0_NT) cnt[(size_t)blockIdx.x * F1 + t] = hist[t];
+}
+
+// cnt[b][bin] -> exclusive prefix over the workgroups b, per bin (one wave per bin); total[bin] = the bin's tuples.
+__global__ __launch_bounds__(BLOCK) void k_p0_scan_blocks(uint32_t *__restrict__ cnt, int nblocks, uint32_t *__restrict__ total) {
+    const int lane = threadIdx.x & 63;
+    const int bin = blockIdx.x * WAVES + (threadIdx.x >> 6);
+    uint32_t running = 0;
+    for (int b0 = 0; b0 < nblocks; b0 += 64) {
+        const int b = b0 + lane;
+        const uint32_t v = b < nblocks ? cnt[(size_t)b * F1 + bin] : 0;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (b < nblocks) cnt[(size_t)b * F1 + bin] = running + incl - v;
+        running += __shfl(incl, 63, 64);
+    }
+    if (lane == 0) total[bin] = running;
+}
+
+// out[0..n] = exclusive prefix of in[0..n) (out[n] = the sum); one workgroup, any n.
+__global__ __launch_bounds__(1024) void k_excl_scan_u32(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, uint32_t n) {
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t per = (n + 1023) / 1024;  // a contiguous piece per thread
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint32_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += in[i];
+    uint32_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t wave_off = 0;
+    for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+    uint32_t run = wave_off + incl - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 1023) s_carry = wave_off + incl;
+    __syncthreads();
+    if (threadIdx.x == 0) out[n] = s_carry;
+}
+
+__global__ __launch_bounds__(1024) void k_excl_scan_u64(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t n) {
+    __shared__ uint64_t s_wave[16];
+    __shared__ uint64_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t per = (n + 1023) / 1024;
+    const uint32_t lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+    uint64_t sum = 0;
+    for (uint32_t i = lo; i < hi; i++) sum += in[i];
+    uint64_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t up = __shfl_up((unsigned long long)incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t wave_off = 0;
+    for (int w = 0; w < wave; w++) wave_off += s_wave[w];
+    uint64_t run = wave_off + incl - sum;
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint64_t v = in[i];
+        out[i] = run;
+        run += v;
+    }
+    if (threadIdx.x == 1023) s_carry = wave_off + incl;
+    __syncthreads();
+    if (threadIdx.x == 0) out[n] = s_carry;
+}
+
+// The second reading of the scan: every match becomes a tuple at binoff[bin] + (workgroup's offset in the bin) + rank.
+// Per tile of 2560 points: the matches take a rank in their bin (LDS atomics), the tile's tuples are laid out in LDS
+// sorted by bin, and the sorted image is copied out 8 bytes per lane — consecutive lanes write consecutive words of a
+// bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.
+template <int KIND>
+__global__ __launch_bounds__(P0_NT) void k_p0_scatter(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
+                                                      const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out, uint32_t entry,
+                                                      uint64_t idx_base) {
+    static_assert(F1 == P0_NT, "one thread per bin in the per-tile scan");
+    __shared__ uint2 s_stage[P0_TILE * 3];   // the tile's tuples, sorted by bin (three 8-byte words each)
+    __shared__ uint16_t s_tbin[P0_TILE];     // bin of the staged tuple
+    __shared__ uint32_t s_cnt[F1], s_base[F1], s_gpos[F1], s_cur[F1], s_wsum[P0_NT / 64];
+    __shared__ uint32_t s_total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s_cur[threadIdx.x] = binoff[threadIdx.x] + cnt_excl[(size_t)blockIdx.x * F1 + threadIdx.x];
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t begin = (uint64_t)blockIdx.x * per_block;
+    const uint64_t end = begin + per_block < c.n ? begin + per_block : c.n;
+    for (uint64_t base = begin; base < end; base += P0_TILE) {
+        RawPoint rps[P0_ITEMS];
+        bool passes[P0_ITEMS];
+        uint32_t bins[P0_ITEMS], ranks[P0_ITEMS];
+#pragma unroll
+        for (int j = 0; j < P0_ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
+            passes[j] = eval_pred_kind<KIND>(c, pr, i < end ? i : end - 1, rps[j]) & (i < end);
+        }
+#pragma unroll
+        for (int j = 0; j < P0_ITEMS; j++) {
+            if (!passes[j]) continue;
+            if (KIND == PCQ_PRED_CLASS) rps[j] = ld_xyz(c, base + (uint64_t)j * P0_NT + threadIdx.x);
+            bins[j] = bin_of(point_hash<KIND>(c, g, rps[j]));
+            ranks[j] = atomicAdd(&s_cnt[bins[j]], 1u);
+        }
+        __syncthreads();
+        {  // exclusive scan of the tile's counts over the bins (thread t = bin t); the workgroup's cursors move on
+            const uint32_t v = s_cnt[threadIdx.x];
+            uint32_t incl = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
             }
-            if (prev == key) return h;
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = incl - v, total = 0;
+            for (int w = 0; w < P0_NT / 64; w++) {
+                before += w < wave ? s_wsum[w] : 0;
+                total += s_wsum[w];
+            }
+            s_base[threadIdx.x] = before;
+            s_gpos[threadIdx.x] = s_cur[threadIdx.x];
+            s_cur[threadIdx.x] += v;
+            s_cnt[threadIdx.x] = 0;
+            if (threadIdx.x == 0) s_total = total;
         }
-        h = (h + 1) & m;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < P0_ITEMS; j++) {
+            if (!passes[j]) continue;
+            const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
+            uint32_t r = 0, gg = 0, b = 0;
+            if (c.rgb) {  // last.rs:145-153
+                const uint8_t *q = c.rgb + i * c.rgb_stride;
+                r = ld_u16(q), gg = ld_u16(q + 2), b = ld_u16(q + 4);
+            }
+            const uint32_t cls = c.cls ? c.cls[i * c.cls_stride] : 0;  // last.rs:138-142
+            const uint32_t at = s_base[bins[j]] + ranks[j];
+            s_stage[at * 3] = make_uint2((uint32_t)rps[j].x, (uint32_t)rps[j].y);
+            s_stage[at * 3 + 1] = make_uint2((uint32_t)rps[j].z, (uint32_t)(idx_base + i));
+            s_stage[at * 3 + 2] = make_uint2(cls | (entry << 8) | (r << 16), gg | (b << 16));
+            s_tbin[at] = (uint16_t)bins[j];
+        }
+        __syncthreads();
+        const uint32_t words = s_total * 3;
+        uint2 *out2 = reinterpret_cast<uint2 *>(out);
+        for (uint32_t w = threadIdx.x; w < words; w += P0_NT) {
+            const uint32_t t = w / 3, k = w - t * 3, bin = s_tbin[t];
+            out2[(uint64_t)(s_gpos[bin] + (t - s_base[bin])) * 3 + k] = s_stage[w];
+        }
+        __syncthreads();  // the stage and the bases are rewritten by the next tile
     }
 }
 
-__device__ __forceinline__ uint64_t find_slot(const DevGridTable &t, uint64_t key) {
-    const uint64_t m = t.cap - 1;
-    uint64_t h = hash64(key) & m;
-    for (;;) {
-        const uint64_t k = t.slots[h].key;
-        if (k == key) return h;
-        if (k == PCQ_EMPTY_KEY) return PCQ_NO_INDEX;  // cannot happen after pass A
-        h = (h + 1) & m;
+// ---------------------------------------------------------------------------------------------------------------
+// fold preparation
+// ---------------------------------------------------------------------------------------------------------------
+// tot[p] = tuples of partition p over all segments.
+__global__ __launch_bounds__(BLOCK) void k_part_totals(const GridSeg *__restrict__ segs, int nsegs, uint32_t nparts, uint32_t *__restrict__ tot) {
+    const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= nparts) return;
+    uint32_t t = 0;
+    for (int r = 0; r < nsegs; r++) t += segs[r].off[p + 1] - segs[r].off[p];
+    tot[p] = t;
+}
+
+// Room for the winners of partition p: never more than its inputs, never more than the LDS table holds.
+__global__ __launch_bounds__(BLOCK) void k_winner_room(const uint32_t *__restrict__ tot, const uint32_t *__restrict__ ocount, uint32_t nparts,
+                                                       uint32_t limit, uint64_t *__restrict__ room) {
+    const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= nparts) return;
+    const uint64_t in = (uint64_t)tot[p] + (ocount ? ocount[p] : 0);
+    room[p] = in < limit ? in : limit;
+}
+
+// Exclusive prefix of up to a few hundred thousand u64 in three small launches (a single workgroup walking 200 k
+// partitions took 0.2 ms): sums of 4096-element pieces, their prefix, the pieces again.
+constexpr int SCAN_PIECE = 4096;
+__global__ __launch_bounds__(1024) void k_scan_piece_sums(const uint64_t *__restrict__ in, uint32_t n, uint64_t *__restrict__ sums) {
+    __shared__ uint64_t s_wave[16];
+    const uint32_t base = blockIdx.x * SCAN_PIECE;
+    uint64_t v = 0;
+    for (int k = 0; k < SCAN_PIECE / 1024; k++) {
+        const uint32_t i = base + k * 1024 + threadIdx.x;
+        v += i < n ? in[i] : 0;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down((unsigned long long)v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < 16; w++) t += s_wave[w];
+        sums[blockIdx.x] = t;
+    }
+}
+// out[i] = piece_prefix[piece] + exclusive prefix inside the piece; thread t owns 4 consecutive elements; out[n] = total
+__global__ __launch_bounds__(1024) void k_scan_pieces(const uint64_t *__restrict__ in, uint32_t n, const uint64_t *__restrict__ piece_prefix,
+                                                      uint64_t *__restrict__ out) {
+    __shared__ uint64_t s_wave[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t i0 = blockIdx.x * SCAN_PIECE + threadIdx.x * 4;
+    uint64_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v[k] = i0 + k < n ? in[i0 + k] : 0;
+        sum += v[k];
+    }
+    uint64_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t up = __shfl_up((unsigned long long)incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t run = piece_prefix[blockIdx.x] + incl - sum;
+    for (int w = 0; w < wave; w++) run += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (i0 + k < n) out[i0 + k] = run;
+        run += v[k];
+        if (i0 + k + 1 == n) out[n] = run;
     }
 }
 
-struct Matched {
-    bool pass;
-    double px, py, pz;
-    RawPoint rp;
+// Distinct cells among the tuples of the first PROBE_BINS level-1 bins (a global hash set; one thread per tuple).
+__global__ __launch_bounds__(BLOCK) void k_probe_distinct(const GridSeg *__restrict__ segs, const GridEntryDev *__restrict__ entries, DevGrid g,
+                                                          uint64_t *__restrict__ set, uint64_t mask, unsigned long long *__restrict__ distinct) {
+    const GridSeg sg = segs[blockIdx.y];
+    const uint32_t lo = sg.off[0], hi = sg.off[PROBE_BINS];
+    uint32_t mine = 0;
+    for (uint32_t i = lo + blockIdx.x * BLOCK + threadIdx.x; i < hi; i += gridDim.x * BLOCK) {
+        const GridTuple t = ld_tuple(sg.tuples + i);
+        const uint64_t key = eval_tuple(g, entries, t).key;
+        uint64_t h = hash64(key) & mask;
+        for (;;) {
+            const uint64_t k = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == key) break;
+            if (k == PCQ_EMPTY_KEY) {
+                const uint64_t prev = atomicCAS((unsigned long long *)&set[h], (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key);
+                if (prev == PCQ_EMPTY_KEY) {
+                    mine++;
+                    break;
+                }
+                if (prev == key) break;
+            }
+            h = (h + 1) & mask;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(distinct, (unsigned long long)mine);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// second partition level: one workgroup per level-1 bin cuts the bin's tuples (and, when the fan-out changes, the
+// earlier winners of the bin) into f2 partitions by the next bits of hash(key).  Histogram in LDS, then scatter.
+// ---------------------------------------------------------------------------------------------------------------
+struct Level2Params {
+    const GridSeg *segs;
+    int nsegs;
+    const GridEntryDev *entries;
+    DevGrid g;
+    uint32_t f2;
+    const uint32_t *binbase;  // [F1 + 1] tuples in front of each bin (prefix over all segments); nullptr: tuples are not moved
+    GridTuple *out;
+    uint32_t *off2;           // [F1 * f2 + 1]
+    // earlier winners, re-cut from f2old partitions per bin into f2 (nullptr: not moved)
+    const uint64_t *okeys;
+    const uint8_t *orecs;
+    const uint64_t *obase;    // [F1 * f2old + 1]
+    const uint32_t *ocount;   // [F1 * f2old]
+    uint32_t f2old;
+    const uint32_t *obinbase; // [F1 + 1] earlier winners in front of each bin
+    uint64_t *okeys2;
+    uint8_t *orecs2;
+    uint32_t *ooff2;          // [F1 * f2 + 1]
 };
 
-__device__ __forceinline__ Matched match_point(const DevCols &c, const DevPred &pr, uint64_t i) {
-    Matched m;
-    bool have = false;
-    m.pass = i < c.n && eval_pred(c, pr, i, m.rp, have);
-    if (m.pass) {
-        if (!have) m.rp = ld_xyz(c, i);
-        m.px = world(m.rp.x, c.scale[0], c.offset[0]);
-        m.py = world(m.rp.y, c.scale[1], c.offset[1]);
-        m.pz = world(m.rp.z, c.scale[2], c.offset[2]);
-    }
-    return m;
-}
-
-// The three passes stream the whole scan range but usually work on few of its points, so each thread takes
-// GRID_BATCH points per step: the predicate inputs of all of them are loaded together (kind fixed at compile
-// time: straight-line code), then the matches are folded one by one.
-constexpr int GRID_BATCH = 4;
-
-template <int KIND, typename F>
-__device__ __forceinline__ void for_each_match(const DevCols &c, const DevPred &pr, F &&body) {
-    const uint64_t step = (uint64_t)gridDim.x * BLOCK * GRID_BATCH;
-    for (uint64_t base = (uint64_t)blockIdx.x * BLOCK * GRID_BATCH + threadIdx.x; base < c.n; base += step) {
-        RawPoint rps[GRID_BATCH];
-        bool passes[GRID_BATCH];
-#pragma unroll
-        for (int j = 0; j < GRID_BATCH; j++) {
-            const uint64_t i = base + (uint64_t)j * BLOCK;
-            passes[j] = eval_pred_kind<KIND>(c, pr, i < c.n ? i : c.n - 1, rps[j]) & (i < c.n);
+__global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
+    __shared__ uint32_t s_hist[F2_MAX], s_cur[F2_MAX], s_ohist[F2_MAX], s_ocur[F2_MAX];
+    const uint32_t bin = blockIdx.x, f2 = P.f2;
+    for (uint32_t t = threadIdx.x; t < F2_MAX; t += L2_NT) s_hist[t] = 0, s_ohist[t] = 0;
+    __syncthreads();
+    if (P.binbase)
+        for (int r = 0; r < P.nsegs; r++) {
+            const GridSeg sg = P.segs[r];
+            const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
+            for (uint32_t i = lo + threadIdx.x; i < hi; i += L2_NT)
+                atomicAdd(&s_hist[sub_of(hash64(eval_tuple(P.g, P.entries, ld_tuple(sg.tuples + i)).key), f2)], 1u);
         }
-#pragma unroll
-        for (int j = 0; j < GRID_BATCH; j++) {
-            if (!passes[j]) continue;
-            const uint64_t i = base + (uint64_t)j * BLOCK;
-            if (KIND == PCQ_PRED_CLASS) rps[j] = ld_xyz(c, i);
-            if (!body(i, rps[j])) return;
+    if (P.okeys)
+        for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
+            const uint64_t base = P.obase[q];
+            const uint32_t n = P.ocount[q];
+            for (uint32_t i = threadIdx.x; i < n; i += L2_NT) atomicAdd(&s_ohist[sub_of(hash64(P.okeys[base + i]), f2)], 1u);
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // f2 <= 256: a serial prefix is a few hundred LDS reads
+        uint32_t run = P.binbase ? P.binbase[bin] : 0, orun = P.okeys ? P.obinbase[bin] : 0;
+        for (uint32_t s = 0; s < f2; s++) {
+            if (P.binbase) P.off2[bin * f2 + s] = run;
+            s_cur[s] = run;
+            run += s_hist[s];
+            if (P.okeys) P.ooff2[bin * f2 + s] = orun;
+            s_ocur[s] = orun;
+            orun += s_ohist[s];
+        }
+        if (bin == F1 - 1) {
+            if (P.binbase) P.off2[F1 * f2] = run;
+            if (P.okeys) P.ooff2[F1 * f2] = orun;
         }
     }
+    __syncthreads();
+    if (P.binbase)
+        for (int r = 0; r < P.nsegs; r++) {
+            const GridSeg sg = P.segs[r];
+            const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
+            for (uint32_t i = lo + threadIdx.x; i < hi; i += L2_NT) {
+                const GridTuple t = ld_tuple(sg.tuples + i);
+                const uint32_t pos = atomicAdd(&s_cur[sub_of(hash64(eval_tuple(P.g, P.entries, t).key), f2)], 1u);
+                st_tuple(P.out + pos, t);
+            }
+        }
+    if (P.okeys)
+        for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
+            const uint64_t base = P.obase[q];
+            const uint32_t n = P.ocount[q];
+            for (uint32_t i = threadIdx.x; i < n; i += L2_NT) {
+                const uint64_t key = P.okeys[base + i];
+                const uint32_t pos = atomicAdd(&s_ocur[sub_of(hash64(key), f2)], 1u);
+                P.okeys2[pos] = key;
+                const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + (base + i) * 32);
+                uint4 *dp = reinterpret_cast<uint4 *>(P.orecs2 + (uint64_t)pos * 32);
+                dp[0] = sp[0];
+                dp[1] = sp[1];
+            }
+        }
 }
 
-// Pass A.  Besides folding the distances it writes the scan's CANDIDATE bitmap (bit i%64 of word i/64): a matched
-// point whose distance was <= the slot minimum it saw.  The minimum only falls, so every point that ends at the
-// final minimum is a candidate; for a coarse grid that is a few points per cell (the harmonic number of the cell's
-// population), and pass B reads only those.
-template <int KIND>
-__global__ __launch_bounds__(BLOCK) void k_grid_pass_a(DevCols c, DevPred pr, DevGrid g, DevGridTable t, uint64_t probe_limit,
-                                                       uint64_t shard_limit, uint64_t *__restrict__ cand) {
-    const uint64_t step = (uint64_t)gridDim.x * BLOCK * GRID_BATCH;
-    const int lane = threadIdx.x & 63;
-    // wave-uniform trip count (the wave's first index decides): the ballots below need the whole wave
-    for (uint64_t base = (uint64_t)blockIdx.x * BLOCK * GRID_BATCH + threadIdx.x; base - lane < c.n; base += step) {
-        RawPoint rps[GRID_BATCH];
-        bool passes[GRID_BATCH];
-#pragma unroll
-        for (int j = 0; j < GRID_BATCH; j++) {
-            const uint64_t i = base + (uint64_t)j * BLOCK;
-            passes[j] = eval_pred_kind<KIND>(c, pr, i < c.n ? i : c.n - 1, rps[j]) & (i < c.n);
+// ocount2[p] = ooff2[p + 1] - ooff2[p], obase2[p] = ooff2[p]   (the re-cut winners are packed)
+__global__ __launch_bounds__(BLOCK) void k_unpack_old_dir(const uint32_t *__restrict__ ooff2, uint32_t nparts, uint64_t *__restrict__ obase2,
+                                                          uint32_t *__restrict__ ocount2) {
+    const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p > nparts) return;
+    obase2[p] = ooff2[p];
+    if (p < nparts) ocount2[p] = ooff2[p + 1] - ooff2[p];
+}
+
+// earlier winners per level-1 bin: obin[b] = sum of ocount over the bin's f2old partitions
+__global__ __launch_bounds__(BLOCK) void k_old_per_bin(const uint32_t *__restrict__ ocount, uint32_t f2old, uint32_t *__restrict__ obin) {
+    const uint32_t b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= F1) return;
+    uint32_t t = 0;
+    for (uint32_t q = b * f2old; q < (b + 1) * f2old; q++) t += ocount[q];
+    obin[b] = t;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// the fold: one workgroup per partition, open-addressing table in LDS
+// ---------------------------------------------------------------------------------------------------------------
+struct FoldParams {
+    const GridSeg *segs;
+    int nsegs;
+    GridSeg seg0;                  // segs[0] again, in the kernel arguments: one dependent load fewer when nsegs == 1
+    const GridEntryDev *entries;
+    DevGrid g;
+    // earlier winners by partition (okeys == nullptr: none)
+    const uint64_t *okeys;
+    const uint8_t *orecs;
+    const uint64_t *obase;
+    const uint32_t *ocount;
+    // output
+    uint64_t *wkeys;
+    uint8_t *wrecs;
+    const uint64_t *wbase;
+    uint32_t *wcount;
+    uint32_t *palias;              // [P] 1: the partition holds aliased keys
+    uint32_t *pay_scratch;         // BIG: the parked payloads, 5 words per slot and partition
+    unsigned long long *stats;     // [0] winners, [1] partitions that overflowed the LDS table, [2] partitions with aliased keys
+};
+
+// Slot of `key` in the LDS table, inserting it if absent; -1 when the table is full (LIMIT cells).
+template <int NSLOT, int LIMIT>
+__device__ __forceinline__ int lds_find_or_insert(uint64_t *s_key, uint64_t key, uint64_t h, uint32_t *s_ncell) {
+    uint32_t s = slot_of<NSLOT>(h);
+    for (int probes = 0; probes < NSLOT; probes++) {
+        const uint64_t k = __hip_atomic_load(&s_key[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (k == key) return (int)s;
+        if (k == PCQ_EMPTY_KEY) {
+            const uint64_t prev = atomicCAS((unsigned long long *)&s_key[s], (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key);
+            if (prev == PCQ_EMPTY_KEY) return atomicAdd(s_ncell, 1u) >= (uint32_t)LIMIT ? -1 : (int)s;
+            if (prev == key) return (int)s;
         }
+        s = s + 1 == NSLOT ? 0 : s + 1;
+    }
+    return -1;
+}
+
+template <int NSLOT, int NT, int LIMIT, bool PAY_LDS>
+__global__ __launch_bounds__(NT) void k_fold(FoldParams P) {
+    constexpr int SPT = (NSLOT + NT - 1) / NT;   // slots per thread in the compaction
+    constexpr int CHUNK = NT * FOLD_K;
+    __shared__ uint64_t s_key[NSLOT];
+    __shared__ uint64_t s_dist[NSLOT];   // f64 bits of the best squared distance (monotone for d >= 0)
+    __shared__ uint64_t s_ord[NSLOT];    // file order of the winner: 0 = an earlier fold's winner, ~0 = none yet
+    __shared__ uint32_t s_pay_lds[PAY_LDS ? NSLOT * 5 : 1];  // winner's x, y, z, w0, w1 — or, for an earlier winner, its index (two words)
+    __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32], s_oldbits[(NSLOT + 31) / 32];
+    __shared__ uint32_t s_ncell, s_over, s_wsum[NT / 64];
+    const uint32_t p = blockIdx.x;
+    uint32_t *pay = PAY_LDS ? s_pay_lds : P.pay_scratch + (size_t)p * NSLOT * 5;
+    // everything that depends on p alone is loaded up front, together
+    const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
+    const uint64_t old_base = P.okeys ? P.obase[p] : 0;
+    const uint64_t out_base = P.wbase[p];
+    for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
+    for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0, s_oldbits[t] = 0;
+    if (threadIdx.x == 0) s_ncell = 0, s_over = 0;
+    __syncthreads();
+
+    // earlier winners first: their distance is recomputed from the record (same f64 expressions, same bits)
+    for (uint32_t i = threadIdx.x; i < n_old; i += NT) {
+        const uint64_t key = P.okeys[old_base + i];
+        const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, key, hash64(key), &s_ncell);
+        if (s < 0) {
+            s_over = 1;
+            continue;
+        }
+        const uint8_t *rec = P.orecs + (old_base + i) * 32;
+        atomicOr(&s_oldbits[s >> 5], 1u << (s & 31));
+        pay[s * 5] = (uint32_t)(old_base + i);
+        pay[s * 5 + 1] = (uint32_t)((old_base + i) >> 32);
+        if (rec[31] & R_ALIAS) {
+            atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
+        } else {
+            const double *pos = reinterpret_cast<const double *>(rec);
+            uint64_t cell[3];
 #pragma unroll
-        for (int j = 0; j < GRID_BATCH; j++) {
-            const uint64_t i = base + (uint64_t)j * BLOCK;
-            const bool pass = passes[j];
-            bool candidate = false;
-            if (pass) {
-                if (KIND == PCQ_PRED_CLASS) rps[j] = ld_xyz(c, i);
-                const RawPoint rp = rps[j];
-                const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]),
-                             pz = world(rp.z, c.scale[2], c.offset[2]);
-                const CellInfo ci = cell_of(g, px, py, pz);
-                const uint64_t db = (uint64_t)__double_as_longlong(centre_dist(g, ci.cell, px, py, pz));
-                const uint64_t h = find_or_insert(t, ci.key, probe_limit, shard_limit);
-                if (h == PCQ_NO_INDEX) return;  // table full: the pass is re-run (bitmap included) after the table has grown
-                // the slot's line was just read for the key; a point that cannot lower the minimum (most points of a
-                // coarse grid) skips the atomic.  A stale value can only be too large: an atomic more, never a miss.
-                const uint64_t seen = __hip_atomic_load(&t.slots[h].dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                candidate = db <= seen;
-                if (db < seen) {
-                    const uint64_t old = atomicMin((unsigned long long *)&t.slots[h].dist, (unsigned long long)db);
-                    if (db < old) t.slots[h].widx = PCQ_NO_INDEX;
+            for (int a = 0; a < 3; a++) cell[a] = (key >> P.g.shift[a]) & P.g.mask[a];  // not aliased: unmasked == masked
+            s_dist[s] = (uint64_t)__double_as_longlong(centre_dist(P.g, cell, pos[0], pos[1], pos[2]));
+            s_ord[s] = 0;
+        }
+    }
+    __syncthreads();
+
+    for (int r = 0; r < P.nsegs; r++) {
+        const GridSeg sg = r == 0 ? P.seg0 : P.segs[r];
+        const uint32_t lo = sg.off[p], cnt = sg.off[p + 1] - lo;
+        for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
+            GridTuple tu[FOLD_K];
+            uint64_t dbits[FOLD_K];
+            int slot[FOLD_K];
+            // the chunk's tuples are loaded together, then folded
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) {
+                const uint32_t i = c0 + k * NT + threadIdx.x;
+                tu[k] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
+            }
+            // phase 1: cells and their minimum distance
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) {
+                const uint32_t i = c0 + k * NT + threadIdx.x;
+                slot[k] = -1;
+                if (i >= cnt) continue;
+                const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
+                dbits[k] = ev.dbits;
+                const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, hash64(ev.key), &s_ncell);
+                if (s < 0) {
+                    s_over = 1;
+                    continue;
                 }
-                if (ci.alias) {
-                    t.slots[h].nflags &= ~F_ALIAS;  // racing writers all clear the same bit; bit0 is not written in pass A
-                    atomicAdd((unsigned long long *)t.n_alias, 1ull);
+                slot[k] = s;
+                if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
+                // most tuples of a coarse grid cannot lower the minimum: a plain read first (a stale value is only too large)
+                if (ev.dbits < __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    const uint64_t old = atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
+                    if (ev.dbits < old) s_ord[s] = ~0ull;  // a new minimum: whoever held the cell is out (racing writers store the same value)
                 }
             }
-            const uint64_t word = __ballot(candidate);
-            if (lane == 0 && i < c.n) cand[i >> 6] = word;  // i of lane 0 is the wave's first index, a multiple of 64
+            __syncthreads();
+            // phase 2: among the tuples at the minimum, the earliest in file order
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) {
+                if (slot[k] < 0) continue;
+                if (dbits[k] == s_dist[slot[k]]) atomicMin((unsigned long long *)&s_ord[slot[k]], (unsigned long long)ord_of(tu[k]));
+            }
+            __syncthreads();
+            // phase 3: a winner from this chunk parks its payload
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) {
+                const int s = slot[k];
+                if (s < 0) continue;
+                if (dbits[k] == s_dist[s] && s_ord[s] == ord_of(tu[k])) {
+                    pay[s * 5] = (uint32_t)tu[k].x, pay[s * 5 + 1] = (uint32_t)tu[k].y, pay[s * 5 + 2] = (uint32_t)tu[k].z;
+                    pay[s * 5 + 3] = tu[k].w0, pay[s * 5 + 4] = tu[k].w1;
+                    atomicAnd(&s_oldbits[s >> 5], ~(1u << (s & 31)));
+                }
+            }
+            // no barrier here: the next chunk's phase 1 can only make this test fail for a slot whose winner is
+            // about to be replaced, and every thread passes the barrier behind it before anyone parks again
         }
     }
-}
-
-// Pass B: the candidates whose distance equals the slot's final minimum race for the lowest file-order index.  It
-// also materialises: the FIRST such point of a cell in this scan (atomicMin found "no index") writes its record
-// right away — for almost every cell it is the only point at the minimum distance.  A second one (an exact
-// distance tie, or a tie with the winner of an earlier scan) only bumps `ties`; pass C, which re-derives the
-// winners from the final indices, then runs for that scan only.  One wave per bitmap word, GRID_BATCH words a step.
-__global__ __launch_bounds__(BLOCK) void k_grid_pass_b(DevCols c, DevGrid g, DevGridTable t, const uint64_t *__restrict__ cand) {
-    const int lane = threadIdx.x & 63;
-    const uint64_t words = (c.n + 63) >> 6;
-    const uint64_t wave = ((uint64_t)blockIdx.x * BLOCK + threadIdx.x) >> 6, nwaves = (uint64_t)gridDim.x * WAVES;
-    for (uint64_t w0 = wave * GRID_BATCH; w0 < words; w0 += nwaves * GRID_BATCH) {
-        uint64_t bits[GRID_BATCH];
-#pragma unroll
-        for (int j = 0; j < GRID_BATCH; j++) bits[j] = w0 + j < words ? cand[w0 + j] : 0;
-        RawPoint rps[GRID_BATCH];
-#pragma unroll
-        for (int j = 0; j < GRID_BATCH; j++) {  // lanes that are not candidates re-read the word's first point
-            const bool on = (bits[j] >> lane) & 1;
-            rps[j] = ld_xyz(c, on ? (w0 + j) * 64 + lane : (w0 + j < words ? (w0 + j) * 64 : 0));
+    if (!PAY_LDS) __threadfence();  // the parked payloads are read back by other threads of the workgroup
+    __syncthreads();
+    if (s_over) {  // more cells than the table holds: the host repeats the fold with more partitions
+        if (threadIdx.x == 0) {
+            P.wcount[p] = 0;
+            atomicAdd(&P.stats[1], 1ull);
         }
+        return;
+    }
+
+    // compaction: thread t owns slots [t * SPT, ...): winners leave in slot order
+    uint32_t mine = 0;
+    const int s0 = threadIdx.x * SPT;
 #pragma unroll
-        for (int j = 0; j < GRID_BATCH; j++) {
-            if (!((bits[j] >> lane) & 1)) continue;
-            const uint64_t i = (w0 + j) * 64 + lane;
-            const RawPoint rp = rps[j];
-            const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]),
-                         pz = world(rp.z, c.scale[2], c.offset[2]);
-            const CellInfo ci = cell_of(g, px, py, pz);
-            const uint64_t h = find_slot(t, ci.key);
-            if (h == PCQ_NO_INDEX) continue;
-            const double d = centre_dist(g, ci.cell, px, py, pz);
-            if ((uint64_t)__double_as_longlong(d) != t.slots[h].dist) continue;
-            const uint64_t prev = atomicMin((unsigned long long *)&t.slots[h].widx, (unsigned long long)(c.first_index + i));
-            if (prev == PCQ_NO_INDEX) {
-                if (t.slots[h].nflags & F_ALIAS) {  // inverted flag: set = NOT aliased (aliased keys belong to pass R)
-                    pcq_point pt;
-                    make_point(c, i, rp, pt);
-                    store_point_slot32(t.pts + h * 32, pt);
-                    t.slots[h].nflags &= ~F_HAS_POINT;
+    for (int j = 0; j < SPT; j++) mine += (s0 + j < NSLOT && s_key[s0 + j] != PCQ_EMPTY_KEY) ? 1 : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wsum[wave] = incl;
+    __syncthreads();
+    uint32_t before = incl - mine, total = 0;
+    for (int w = 0; w < NT / 64; w++) {
+        before += w < wave ? s_wsum[w] : 0;
+        total += s_wsum[w];
+    }
+    bool any_alias = false;
+    uint64_t o = out_base + before;
+#pragma unroll
+    for (int j = 0; j < SPT; j++) {
+        const int s = s0 + j;
+        if (s >= NSLOT || s_key[s] == PCQ_EMPTY_KEY) continue;
+        const uint64_t key = s_key[s];
+        P.wkeys[o] = key;
+        uint8_t *dst = P.wrecs + o * 32;
+        const bool alias = (s_aliasbits[s >> 5] >> (s & 31)) & 1, old = (s_oldbits[s >> 5] >> (s & 31)) & 1;
+        if (alias) {  // left to the exact replay: the state before this fold (the earlier winner, if there is one) + the flag
+            any_alias = true;
+            uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
+            for (uint32_t i = 0; i < n_old; i++)
+                if (P.okeys[old_base + i] == key) {
+                    const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + (old_base + i) * 32);
+                    a = sp[0], b = sp[1];
+                    b.w |= (uint32_t)R_ALIAS << 24;
+                    break;
                 }
+            reinterpret_cast<uint4 *>(dst)[0] = a;
+            reinterpret_cast<uint4 *>(dst)[1] = b;
+        } else {
+            uint32_t w[5];
+#pragma unroll
+            for (int q = 0; q < 5; q++)
+                w[q] = PAY_LDS ? pay[s * 5 + q] : __hip_atomic_load(&pay[s * 5 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (old) {
+                const uint64_t oi = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+                const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + oi * 32);
+                reinterpret_cast<uint4 *>(dst)[0] = sp[0];
+                reinterpret_cast<uint4 *>(dst)[1] = sp[1];
             } else {
-                atomicAdd((unsigned long long *)(t.n_alias + 1), 1ull);
+                st_record(dst, P.entries[(w[3] >> 8) & 0xff], (int32_t)w[0], (int32_t)w[1], (int32_t)w[2], w[3], w[4], R_HAS);
+            }
+        }
+        o++;
+    }
+    if (__syncthreads_or(any_alias) && threadIdx.x == 0) {
+        P.palias[p] = 1;
+        atomicAdd(&P.stats[2], 1ull);
+    }
+    if (threadIdx.x == 0) {
+        P.wcount[p] = total;
+        if (total) atomicAdd(&P.stats[0], (unsigned long long)total);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// aliased keys: exact sequential replay (grid_sampling.rs:72-103), rare
+// ---------------------------------------------------------------------------------------------------------------
+// The tuples of this fold that belong to aliased keys: counted (EMIT = false) or appended to `list` (EMIT = true).
+template <bool EMIT>
+__global__ __launch_bounds__(L2_NT) void k_alias_gather(FoldParams P, AliasItem *__restrict__ list, unsigned long long *__restrict__ cursor) {
+    __shared__ uint64_t s_akeys[BIG_LIMIT];
+    __shared__ uint32_t s_n;
+    const uint32_t p = blockIdx.x;
+    if (!P.palias[p]) return;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint64_t wb = P.wbase[p];
+    const uint32_t wn = P.wcount[p];
+    for (uint32_t i = threadIdx.x; i < wn; i += L2_NT)
+        if (P.wrecs[(wb + i) * 32 + 31] & R_ALIAS) s_akeys[atomicAdd(&s_n, 1u)] = P.wkeys[wb + i];
+    __syncthreads();
+    const uint32_t na = s_n;
+    uint32_t mine = 0;
+    for (int r = 0; r < P.nsegs; r++) {
+        const GridSeg sg = P.segs[r];
+        const uint32_t lo = sg.off[p], hi = sg.off[p + 1];
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += L2_NT) {
+            const GridTuple t = ld_tuple(sg.tuples + i);
+            const uint64_t key = eval_tuple(P.g, P.entries, t).key;
+            bool hit = false;
+            for (uint32_t q = 0; q < na && !hit; q++) hit = s_akeys[q] == key;
+            if (!hit) continue;
+            if (EMIT) {
+                AliasItem it;
+                it.key = key, it.ord = ord_of(t);
+                it.x = t.x, it.y = t.y, it.z = t.z, it.w0 = t.w0, it.w1 = t.w1, it._pad = 0;
+                list[atomicAdd(cursor, 1ull)] = it;
+            } else {
+                mine++;
             }
         }
     }
+    if (!EMIT && mine) atomicAdd(cursor, (unsigned long long)mine);
 }
 
-template <int KIND>
-__global__ __launch_bounds__(BLOCK) void k_grid_pass_c(DevCols c, DevPred pr, DevGrid g, DevGridTable t) {
-    for_each_match<KIND>(c, pr, [&](uint64_t i, const RawPoint &rp) {
-        const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]),
-                     pz = world(rp.z, c.scale[2], c.offset[2]);
-        const CellInfo ci = cell_of(g, px, py, pz);
-        const uint64_t h = find_slot(t, ci.key);
-        if (h == PCQ_NO_INDEX) return true;
-        if (!(t.slots[h].nflags & F_ALIAS)) return true;  // aliased key: resolved by pass R
-        if (t.slots[h].widx == c.first_index + i) {
-            pcq_point pt;
-            make_point(c, i, rp, pt);
-            store_point_slot32(t.pts + h * 32, pt);
-            t.slots[h].nflags &= ~F_HAS_POINT;
-        }
-        return true;
-    });
-}
-
-// Pass R: exact sequential fold for aliased keys.  `list` / `lkeys` hold, in file order, the local
-// index and the key of this scan's matched points whose key is flagged.  The thread of the FIRST list
-// entry of a key owns that key: it walks the rest of the list and applies insert_point
-// (grid_sampling.rs:72-103) to the entries of its key, starting from the slot's state before the scan.
-__global__ __launch_bounds__(BLOCK) void k_grid_pass_r(DevCols c, DevGrid g, DevGridTable t,
-                                                       const uint64_t *__restrict__ list,
-                                                       const uint64_t *__restrict__ lkeys, uint64_t nlist) {
+// sorted[rank] = list[e], rank = number of items in front of it by (key, file order); quadratic, the list is short
+__global__ __launch_bounds__(BLOCK) void k_alias_rank(const AliasItem *__restrict__ list, uint64_t n, AliasItem *__restrict__ sorted) {
     const uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (e >= nlist) return;
-    const uint64_t key = lkeys[e];
-    for (uint64_t q = 0; q < e; q++)
-        if (lkeys[q] == key) return;  // an earlier entry owns this key
-    const uint64_t h = find_slot(t, key);
-    if (h == PCQ_NO_INDEX) return;
-    bool has = !(t.slots[h].nflags & F_HAS_POINT);
-    pcq_point cur;
-    if (has) {
-        const uint8_t *s = t.pts + h * 32;
-        uint8_t *d = reinterpret_cast<uint8_t *>(&cur);
-        for (int k = 0; k < 31; k++) d[k] = s[k];
+    if (e >= n) return;
+    const AliasItem me = list[e];
+    uint64_t rank = 0;
+    for (uint64_t j = 0; j < n; j++) {
+        const uint64_t k = list[j].key, o = list[j].ord;
+        rank += (k < me.key || (k == me.key && o < me.ord)) ? 1 : 0;
     }
-    for (uint64_t q = e; q < nlist; q++) {
-        if (lkeys[q] != key) continue;
-        const uint64_t i = list[q];
-        const RawPoint rp = ld_xyz(c, i);
-        const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]),
-                     pz = world(rp.z, c.scale[2], c.offset[2]);
+    sorted[rank] = me;
+}
+
+// The thread of the FIRST item of a key owns that key: it applies insert_point to the key's items in file order,
+// starting from the state the fold left in the winner record.
+__global__ __launch_bounds__(BLOCK) void k_alias_replay(const AliasItem *__restrict__ sorted, uint64_t n, FoldParams P, uint32_t f2) {
+    const uint64_t e = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (e >= n) return;
+    const uint64_t key = sorted[e].key;
+    if (e > 0 && sorted[e - 1].key == key) return;
+    const uint64_t h = hash64(key);
+    const uint32_t p = bin_of(h) * f2 + sub_of(h, f2);
+    const uint64_t wb = P.wbase[p];
+    const uint32_t wn = P.wcount[p];
+    uint64_t o = ~0ull;
+    for (uint32_t i = 0; i < wn && o == ~0ull; i++)
+        if (P.wkeys[wb + i] == key) o = wb + i;
+    if (o == ~0ull) return;  // cannot happen: the fold wrote a record for every key it saw
+    uint8_t *rec = P.wrecs + o * 32;
+    bool has = rec[31] & R_HAS;
+    uint4 ra = reinterpret_cast<const uint4 *>(rec)[0], rb = reinterpret_cast<const uint4 *>(rec)[1];
+    double cx = __longlong_as_double((long long)((uint64_t)ra.x | ((uint64_t)ra.y << 32))),
+           cy = __longlong_as_double((long long)((uint64_t)ra.z | ((uint64_t)ra.w << 32))),
+           cz = __longlong_as_double((long long)((uint64_t)rb.x | ((uint64_t)rb.y << 32)));
+    bool changed = false;
+    AliasItem best = sorted[e];
+    for (uint64_t q = e; q < n && sorted[q].key == key; q++) {
+        const AliasItem it = sorted[q];
+        const GridEntryDev &en = P.entries[(it.w0 >> 8) & 0xff];
+        const double px = world(it.x, en.scale[0], en.offset[0]), py = world(it.y, en.scale[1], en.offset[1]), pz = world(it.z, en.scale[2], en.offset[2]);
         bool take;
         if (!has) {
             take = true;  // grid_sampling.rs:73-76
         } else {          // :77-103 — both distances against the NEW point's (unmasked) cell centre
-            const CellInfo ci = cell_of(g, px, py, pz);
-            const double cur_d = centre_dist(g, ci.cell, cur.x, cur.y, cur.z);
-            const double new_d = centre_dist(g, ci.cell, px, py, pz);
-            take = new_d < cur_d;
+            const CellInfo ci = cell_of(P.g, px, py, pz);
+            take = centre_dist(P.g, ci.cell, px, py, pz) < centre_dist(P.g, ci.cell, cx, cy, cz);
         }
         if (take) {
-            make_point(c, i, rp, cur);
+            best = it, cx = px, cy = py, cz = pz;
             has = true;
+            changed = true;
         }
     }
-    if (has) {
-        store_point31(t.pts + h * 32, cur);
-        t.slots[h].nflags &= ~F_HAS_POINT;
-    }
+    if (changed) st_record(rec, P.entries[(best.w0 >> 8) & 0xff], best.x, best.y, best.z, best.w0, best.w1, R_HAS | R_ALIAS);
 }
 
-// Selector for pass R's list: matched && key flagged (two-pass stable compaction of local indices).
-__global__ __launch_bounds__(BLOCK) void k_alias_tile_counts(DevCols c, DevPred pr, DevGrid g, DevGridTable t,
-                                                             uint64_t *__restrict__ counts) {
-    const uint64_t base = (uint64_t)blockIdx.x * TILE;
-    uint32_t cnt = 0;
-    for (int j = 0; j < ITEMS; j++) {
-        const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
-        const Matched m = match_point(c, pr, i);
-        bool sel = false;
-        if (m.pass) {
-            const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
-            const uint64_t h = find_slot(t, ci.key);
-            sel = h != PCQ_NO_INDEX && !(t.slots[h].nflags & F_ALIAS);
-        }
-        cnt += (uint32_t)__popcll(__ballot(sel));
-    }
-    __shared__ uint32_t s_w[WAVES];
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tt = 0;
-        for (int i = 0; i < WAVES; i++) tt += s_w[i];
-        counts[blockIdx.x] = tt;
-    }
-}
+// ---------------------------------------------------------------------------------------------------------------
+// drain: the winners of partition p, packed to 31-byte points at out31[dpre[p] ...] and their keys
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int DRAIN_RECS = 1024;  // records per LDS image
+constexpr int DRAIN_STAGE = DRAIN_RECS * 31 + 16;
 
-__global__ __launch_bounds__(BLOCK) void k_alias_emit(DevCols c, DevPred pr, DevGrid g, DevGridTable t,
-                                                      const uint64_t *__restrict__ offsets, uint64_t *__restrict__ list,
-                                                      uint64_t *__restrict__ lkeys) {
-    __shared__ uint32_t s_w[WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t base = (uint64_t)blockIdx.x * TILE;
-    uint64_t run = offsets[blockIdx.x];
-    for (int j = 0; j < ITEMS; j++) {
-        const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
-        const Matched m = match_point(c, pr, i);
-        bool sel = false;
-        uint64_t key = 0;
-        if (m.pass) {
-            const CellInfo ci = cell_of(g, m.px, m.py, m.pz);
-            const uint64_t h = find_slot(t, ci.key);
-            sel = h != PCQ_NO_INDEX && !(t.slots[h].nflags & F_ALIAS);
-            key = ci.key;
+__global__ __launch_bounds__(BLOCK) void k_drain(const uint64_t *__restrict__ wkeys, const uint8_t *__restrict__ wrecs, const uint64_t *__restrict__ wbase,
+                                                 const uint32_t *__restrict__ wcount, const uint32_t *__restrict__ dpre, uint8_t *__restrict__ out31,
+                                                 uint64_t *__restrict__ keys_out) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_stage[DRAIN_STAGE];
+    const uint32_t p = blockIdx.x, n = wcount[p];
+    if (n == 0) return;
+    const uint64_t src = wbase[p], dst = dpre[p];
+    if (keys_out)
+        for (uint32_t i = threadIdx.x; i < n; i += BLOCK) keys_out[dst + i] = wkeys[src + i];
+    if (!out31) return;
+    // the 31-byte records are assembled in LDS congruent (mod 16) to their place in the output and leave as 16-byte
+    // stores; only the two ragged ends use byte stores, so neighbouring pieces never write the same 16 bytes
+    for (uint32_t c0 = 0; c0 < n; c0 += DRAIN_RECS) {
+        const uint32_t m = n - c0 < DRAIN_RECS ? n - c0 : DRAIN_RECS;
+        const uint64_t gbyte0 = (dst + c0) * 31ull;
+        const uint32_t pad = (uint32_t)(gbyte0 & 15);
+        for (uint32_t i = threadIdx.x; i < m; i += BLOCK) {
+            const uint4 *sp = reinterpret_cast<const uint4 *>(wrecs + (src + c0 + i) * 32);
+            const uint4 a = sp[0], b = sp[1];
+            const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint8_t *dp = s_stage + pad + 31u * i;
+#pragma unroll
+            for (int k = 0; k < 31; k++) dp[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
         }
-        const uint64_t mask = __ballot(sel);
-        if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
         __syncthreads();
-        uint32_t before = 0, all = 0;
-        for (int w = 0; w < WAVES; w++) {
-            const uint32_t v = s_w[w];
-            before += w < wave ? v : 0;
-            all += v;
-        }
-        if (sel) {
-            const uint64_t pos = run + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            list[pos] = i;
-            lkeys[pos] = key;
-        }
-        run += all;
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(1024) void k_scan_u64(uint64_t *__restrict__ counts, uint64_t n, uint64_t *__restrict__ total_out) {
-    __shared__ uint64_t s_wave[16];
-    __shared__ uint64_t s_carry;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (uint64_t base = 0; base < n; base += 1024) {
-        const uint64_t i = base + threadIdx.x;
-        const uint64_t v = i < n ? counts[i] : 0;
-        uint64_t incl = v;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint64_t up = __shfl_up((unsigned long long)incl, off, 64);
-            if (lane >= off) incl += up;
-        }
-        if (lane == 63) s_wave[wave] = incl;
-        __syncthreads();
-        uint64_t wave_off = 0;
-        for (int w = 0; w < wave; w++) wave_off += s_wave[w];
-        const uint64_t carry = s_carry;
-        if (i < n) counts[i] = carry + wave_off + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total_out = s_carry;
-}
-
-// out[0] = occupied slots (sum of the shards), out[1] = aliased points, out[2] = distance ties of the last scan,
-// out[3] = overflow word of the last pass A.
-__global__ __launch_bounds__(OCC_SHARDS) void k_sum_occupied(const uint64_t *__restrict__ occ, const uint64_t *__restrict__ n_alias,
-                                                             uint64_t *__restrict__ out) {
-    __shared__ uint64_t s[OCC_SHARDS];
-    s[threadIdx.x] = occ[threadIdx.x * OCC_STRIDE];
-    __syncthreads();
-    for (int off = OCC_SHARDS / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) s[threadIdx.x] += s[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        out[0] = s[0];
-        out[1] = n_alias[0];
-        out[2] = n_alias[1];  // distance ties seen by pass B
-        out[3] = n_alias[2];  // pass A gave up: table full
-    }
-}
-
-// Re-insert every used slot of `src` into `dst` (table growth).
-__global__ __launch_bounds__(BLOCK) void k_grid_rehash(DevGridTable src, DevGridTable dst) {
-    const uint64_t nthreads = (uint64_t)gridDim.x * BLOCK;
-    for (uint64_t h = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; h < src.cap; h += nthreads) {
-        const GridSlot sl = src.slots[h];
-        const uint64_t key = sl.key;
-        if (key == PCQ_EMPTY_KEY) continue;
-        const uint64_t m = dst.cap - 1;
-        uint64_t d = hash64(key) & m;
-        for (;;) {
-            const uint64_t prev = atomicCAS((unsigned long long *)&dst.slots[d].key, (unsigned long long)PCQ_EMPTY_KEY,
-                                            (unsigned long long)key);
-            if (prev == PCQ_EMPTY_KEY) break;
-            d = (d + 1) & m;
-        }
-        dst.slots[d].dist = sl.dist;
-        dst.slots[d].widx = sl.widx;
-        dst.slots[d].nflags = sl.nflags;
-        const uint4 *sp = reinterpret_cast<const uint4 *>(src.pts + h * 32);
-        uint4 *dp = reinterpret_cast<uint4 *>(dst.pts + d * 32);
-        dp[0] = sp[0];
-        dp[1] = sp[1];
-    }
-}
-
-// Drain: deterministic slot-order compaction of the used slots into packed 31-byte points + keys
-// (tile counts -> exclusive scan -> emit; same ballot-rank scheme as the buffer collector).
-__global__ __launch_bounds__(BLOCK) void k_drain_tile_counts(DevGridTable t, uint64_t *__restrict__ counts) {
-    const uint64_t base = (uint64_t)blockIdx.x * TILE;
-    uint32_t cnt = 0;
-    for (int j = 0; j < ITEMS; j++) {
-        const uint64_t h = base + (uint64_t)j * BLOCK + threadIdx.x;
-        const bool used = h < t.cap && t.slots[h].key != PCQ_EMPTY_KEY && !(t.slots[h].nflags & F_HAS_POINT);
-        cnt += (uint32_t)__popcll(__ballot(used));
-    }
-    __shared__ uint32_t s_w[WAVES];
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tt = 0;
-        for (int i = 0; i < WAVES; i++) tt += s_w[i];
-        counts[blockIdx.x] = tt;
-    }
-}
-
-__global__ __launch_bounds__(BLOCK) void k_drain_emit(DevGridTable t, const uint64_t *__restrict__ offsets,
-                                                      uint8_t *__restrict__ out31, uint64_t *__restrict__ keys_out) {
-    __shared__ uint32_t s_w[WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint64_t base = (uint64_t)blockIdx.x * TILE;
-    uint64_t run = offsets[blockIdx.x];
-    for (int j = 0; j < ITEMS; j++) {
-        const uint64_t h = base + (uint64_t)j * BLOCK + threadIdx.x;
-        const bool used = h < t.cap && t.slots[h].key != PCQ_EMPTY_KEY && !(t.slots[h].nflags & F_HAS_POINT);
-        const uint64_t mask = __ballot(used);
-        if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
-        __syncthreads();
-        uint32_t before = 0, all = 0;
-        for (int w = 0; w < WAVES; w++) {
-            const uint32_t v = s_w[w];
-            before += w < wave ? v : 0;
-            all += v;
-        }
-        if (used) {
-            const uint64_t pos = run + before + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-            if (out31) {
-                const uint8_t *sp = t.pts + h * 32;
-                uint8_t *dp = out31 + pos * 31;
-                for (int k = 0; k < 31; k++) dp[k] = sp[k];
+        const uint32_t total = pad + m * 31u;
+        uint8_t *gdst = out31 + (gbyte0 - pad);
+        for (uint32_t b0 = threadIdx.x * 16u; b0 < total; b0 += BLOCK * 16u) {
+            const uint32_t b1 = b0 + 16u;
+            if (b0 >= pad && b1 <= total) {
+                *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(s_stage + b0);
+            } else {
+                const uint32_t lo = b0 > pad ? b0 : pad, hi = b1 < total ? b1 : total;
+                for (uint32_t k = lo; k < hi; k++) gdst[k] = s_stage[k];
             }
-            if (keys_out) keys_out[pos] = t.slots[h].key;
         }
-        run += all;
         __syncthreads();
     }
 }
 
 }  // namespace
 
-static void table_free(DevGridTable &t) {
-    if (t.slots) (void)hipFree(t.slots);
-    if (t.pts) (void)hipFree(t.pts);
-    if (t.occupied) (void)hipFree(t.occupied);
-    t = DevGridTable{};
+// ---------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------
+struct GridRun {
+    GridTuple *tuples;
+    uint64_t cap;      // tuples the run has room for (= points scanned)
+    uint32_t *binoff;  // device, F1 + 1
+};
+
+struct GridState {
+    // pending: pass-0 runs not folded yet
+    std::vector<GridRun> runs;
+    std::vector<GridEntryDev> entries;
+    std::vector<uint64_t> entry_base;  // first file-order index of each entry
+    uint64_t entry_end = 0;            // index behind the last point scanned into the last entry
+    std::vector<void *> slabs;         // pool blocks holding the tuples
+    uint8_t *slab_cur = nullptr;
+    size_t slab_left = 0;
+    uint64_t pending_cap = 0;
+    uint32_t *binoff_store = nullptr;  // MAX_RUNS x (F1 + 1)
+    // folded winners, grouped by partition
+    uint64_t *wkeys = nullptr;
+    uint8_t *wrecs = nullptr;
+    uint64_t *wbase = nullptr;   // [P + 1]
+    uint32_t *wcount = nullptr;  // [P]
+    uint32_t f2 = 1;
+    uint64_t wtotal = 0;
+};
+
+static void grid_free_pending(pcq_ctx *ctx, GridState *gs) {
+    for (void *p : gs->slabs) pcq_pool_free(ctx, p);
+    gs->slabs.clear();
+    gs->slab_cur = nullptr;
+    gs->slab_left = 0;
+    gs->pending_cap = 0;
+    gs->runs.clear();
+    gs->entries.clear();
+    gs->entry_base.clear();
+    gs->entry_end = 0;
 }
 
-void pcq_grid_cache_clear(pcq_ctx *ctx) {
-    for (DevGridTable &e : ctx->grid_cache) table_free(e);
+static void grid_free_winners(pcq_ctx *ctx, GridState *gs) {
+    pcq_pool_free(ctx, gs->wkeys);
+    pcq_pool_free(ctx, gs->wrecs);
+    pcq_pool_free(ctx, gs->wbase);
+    pcq_pool_free(ctx, gs->wcount);
+    gs->wkeys = nullptr, gs->wrecs = nullptr, gs->wbase = nullptr, gs->wcount = nullptr;
+    gs->wtotal = 0;
+    gs->f2 = 1;
 }
 
-// Retires the collector's table.  The context keeps up to two retired tables (device allocations of this size cost
-// from tens of milliseconds to more than a second): a process that alternates coarse and dense grids finds both
-// its small and its large table again.  A third size replaces the smaller of the two if it is larger.
 void pcq_grid_release(pcq_collector *c) {
-    DevGridTable &t = c->table;
-    pcq_ctx *ctx = c->ctx;
-    if (!t.slots) return;
-    if (ctx) {
-        DevGridTable *victim = nullptr;
-        for (DevGridTable &e : ctx->grid_cache) {
-            if (!e.slots) {
-                victim = &e;
-                break;
-            }
-            if (!victim || e.cap < victim->cap) victim = &e;
-        }
-        if (!victim->slots || victim->cap < t.cap) {
-            table_free(*victim);
-            *victim = t;
-            t = DevGridTable{};
-            return;
-        }
-    }
-    table_free(t);
+    if (!c->gs) return;
+    grid_free_pending(c->ctx, c->gs);
+    grid_free_winners(c->ctx, c->gs);
+    pcq_pool_free(c->ctx, c->gs->binoff_store);
+    delete c->gs;
+    c->gs = nullptr;
 }
 
-static int table_alloc(pcq_ctx *ctx, DevGridTable *t, uint64_t cap, hipStream_t s) {
-    *t = DevGridTable{};
-    DevGridTable *hit = nullptr;  // the smallest retired table that is large enough, and not wastefully larger
-    for (DevGridTable &e : ctx->grid_cache)
-        if (e.slots && e.cap >= cap && e.cap <= 4 * cap && (!hit || e.cap < hit->cap)) hit = &e;
-    if (hit) {
-        *t = *hit;  // reuse (a larger table only lowers the load factor)
-        *hit = DevGridTable{};
-        cap = t->cap;
-    } else {
-        t->cap = cap;
-        PCQ_HIP(hipMalloc((void **)&t->slots, cap * sizeof(GridSlot)));
-        PCQ_HIP(hipMalloc((void **)&t->pts, cap * 32));
-        PCQ_HIP(hipMalloc((void **)&t->occupied, OCC_WORDS * 8));
-        t->n_alias = t->occupied + (size_t)OCC_SHARDS * OCC_STRIDE;
+// a scratch list of pool blocks released together
+struct Scratch {
+    pcq_ctx *ctx;
+    std::vector<void *> blocks;
+    explicit Scratch(pcq_ctx *c) : ctx(c) {}
+    ~Scratch() {
+        for (void *p : blocks) pcq_pool_free(ctx, p);
     }
-    PCQ_HIP(hipMemsetAsync(t->slots, 0xff, cap * sizeof(GridSlot), s));  // all-ones = empty (flags are inverted)
-    PCQ_HIP(hipMemsetAsync(t->occupied, 0, OCC_WORDS * 8, s));
+    template <typename T>
+    int get(size_t count, T **out) {
+        void *p = nullptr;
+        const int rc = pcq_pool_alloc(ctx, count * sizeof(T), &p);
+        if (rc) return rc;
+        blocks.push_back(p);
+        *out = (T *)p;
+        return PCQ_OK;
+    }
+    void keep(void *p) { blocks.erase(std::remove(blocks.begin(), blocks.end(), p), blocks.end()); }
+};
+
+static int grid_fold(pcq_ctx *ctx, pcq_collector *c);
+
+static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, GridTuple **out) {
+    const size_t bytes = (size_t)tuples * sizeof(GridTuple);
+    if (bytes > gs->slab_left) {
+        size_t slab = 256ull << 20;
+        if (slab < bytes) slab = bytes;
+        void *p = nullptr;
+        const int rc = pcq_pool_alloc(ctx, slab, &p);
+        if (rc) return rc;
+        gs->slabs.push_back(p);
+        gs->slab_cur = (uint8_t *)p;
+        gs->slab_left = slab;
+    }
+    *out = (GridTuple *)gs->slab_cur;
+    const size_t used = (bytes + 255) & ~(size_t)255;
+    gs->slab_cur += used < gs->slab_left ? used : gs->slab_left;
+    gs->slab_left -= used < gs->slab_left ? used : gs->slab_left;
     return PCQ_OK;
 }
 
-static uint64_t next_pow2(uint64_t v) {
-    uint64_t p = 1024;
-    while (p < v) p <<= 1;
-    return p;
-}
-
-static int grid_blocks(pcq_ctx *ctx, uint64_t n) {
-    uint64_t want = (n + BLOCK * GRID_BATCH - 1) / (BLOCK * GRID_BATCH);
-    const uint64_t cap = (uint64_t)ctx->num_cus * 16;
-    if (want < 1) want = 1;
-    return (int)(want < cap ? want : cap);
-}
-
-// Make room for `additional` new cells: load factor <= 1/2.
-static int grid_reserve(pcq_ctx *ctx, pcq_collector *c, uint64_t additional, hipStream_t s) {
-    const uint64_t need = next_pow2(2 * (c->table_used_bound + additional) + 1);
-    if (c->table.slots && c->table.cap >= need) return PCQ_OK;
-    if (!c->table.slots) return table_alloc(ctx, &c->table, need, s);
-    DevGridTable nt;
-    int rc = table_alloc(ctx, &nt, need, s);
-    if (rc) return rc;
-    // carry the counters over, then re-insert
-    PCQ_HIP(hipMemcpyAsync(nt.occupied, c->table.occupied, OCC_WORDS * 8, hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(k_grid_rehash, dim3(grid_blocks(ctx, c->table.cap)), dim3(BLOCK), 0, s, c->table, nt);
-    PCQ_HIP(hipGetLastError());
-    PCQ_HIP(hipStreamSynchronize(s));
-    pcq_grid_release(c);
-    c->table = nt;
-    return PCQ_OK;
-}
-
-int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const DevPred &pred,
-                  uint64_t matches_upper_bound, hipStream_t s) {
-    if (cols.n == 0 || matches_upper_bound == 0) return PCQ_OK;
-    // new cells <= matches, and <= the number of distinct keys the bit layout can express
-    const uint64_t bitsum = c->bits[0] + c->bits[1] + c->bits[2];
-    uint64_t additional = matches_upper_bound;
-    if (bitsum < 62) {
-        const uint64_t keyspace = 1ull << bitsum;
-        const uint64_t room = keyspace > c->table_used_bound ? keyspace - c->table_used_bound : 0;
-        if (additional > room) additional = room;
-    }
-    // Table size.  `additional` is the guaranteed bound, but a coarse grid (the paper's 100 m cells: one cell per
-    // ~90 points) would then spread a few million cells over a table of gigabytes: every probe an HBM miss and a
-    // memset of the whole table per file.  So the first size is a guess — an eighth of the bound — unless this
-    // collector, or the previous scan of this context, has shown the grid to be dense; pass A raises the overflow
-    // word if the guess was too small and is then re-run (it is idempotent) on a table of the guaranteed size.
-    const uint64_t used_before = c->table_used_bound;
-    bool guessing = ctx->grid_guess && !c->grid_dense && !ctx->grid_dense_hint && additional > (1ull << 20);
-    int rc = grid_reserve(ctx, c, guessing ? additional / 8 : additional, s);
-    if (rc) return rc;
-    const int grid = grid_blocks(ctx, cols.n);
-    const DevGrid &g = c->grid;
-    const uint64_t cand_words = (cols.n + 63) / 64;  // candidate bitmap of this scan (context scratch, grow-only)
-    if (cand_words > ctx->cand_words) {
-        PCQ_HIP(hipStreamSynchronize(s));
-        if (ctx->d_cand) PCQ_HIP(hipFree(ctx->d_cand));
-        ctx->d_cand = nullptr;
-        ctx->cand_words = 0;
-        if (hipMalloc((void **)&ctx->d_cand, cand_words * 8) != hipSuccess) {
-            (void)hipGetLastError();
-            return pcq_fail(PCQ_ERR_NOMEM, "grid candidate bitmap: %llu bytes", (unsigned long long)(cand_words * 8));
+int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const DevPred &pred, hipStream_t s) {
+    if (cols_in.n == 0) return PCQ_OK;
+    if (!c->gs) c->gs = new GridState();
+    GridState *gs = c->gs;
+    const uint64_t budget = ctx->grid_pending_budget > 0 ? (uint64_t)ctx->grid_pending_budget : (384ull << 20);  // tuples: 9 GB
+    for (uint64_t first = 0; first < cols_in.n; first += RUN_POINTS) {
+        DevCols cols = cols_in;
+        cols.n = cols_in.n - first < RUN_POINTS ? cols_in.n - first : RUN_POINTS;
+        cols.first_index = cols_in.first_index + first;
+        cols.xyz = cols_in.xyz ? cols_in.xyz + first * cols_in.xyz_stride : nullptr;
+        cols.cls = cols_in.cls ? cols_in.cls + first * cols_in.cls_stride : nullptr;
+        cols.rgb = cols_in.rgb ? cols_in.rgb + first * cols_in.rgb_stride : nullptr;
+        // the entry: scans of one file share it (same scale / offset, indices within 32 bits of its base)
+        bool fresh = gs->entries.empty();
+        if (!fresh) {
+            const GridEntryDev &e = gs->entries.back();
+            fresh = memcmp(e.scale, cols.scale, sizeof e.scale) != 0 || memcmp(e.offset, cols.offset, sizeof e.offset) != 0 ||
+                    cols.first_index < gs->entry_end || cols.first_index + cols.n - gs->entry_base.back() > 0xffffffffull;
         }
-        ctx->cand_words = cand_words;
-    }
-    for (;;) {
-        PCQ_HIP(hipMemsetAsync(c->table.n_alias, 0, 24, s));  // per scan: aliased points, distance ties, overflow
-        const uint64_t shard_limit = guessing ? c->table.cap / OCC_SHARDS * 5 / 8 : ~0ull;
-        const uint64_t probe_limit = guessing ? 1024ull : ~0ull;
-        if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_grid_pass_a<PCQ_PRED_BOUNDS>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, c->table, probe_limit, shard_limit, ctx->d_cand);
-        else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_grid_pass_a<PCQ_PRED_CLASS>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, c->table, probe_limit, shard_limit, ctx->d_cand);
-        else hipLaunchKernelGGL(k_grid_pass_a<PCQ_PRED_BOUNDS_F64>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, c->table, probe_limit, shard_limit, ctx->d_cand);
+        if ((fresh && gs->entries.size() == 255) || gs->runs.size() == (size_t)MAX_RUNS ||
+            (gs->pending_cap && gs->pending_cap + cols.n > budget)) {
+            c->last_stream = s;
+            const int frc = grid_fold(ctx, c);
+            if (frc) return frc;
+            fresh = true;
+        }
+        if (fresh) {
+            GridEntryDev e;
+            for (int a = 0; a < 3; a++) e.scale[a] = cols.scale[a], e.offset[a] = cols.offset[a];
+            gs->entries.push_back(e);
+            gs->entry_base.push_back(cols.first_index);
+        }
+        gs->entry_end = cols.first_index + cols.n;
+        const uint32_t entry = (uint32_t)gs->entries.size() - 1;
+        const uint64_t idx_base = cols.first_index - gs->entry_base.back();
+
+        if (!gs->binoff_store) {
+            void *p = nullptr;
+            const int rc = pcq_pool_alloc(ctx, (size_t)MAX_RUNS * (F1 + 1) * sizeof(uint32_t), &p);
+            if (rc) return rc;
+            gs->binoff_store = (uint32_t *)p;
+        }
+        if (!ctx->d_grid_cnt) PCQ_HIP(hipMalloc((void **)&ctx->d_grid_cnt, (size_t)(P0_MAX_BLOCKS + 1) * F1 * sizeof(uint32_t)));
+        GridRun run;
+        run.cap = cols.n;
+        run.binoff = gs->binoff_store + gs->runs.size() * (F1 + 1);
+        int rc = grid_tuple_room(ctx, gs, cols.n, &run.tuples);
+        if (rc) return rc;
+        gs->pending_cap += cols.n;
+
+        uint64_t nblocks = (cols.n + P0_TILE - 1) / P0_TILE;
+        uint64_t maxb = (uint64_t)ctx->num_cus * 2;  // two workgroups per CU are resident (LDS); each owns one piece of every bin
+        if (maxb > P0_MAX_BLOCKS) maxb = P0_MAX_BLOCKS;
+        if (nblocks > maxb) nblocks = maxb;
+        uint64_t per_block = (cols.n + nblocks - 1) / nblocks;
+        per_block = (per_block + P0_TILE - 1) / P0_TILE * P0_TILE;
+        nblocks = (cols.n + per_block - 1) / per_block;
+        uint32_t *cnt = ctx->d_grid_cnt, *total = ctx->d_grid_cnt + (size_t)P0_MAX_BLOCKS * F1;
+        const DevGrid &g = c->grid;
+        const dim3 gb((unsigned)nblocks), tb(P0_NT);
+        if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_p0_hist<PCQ_PRED_BOUNDS>, gb, tb, 0, s, cols, pred, g, per_block, cnt);
+        else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_p0_hist<PCQ_PRED_CLASS>, gb, tb, 0, s, cols, pred, g, per_block, cnt);
+        else hipLaunchKernelGGL(k_p0_hist<PCQ_PRED_BOUNDS_F64>, gb, tb, 0, s, cols, pred, g, per_block, cnt);
+        hipLaunchKernelGGL(k_p0_scan_blocks, dim3(F1 / WAVES), dim3(BLOCK), 0, s, cnt, (int)nblocks, total);
+        hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, total, run.binoff, (uint32_t)F1);
+        if (pred.kind == PCQ_PRED_BOUNDS)
+            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_BOUNDS>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
+        else if (pred.kind == PCQ_PRED_CLASS)
+            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_CLASS>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
+        else
+            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_BOUNDS_F64>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
         PCQ_HIP(hipGetLastError());
-        hipLaunchKernelGGL(k_sum_occupied, dim3(1), dim3(OCC_SHARDS), 0, s, c->table.occupied, c->table.n_alias, ctx->d_scalars + 16);
-        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars + 16, 32, hipMemcpyDeviceToHost, s));
-        PCQ_HIP(hipStreamSynchronize(s));
-        if (!ctx->h_scalars[3]) break;
-        if (!guessing) return pcq_fail(PCQ_ERR_HIP, "grid table of the guaranteed size overflowed");
-        guessing = false;
-        ctx->grid_overflows++;
-        c->grid_dense = true;
-        c->table_used_bound = ctx->h_scalars[0];  // the cells inserted so far stay (re-inserting finds them)
-        const uint64_t still = additional > ctx->h_scalars[0] - used_before ? additional - (ctx->h_scalars[0] - used_before) : 0;
-        rc = grid_reserve(ctx, c, still, s);
-        if (rc) return rc;
+        gs->runs.push_back(run);
     }
-    c->table_used_bound = ctx->h_scalars[0];
-    if (ctx->h_scalars[1]) c->grid_has_alias = true;  // sticky: flagged keys stay flagged
-    // the next scan of this context starts from a guess again only if this one would have fitted it
-    ctx->grid_dense_hint = (c->table_used_bound - used_before) > additional / 8;
-    if (2 * c->table_used_bound >= c->table.cap) {  // only after a guess: back to a load factor <= 1/2 for the lookups
-        ctx->grid_regrows++;
-        rc = grid_reserve(ctx, c, 0, s);
-        if (rc) return rc;
+    return PCQ_OK;
+}
+
+// Folds the pending runs (and the earlier winners) into a new set of winners.  Synchronises.
+static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
+    GridState *gs = c->gs;
+    if (!gs || gs->runs.empty()) return PCQ_OK;
+    hipStream_t s = ctx->stream;
+    if (c->last_stream && c->last_stream != s) PCQ_HIP(hipStreamSynchronize(c->last_stream));
+    Scratch tmp(ctx);
+    const int nruns = (int)gs->runs.size();
+    const DevGrid &g = c->grid;
+
+    // run directory + entries
+    std::vector<GridSeg> hsegs(nruns);
+    for (int r = 0; r < nruns; r++) hsegs[r] = GridSeg{gs->runs[r].tuples, gs->runs[r].binoff};
+    GridSeg *d_segs = nullptr;
+    GridEntryDev *d_entries = nullptr;
+    uint32_t *d_bintot = nullptr, *d_binbase = nullptr;
+    unsigned long long *d_stats = nullptr;
+    int rc = tmp.get(nruns + 1, &d_segs);
+    if (!rc) rc = tmp.get(256, &d_entries);
+    if (!rc) rc = tmp.get(F1, &d_bintot);
+    if (!rc) rc = tmp.get(F1 + 1, &d_binbase);
+    if (!rc) rc = tmp.get(8, &d_stats);
+    if (rc) return rc;
+    PCQ_HIP(hipMemcpyAsync(d_segs, hsegs.data(), nruns * sizeof(GridSeg), hipMemcpyHostToDevice, s));
+    PCQ_HIP(hipMemcpyAsync(d_entries, gs->entries.data(), gs->entries.size() * sizeof(GridEntryDev), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_part_totals, dim3(F1 / BLOCK), dim3(BLOCK), 0, s, d_segs, nruns, (uint32_t)F1, d_bintot);
+    hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, d_bintot, d_binbase, (uint32_t)F1);
+    uint32_t h_probe[2] = {0, 0};  // tuples in the probe bins, tuples in all
+    PCQ_HIP(hipMemcpyAsync(&h_probe[0], d_binbase + PROBE_BINS, 4, hipMemcpyDeviceToHost, s));
+    PCQ_HIP(hipMemcpyAsync(&h_probe[1], d_binbase + F1, 4, hipMemcpyDeviceToHost, s));
+    PCQ_HIP(hipStreamSynchronize(s));  // also: the pageable sources above have been read
+    const uint64_t m = h_probe[1], w_old = gs->wtotal;
+    if (m == 0) {
+        grid_free_pending(ctx, gs);
+        return PCQ_OK;
     }
-    DevGridTable &t = c->table;
-    hipLaunchKernelGGL(k_grid_pass_b, dim3(grid), dim3(BLOCK), 0, s, cols, g, t, ctx->d_cand);
-    PCQ_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_sum_occupied, dim3(1), dim3(OCC_SHARDS), 0, s, t.occupied, t.n_alias, ctx->d_scalars + 16);
-    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars + 16, 32, hipMemcpyDeviceToHost, s));
-    PCQ_HIP(hipStreamSynchronize(s));
-    const uint64_t n_ties = ctx->h_scalars[2];
-    if (c->grid_has_alias) {
-        const uint64_t nblocks = (cols.n + TILE - 1) / TILE;
-        rc = pcq_ensure_partials(ctx, (size_t)nblocks);
+    ctx->grid_folds++;
+
+    // how dense is the grid?  estimated cells per level-1 bin -> fold the bins directly, or cut them again first
+    uint32_t f2 = 1;
+    const double old_per_bin = (double)w_old / F1;
+    if (ctx->grid_f2 > 0) {
+        f2 = (uint32_t)ctx->grid_f2;
+    } else if ((double)m / F1 + old_per_bin > BIG_DIRECT) {
+        uint64_t cap = 1024;
+        while (cap < 2ull * h_probe[0] + 2) cap <<= 1;
+        uint64_t *d_set = nullptr;
+        rc = tmp.get(cap, &d_set);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_alias_tile_counts, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, g, t, ctx->d_partials);
-        hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, ctx->d_partials, nblocks, ctx->d_scalars);
-        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars, 8, hipMemcpyDeviceToHost, s));
+        PCQ_HIP(hipMemsetAsync(d_set, 0xff, cap * 8, s));
+        PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
+        unsigned per_seg = (unsigned)((h_probe[0] / (unsigned)nruns + BLOCK - 1) / BLOCK);
+        if (per_seg < 1) per_seg = 1;
+        if (per_seg > 4096) per_seg = 4096;
+        hipLaunchKernelGGL(k_probe_distinct, dim3(per_seg, (unsigned)nruns), dim3(BLOCK), 0, s, d_segs, d_entries, g, d_set, cap - 1, d_stats);
+        unsigned long long distinct = 0;
+        PCQ_HIP(hipMemcpyAsync(&distinct, d_stats, 8, hipMemcpyDeviceToHost, s));
         PCQ_HIP(hipStreamSynchronize(s));
-        const uint64_t nlist = ctx->h_scalars[0];
-        if (nlist) {
-            uint64_t *d_list = nullptr;
-            PCQ_HIP(hipMalloc((void **)&d_list, nlist * 16));
-            uint64_t *d_lkeys = d_list + nlist;
-            hipLaunchKernelGGL(k_alias_emit, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, cols, pred, g, t, ctx->d_partials,
-                               d_list, d_lkeys);
-            hipLaunchKernelGGL(k_grid_pass_r, dim3((unsigned)((nlist + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, cols, g, t,
-                               d_list, d_lkeys, nlist);
-            hipError_t e = hipStreamSynchronize(s);
-            (void)hipFree(d_list);
-            if (e != hipSuccess) return pcq_fail(PCQ_ERR_HIP, "grid pass R failed: %s", hipGetErrorString(e));
+        const double est = (double)distinct / PROBE_BINS + old_per_bin;
+        if (est > BIG_DIRECT) {
+            f2 = (uint32_t)std::ceil(est / SMALL_TARGET);
+            if (f2 > F2_MAX) f2 = F2_MAX;
         }
     }
-    if (n_ties) {
-        if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_grid_pass_c<PCQ_PRED_BOUNDS>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
-        else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_grid_pass_c<PCQ_PRED_CLASS>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
-        else hipLaunchKernelGGL(k_grid_pass_c<PCQ_PRED_BOUNDS_F64>, dim3(grid), dim3(BLOCK), 0, s, cols, pred, g, t);
+
+    for (int attempt = 0;; attempt++) {
+        const uint32_t nparts = (uint32_t)F1 * f2;
+        Scratch att(ctx);
+        const GridSeg *fold_segs = d_segs;
+        GridSeg fold_seg0 = hsegs[0];
+        int fold_nsegs = nruns;
+        const uint32_t *d_tot = d_bintot;
+        const uint64_t *obase = gs->wbase;
+        const uint32_t *ocount = gs->wcount;
+        const uint64_t *okeys = gs->wkeys;
+        const uint8_t *orecs = gs->wrecs;
+        const bool recut_old = w_old && gs->f2 != f2;
+        if (f2 > 1 || recut_old) {
+            Level2Params L{};
+            L.segs = d_segs, L.nsegs = nruns, L.entries = d_entries, L.g = g, L.f2 = f2;
+            GridTuple *d_t2 = nullptr;
+            uint32_t *d_off2 = nullptr;
+            if (f2 > 1) {
+                rc = att.get(m, &d_t2);
+                if (!rc) rc = att.get((size_t)nparts + 1, &d_off2);
+                if (rc) return rc;
+                L.binbase = d_binbase, L.out = d_t2, L.off2 = d_off2;
+            }
+            uint64_t *d_okeys2 = nullptr, *d_obase2 = nullptr;
+            uint8_t *d_orecs2 = nullptr;
+            uint32_t *d_ooff2 = nullptr, *d_ocount2 = nullptr, *d_obin = nullptr, *d_obinbase = nullptr;
+            if (recut_old) {
+                rc = att.get(w_old, &d_okeys2);
+                if (!rc) rc = att.get(w_old * 32, &d_orecs2);
+                if (!rc) rc = att.get((size_t)nparts + 1, &d_ooff2);
+                if (!rc) rc = att.get((size_t)nparts + 1, &d_obase2);
+                if (!rc) rc = att.get((size_t)nparts + 1, &d_ocount2);
+                if (!rc) rc = att.get(F1, &d_obin);
+                if (!rc) rc = att.get(F1 + 1, &d_obinbase);
+                if (rc) return rc;
+                hipLaunchKernelGGL(k_old_per_bin, dim3(F1 / BLOCK), dim3(BLOCK), 0, s, gs->wcount, gs->f2, d_obin);
+                hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, d_obin, d_obinbase, (uint32_t)F1);
+                L.okeys = gs->wkeys, L.orecs = gs->wrecs, L.obase = gs->wbase, L.ocount = gs->wcount, L.f2old = gs->f2;
+                L.obinbase = d_obinbase, L.okeys2 = d_okeys2, L.orecs2 = d_orecs2, L.ooff2 = d_ooff2;
+            }
+            hipLaunchKernelGGL(k_level2, dim3(F1), dim3(L2_NT), 0, s, L);
+            PCQ_HIP(hipGetLastError());
+            if (f2 > 1) {
+                ctx->grid_level2++;
+                GridSeg one{d_t2, d_off2};
+                GridSeg *d_one = nullptr;
+                uint32_t *d_tot2 = nullptr;
+                rc = att.get(1, &d_one);
+                if (!rc) rc = att.get(nparts, &d_tot2);
+                if (rc) return rc;
+                PCQ_HIP(hipMemcpyAsync(d_one, &one, sizeof one, hipMemcpyHostToDevice, s));
+                PCQ_HIP(hipStreamSynchronize(s));  // `one` is on this stack frame
+                hipLaunchKernelGGL(k_part_totals, dim3((nparts + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_one, 1, nparts, d_tot2);
+                fold_segs = d_one, fold_seg0 = one, fold_nsegs = 1, d_tot = d_tot2;
+            }
+            if (recut_old) {
+                hipLaunchKernelGGL(k_unpack_old_dir, dim3((nparts + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_ooff2, nparts, d_obase2, d_ocount2);
+                okeys = d_okeys2, orecs = d_orecs2, obase = d_obase2, ocount = d_ocount2;
+            }
+        }
+        // room for the winners
+        const bool big = f2 == 1;
+        const uint32_t limit = big ? BIG_LIMIT : SMALL_LIMIT;
+        uint64_t wcap = m + w_old;
+        if (wcap > (uint64_t)nparts * limit) wcap = (uint64_t)nparts * limit;
+        if (wcap >= (1ull << 32)) return pcq_fail(PCQ_ERR_UNSUPPORTED, "grid collector: more than 2^32 cells in one fold");
+        uint64_t *n_wkeys = nullptr, *n_wbase = nullptr, *d_room = nullptr, *d_pieces = nullptr, *d_piece_pre = nullptr;
+        uint8_t *n_wrecs = nullptr;
+        uint32_t *n_wcount = nullptr, *d_palias = nullptr, *d_pay = nullptr;
+        const uint32_t npieces = (nparts + SCAN_PIECE - 1) / SCAN_PIECE;
+        rc = att.get(wcap, &n_wkeys);
+        if (!rc) rc = att.get(wcap * 32, &n_wrecs);
+        if (!rc) rc = att.get((size_t)nparts + 1, &n_wbase);
+        if (!rc) rc = att.get(nparts, &n_wcount);
+        if (!rc) rc = att.get(nparts, &d_room);
+        if (!rc) rc = att.get(nparts, &d_palias);
+        if (!rc) rc = att.get(npieces, &d_pieces);
+        if (!rc) rc = att.get((size_t)npieces + 1, &d_piece_pre);
+        if (!rc && big) rc = att.get((size_t)nparts * BIG_SLOTS * 5, &d_pay);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_winner_room, dim3((nparts + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_tot, w_old ? ocount : nullptr, nparts, limit, d_room);
+        hipLaunchKernelGGL(k_scan_piece_sums, dim3(npieces), dim3(1024), 0, s, d_room, nparts, d_pieces);
+        hipLaunchKernelGGL(k_excl_scan_u64, dim3(1), dim3(1024), 0, s, d_pieces, d_piece_pre, npieces);
+        hipLaunchKernelGGL(k_scan_pieces, dim3(npieces), dim3(1024), 0, s, d_room, nparts, d_piece_pre, n_wbase);
+        PCQ_HIP(hipMemsetAsync(d_palias, 0, (size_t)nparts * 4, s));
+        PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
+        FoldParams F{};
+        F.segs = fold_segs, F.nsegs = fold_nsegs, F.seg0 = fold_seg0, F.entries = d_entries, F.g = g;
+        if (w_old) F.okeys = okeys, F.orecs = orecs, F.obase = obase, F.ocount = ocount;
+        F.wkeys = n_wkeys, F.wrecs = n_wrecs, F.wbase = n_wbase, F.wcount = n_wcount, F.palias = d_palias, F.pay_scratch = d_pay, F.stats = d_stats;
+        if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_LIMIT, false>), dim3(nparts), dim3(BIG_NT), 0, s, F);
+        else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_LIMIT, true>), dim3(nparts), dim3(SMALL_NT), 0, s, F);
+        PCQ_HIP(hipGetLastError());
+        unsigned long long st[4] = {0, 0, 0, 0};
+        PCQ_HIP(hipMemcpyAsync(st, d_stats, sizeof st, hipMemcpyDeviceToHost, s));
+        PCQ_HIP(hipStreamSynchronize(s));
+        if (st[1]) {  // a partition held more cells than the LDS table: more partitions
+            if (f2 >= F2_MAX || attempt > 8) return pcq_fail(PCQ_ERR_UNSUPPORTED, "grid collector: a partition does not fit the LDS table at the largest fan-out");
+            ctx->grid_refolds++;
+            f2 = big ? (uint32_t)((BIG_LIMIT * 3 / 2 + SMALL_TARGET - 1) / SMALL_TARGET) : (f2 * 2 > F2_MAX ? F2_MAX : f2 * 2);
+            continue;
+        }
+        if (st[2]) {  // aliased keys: gather their tuples, sort by (key, file order), replay
+            PCQ_HIP(hipMemsetAsync(d_stats + 4, 0, 8, s));
+            hipLaunchKernelGGL(k_alias_gather<false>, dim3(nparts), dim3(L2_NT), 0, s, F, (AliasItem *)nullptr, d_stats + 4);
+            unsigned long long na = 0;
+            PCQ_HIP(hipMemcpyAsync(&na, d_stats + 4, 8, hipMemcpyDeviceToHost, s));
+            PCQ_HIP(hipStreamSynchronize(s));
+            if (na) {
+                AliasItem *d_list = nullptr, *d_sorted = nullptr;
+                rc = att.get(na, &d_list);
+                if (!rc) rc = att.get(na, &d_sorted);
+                if (rc) return rc;
+                PCQ_HIP(hipMemsetAsync(d_stats + 4, 0, 8, s));
+                hipLaunchKernelGGL(k_alias_gather<true>, dim3(nparts), dim3(L2_NT), 0, s, F, d_list, d_stats + 4);
+                hipLaunchKernelGGL(k_alias_rank, dim3((unsigned)((na + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, d_list, (uint64_t)na, d_sorted);
+                hipLaunchKernelGGL(k_alias_replay, dim3((unsigned)((na + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, d_sorted, (uint64_t)na, F, f2);
+                PCQ_HIP(hipGetLastError());
+                PCQ_HIP(hipStreamSynchronize(s));
+            }
+        }
+        // install
+        att.keep(n_wkeys), att.keep(n_wrecs), att.keep(n_wbase), att.keep(n_wcount);
+        grid_free_winners(ctx, gs);
+        gs->wkeys = n_wkeys, gs->wrecs = n_wrecs, gs->wbase = n_wbase, gs->wcount = n_wcount;
+        gs->f2 = f2;
+        gs->wtotal = st[0];
+        ctx->grid_last_f2 = f2;
+        break;
     }
-    PCQ_HIP(hipGetLastError());
+    grid_free_pending(ctx, gs);
     return PCQ_OK;
 }
 
@@ -710,32 +1330,30 @@ int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_
     pcq_ctx *ctx = c->ctx;
     hipStream_t s = ctx->stream;
     *out_n = 0;
-    if (c->last_stream && c->last_stream != s) PCQ_HIP(hipStreamSynchronize(c->last_stream));
-    if (!c->table.slots) return PCQ_OK;
-    hipLaunchKernelGGL(k_sum_occupied, dim3(1), dim3(OCC_SHARDS), 0, s, c->table.occupied, c->table.n_alias, ctx->d_scalars + 16);
-    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, ctx->d_scalars + 16, 8, hipMemcpyDeviceToHost, s));
-    PCQ_HIP(hipStreamSynchronize(s));
-    const uint64_t n = ctx->h_scalars[0];
+    GridState *gs = c->gs;
+    if (!gs) return PCQ_OK;
+    int rc = grid_fold(ctx, c);
+    if (rc) return rc;
+    const uint64_t n = gs->wtotal;
     *out_n = n;
     if ((!out && !keys_out) || n == 0) return PCQ_OK;
     if (cap < n) return pcq_fail(PCQ_ERR_CAPACITY, "grid collector holds %llu points, capacity %llu", (unsigned long long)n,
                                  (unsigned long long)cap);
+    Scratch tmp(ctx);
+    const uint32_t nparts = (uint32_t)F1 * gs->f2;
+    uint32_t *d_pre = nullptr;
     uint8_t *d_out = nullptr;
     uint64_t *d_keys = nullptr;
-    const uint64_t nblocks = (c->table.cap + TILE - 1) / TILE;
-    int rc = pcq_ensure_partials(ctx, (size_t)nblocks);
+    rc = tmp.get((size_t)nparts + 1, &d_pre);
+    if (!rc && out) rc = tmp.get(n * 31 + 16, &d_out);
+    if (!rc && keys_out) rc = tmp.get(n, &d_keys);
     if (rc) return rc;
-    if (out) PCQ_HIP(hipMalloc((void **)&d_out, n * 31));
-    if (keys_out) PCQ_HIP(hipMalloc((void **)&d_keys, n * 8));
-    hipLaunchKernelGGL(k_drain_tile_counts, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, c->table, ctx->d_partials);
-    hipLaunchKernelGGL(k_scan_u64, dim3(1), dim3(1024), 0, s, ctx->d_partials, nblocks, ctx->d_scalars);
-    hipLaunchKernelGGL(k_drain_emit, dim3((unsigned)nblocks), dim3(BLOCK), 0, s, c->table, ctx->d_partials, d_out, d_keys);
+    hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, gs->wcount, d_pre, nparts);
+    hipLaunchKernelGGL(k_drain, dim3(nparts), dim3(BLOCK), 0, s, gs->wkeys, gs->wrecs, gs->wbase, gs->wcount, d_pre, d_out, d_keys);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && out) e = hipMemcpyAsync(out, d_out, n * 31, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && keys_out) e = hipMemcpyAsync(keys_out, d_keys, n * 8, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
-    if (d_out) (void)hipFree(d_out);
-    if (d_keys) (void)hipFree(d_keys);
     if (e != hipSuccess) return pcq_fail(PCQ_ERR_HIP, "grid drain failed: %s", hipGetErrorString(e));
     return PCQ_OK;
 }

@@ -140,6 +140,7 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
 }
 
 extern "C" int pcq_shutdown(pcq_ctx *ctx) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx) return PCQ_OK;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -152,9 +153,9 @@ extern "C" int pcq_shutdown(pcq_ctx *ctx) {
     }
     delete ctx->copy_pool;
     ctx->copy_pool = nullptr;
-    pcq_grid_cache_clear(ctx);
+    pcq_pool_clear(ctx);
+    if (ctx->d_grid_cnt) (void)hipFree(ctx->d_grid_cnt);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
-    if (ctx->d_cand) (void)hipFree(ctx->d_cand);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
     if (ctx->d_segments) (void)hipFree(ctx->d_segments);
@@ -163,6 +164,66 @@ extern "C" int pcq_shutdown(pcq_ctx *ctx) {
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     delete ctx;
     return PCQ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// device-memory pool
+// ---------------------------------------------------------------------------------------------
+int pcq_pool_alloc(pcq_ctx *ctx, size_t bytes, void **out) {
+    *out = nullptr;
+    if (bytes == 0) bytes = 256;
+    PoolBlock *best = nullptr;  // the smallest free block that is large enough, and not wastefully larger
+    for (PoolBlock &b : ctx->pool)
+        if (!b.used && b.bytes >= bytes && (b.bytes <= 2 * bytes + (64u << 20)) && (!best || b.bytes < best->bytes)) best = &b;
+    if (best) {
+        best->used = true;
+        *out = best->p;
+        return PCQ_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {  // give the free blocks back and try once more
+        (void)hipGetLastError();
+        for (size_t i = 0; i < ctx->pool.size();) {
+            if (!ctx->pool[i].used) {
+                (void)hipFree(ctx->pool[i].p);
+                ctx->pool.erase(ctx->pool.begin() + (long)i);
+            } else {
+                i++;
+            }
+        }
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return pcq_fail(PCQ_ERR_NOMEM, "device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    }
+    ctx->pool.push_back(PoolBlock{p, bytes, true});
+    *out = p;
+    return PCQ_OK;
+}
+
+void pcq_pool_free(pcq_ctx *ctx, void *p) {
+    if (!p) return;
+    uint64_t free_bytes = 0;
+    for (PoolBlock &b : ctx->pool) {
+        if (b.p == p) b.used = false;
+        if (!b.used) free_bytes += b.bytes;
+    }
+    while (free_bytes > ctx->pool_limit) {  // keep the pool bounded: drop the largest free block
+        size_t big = ctx->pool.size();
+        for (size_t i = 0; i < ctx->pool.size(); i++)
+            if (!ctx->pool[i].used && (big == ctx->pool.size() || ctx->pool[i].bytes > ctx->pool[big].bytes)) big = i;
+        if (big == ctx->pool.size()) break;
+        free_bytes -= ctx->pool[big].bytes;
+        (void)hipFree(ctx->pool[big].p);
+        ctx->pool.erase(ctx->pool.begin() + (long)big);
+    }
+}
+
+void pcq_pool_clear(pcq_ctx *ctx) {
+    for (PoolBlock &b : ctx->pool) (void)hipFree(b.p);
+    ctx->pool.clear();
 }
 
 int pcq_ensure_partials(pcq_ctx *ctx, size_t n) {
@@ -197,6 +258,7 @@ extern "C" int pcq_get_device_info(pcq_ctx *ctx, pcq_device_info *out) {
 extern "C" void *pcq_ctx_stream(pcq_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 extern "C" int pcq_ctx_synchronize(pcq_ctx *ctx) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_ctx_synchronize: null context");
     PCQ_HIP(hipStreamSynchronize(ctx->stream));
     PCQ_HIP(hipStreamSynchronize(ctx->copy_stream));
@@ -211,6 +273,7 @@ extern "C" int pcq_bind_thread_near_device(pcq_ctx *ctx) {
 }
 
 extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx || !key) return pcq_fail(PCQ_ERR_ARG, "pcq_set_option: null argument");
     if (!strcmp(key, "k1_variant")) {
         if (value < 0 || value > 14) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..14");
@@ -239,9 +302,12 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "batch_waves_per_cu")) {
         if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "batch_waves_per_cu must be 1..32");
         ctx->batch_waves_per_cu = (int)value;
-    } else if (!strcmp(key, "grid_guess")) {
-        ctx->grid_guess = value != 0;
-        ctx->grid_dense_hint = false;
+    } else if (!strcmp(key, "grid_pending_budget")) {
+        if (value < 0) return pcq_fail(PCQ_ERR_ARG, "grid_pending_budget must be >= 0");
+        ctx->grid_pending_budget = value;
+    } else if (!strcmp(key, "grid_f2")) {
+        if (value < 0 || value > 256) return pcq_fail(PCQ_ERR_ARG, "grid_f2 must be 0..256");
+        ctx->grid_f2 = (int)value;
     } else if (!strcmp(key, "numa_local")) {
         ctx->numa_local = value != 0;
         delete ctx->copy_pool;  // helpers are re-created with or without the affinity
@@ -280,10 +346,12 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     else if (!strcmp(key, "copy_threads")) *value = ctx->copy_threads;
     else if (!strcmp(key, "numa_local")) *value = ctx->numa_local;
     else if (!strcmp(key, "numa_node")) *value = ctx->numa_node;
-    else if (!strcmp(key, "grid_guess")) *value = ctx->grid_guess;
-    else if (!strcmp(key, "grid_dense_hint")) *value = ctx->grid_dense_hint;
-    else if (!strcmp(key, "grid_overflows")) *value = ctx->grid_overflows;
-    else if (!strcmp(key, "grid_regrows")) *value = ctx->grid_regrows;
+    else if (!strcmp(key, "grid_pending_budget")) *value = ctx->grid_pending_budget;
+    else if (!strcmp(key, "grid_f2")) *value = ctx->grid_f2;
+    else if (!strcmp(key, "grid_folds")) *value = ctx->grid_folds;
+    else if (!strcmp(key, "grid_level2")) *value = ctx->grid_level2;
+    else if (!strcmp(key, "grid_refolds")) *value = ctx->grid_refolds;
+    else if (!strcmp(key, "grid_last_f2")) *value = ctx->grid_last_f2;
     else return pcq_fail(PCQ_ERR_ARG, "unknown option '%s'", key);
     return PCQ_OK;
 }
@@ -292,6 +360,7 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
 // device memory helpers
 // ---------------------------------------------------------------------------------------------
 extern "C" int pcq_device_alloc(pcq_ctx *ctx, uint64_t bytes, void **out) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx || !out) return pcq_fail(PCQ_ERR_ARG, "pcq_device_alloc: null argument");
     *out = nullptr;
     PCQ_HIP(hipSetDevice(ctx->device));
@@ -299,16 +368,19 @@ extern "C" int pcq_device_alloc(pcq_ctx *ctx, uint64_t bytes, void **out) {
     return PCQ_OK;
 }
 extern "C" int pcq_device_free(pcq_ctx *ctx, void *p) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_device_free: null context");
     if (p) PCQ_HIP(hipFree(p));
     return PCQ_OK;
 }
 extern "C" int pcq_copy_to_device(pcq_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx || (!dst && bytes) || (!src && bytes)) return pcq_fail(PCQ_ERR_ARG, "pcq_copy_to_device: null argument");
     if (bytes) PCQ_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
     return PCQ_OK;
 }
 extern "C" int pcq_copy_to_host(pcq_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx || (!dst && bytes) || (!src && bytes)) return pcq_fail(PCQ_ERR_ARG, "pcq_copy_to_host: null argument");
     if (bytes) {
         PCQ_HIP(hipStreamSynchronize(ctx->stream));
@@ -317,6 +389,7 @@ extern "C" int pcq_copy_to_host(pcq_ctx *ctx, void *dst, const void *src, uint64
     return PCQ_OK;
 }
 extern "C" int pcq_device_memset(pcq_ctx *ctx, void *dst, int value, uint64_t bytes, void *stream) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx || (!dst && bytes)) return pcq_fail(PCQ_ERR_ARG, "pcq_device_memset: null argument");
     if (bytes) PCQ_HIP(hipMemsetAsync(dst, value, bytes, stream ? (hipStream_t)stream : ctx->stream));
     return PCQ_OK;
@@ -391,12 +464,12 @@ static int new_collector(pcq_ctx *ctx, int kind, pcq_collector **out) {
     if (!c) return pcq_fail(PCQ_ERR_NOMEM, "collector: out of memory");
     c->kind = kind;
     c->ctx = ctx;
-    c->table = DevGridTable{};
     *out = c;
     return PCQ_OK;
 }
 
 extern "C" int pcq_collector_new_count(pcq_ctx *ctx, pcq_collector **out) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     int rc = new_collector(ctx, COLL_COUNT, out);
     if (rc) return rc;
     pcq_collector *c = *out;
@@ -413,6 +486,7 @@ extern "C" int pcq_collector_new_count(pcq_ctx *ctx, pcq_collector **out) {
 }
 
 extern "C" int pcq_collector_new_count_at(pcq_ctx *ctx, uint64_t *device_counter, pcq_collector **out) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!device_counter) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_new_count_at: null counter");
     int rc = new_collector(ctx, COLL_COUNT, out);
     if (rc) return rc;
@@ -426,6 +500,7 @@ extern "C" int pcq_collector_new_buffer(pcq_ctx *ctx, pcq_collector **out) { ret
 // SparseGrid::new — grid_sampling.rs:18-47
 extern "C" int pcq_collector_new_grid(pcq_ctx *ctx, const double bmin[3], const double bmax[3], double cell_size,
                                       pcq_collector **out) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!bmin || !bmax) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_new_grid: null bounds");
     int rc = new_collector(ctx, COLL_GRID, out);
     if (rc) return rc;
@@ -472,6 +547,7 @@ extern "C" int pcq_collector_new_grid(pcq_ctx *ctx, const double bmin[3], const 
 }
 
 extern "C" int pcq_collector_free(pcq_collector *c) {
+    PCQ_ON_DEVICE_OF_COLLECTOR(c);
     if (!c) return PCQ_OK;
     if (c->ctx) {
         (void)hipSetDevice(c->ctx->device);
@@ -486,6 +562,7 @@ extern "C" int pcq_collector_free(pcq_collector *c) {
 }
 
 extern "C" int pcq_collector_reset(pcq_collector *c) {
+    PCQ_ON_DEVICE_OF_COLLECTOR(c);
     if (!c) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_reset: null collector");
     hipStream_t s = c->ctx->stream;
     c->next_index = 0;
@@ -493,9 +570,8 @@ extern "C" int pcq_collector_reset(pcq_collector *c) {
     if (c->kind == COLL_BUFFER) c->n_points = 0;
     if (c->kind == COLL_GRID) {
         PCQ_HIP(hipStreamSynchronize(s));
+        if (c->last_stream && c->last_stream != s) PCQ_HIP(hipStreamSynchronize(c->last_stream));
         pcq_grid_release(c);
-        c->table_used_bound = 0;
-        c->grid_has_alias = false;
     }
     return PCQ_OK;
 }
@@ -503,6 +579,7 @@ extern "C" int pcq_collector_reset(pcq_collector *c) {
 extern "C" int pcq_collector_has_points(const pcq_collector *c) { return c && c->kind != COLL_COUNT; }
 
 extern "C" int pcq_collector_point_count(pcq_collector *c, uint64_t *out) {
+    PCQ_ON_DEVICE_OF_COLLECTOR(c);
     if (!c || !out) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_point_count: null argument");
     pcq_ctx *ctx = c->ctx;
     if (c->last_stream && c->last_stream != ctx->stream) PCQ_HIP(hipStreamSynchronize(c->last_stream));
@@ -522,6 +599,7 @@ extern "C" int pcq_collector_point_count(pcq_collector *c, uint64_t *out) {
 }
 
 extern "C" int pcq_collector_points(pcq_collector *c, pcq_point *out, uint64_t cap, uint64_t *out_n) {
+    PCQ_ON_DEVICE_OF_COLLECTOR(c);
     if (!c || !out_n) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_points: null argument");
     pcq_ctx *ctx = c->ctx;
     *out_n = 0;
@@ -541,6 +619,7 @@ extern "C" int pcq_collector_points(pcq_collector *c, pcq_point *out, uint64_t c
 }
 
 extern "C" int pcq_collector_grid_cells(pcq_collector *c, uint64_t *out, uint64_t cap, uint64_t *out_n) {
+    PCQ_ON_DEVICE_OF_COLLECTOR(c);
     if (!c || !out_n) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_grid_cells: null argument");
     if (c->kind != COLL_GRID) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_grid_cells: not a grid collector");
     return pcq_grid_drain(c, nullptr, out, cap, out_n);
@@ -653,21 +732,14 @@ static int scan_dev_impl(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predic
     }
     case COLL_GRID: {
         if (dp.kind == PCQ_PRED_BOUNDS && dp.empty) return PCQ_OK;
-        // the number of matches bounds the number of new cells (sizes the hash table)
-        PCQ_HIP(hipMemsetAsync(ctx->d_scalars + 8, 0, 8, s));
-        rc = count_into(ctx, dc, dp, ctx->d_scalars + 8, s);
-        if (rc) return rc;
-        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars + 8, ctx->d_scalars + 8, 8, hipMemcpyDeviceToHost, s));
-        PCQ_HIP(hipStreamSynchronize(s));
-        const uint64_t matches = ctx->h_scalars[8];
-        if (matches == 0) return PCQ_OK;
-        return pcq_grid_scan(ctx, c, dc, dp, matches, s);
+        return pcq_grid_scan(ctx, c, dc, dp, s);  // asynchronous: the matches are partitioned now and folded when a result is asked for
     }
     }
     return pcq_fail(PCQ_ERR_ARG, "scan: unknown collector kind");
 }
 
 extern "C" int pcq_scan_dev(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c, void *stream) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_dev: null context");
     return scan_dev_impl(ctx, cols, pred, c, stream ? (hipStream_t)stream : ctx->stream);
 }
@@ -899,14 +971,17 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
 }
 
 extern "C" int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     return scan_host_impl(ctx, -1, cols, pred, c, true);
 }
 
 extern "C" int pcq_scan_host_nowait(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     return scan_host_impl(ctx, -1, cols, pred, c, false);
 }
 
 extern "C" int pcq_scan_fd(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (fd < 0) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_fd: bad file descriptor");
     return scan_host_impl(ctx, fd, cols, pred, c, true);
 }

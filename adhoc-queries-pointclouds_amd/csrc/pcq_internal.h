@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "pcq.h"
 
@@ -24,6 +25,26 @@ int pcq_fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)
             return pcq_fail(PCQ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
                             __FILE__, __LINE__);                                                \
     } while (0)
+
+// Every entry point that takes a context or a collector runs on the context's device, whatever device the calling
+// thread used before (a driver thread draining the collectors of several GPUs sits on device 0 by default: memory
+// allocated and kernels launched from there would land on the wrong GPU).  The caller's device is restored on return.
+struct DeviceGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceGuard(int device) {
+        if (device < 0) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != device) changed = hipSetDevice(device) == hipSuccess && prev >= 0;
+    }
+    ~DeviceGuard() {
+        if (changed) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define PCQ_ON_DEVICE_OF_CTX(ctx) DeviceGuard _device_guard((ctx) ? (ctx)->device : -1)
+#define PCQ_ON_DEVICE_OF_COLLECTOR(c) DeviceGuard _device_guard((c) && (c)->ctx ? (c)->ctx->device : -1)
 
 // ---------------------------------------------------------------------------------------------
 // device-side views
@@ -84,32 +105,18 @@ struct DevGrid {
     uint32_t shift[3];    // 0, bits_x, bits_x + bits_y  (already & 63)
 };
 
-// HBM hash table behind the grid collector.  One 32-byte slot holds everything the three passes
-// touch for a cell (key, best distance, winner index, flags), so a probe costs ONE random memory
-// access; the winner's record lives in a parallel 32-byte array.  A fresh table is all-ones:
-// key = empty, dist = +max, widx = none, and the flag bits are therefore stored INVERTED
-// (bit cleared = set).
-struct GridSlot {
-    uint64_t key;     // PCQ_EMPTY_KEY = free
-    uint64_t dist;    // f64 bits of the winning squared distance (monotone for d >= 0)
-    uint64_t widx;    // file-order index of the winner
-    uint32_t nflags;  // inverted: bit0 clear = pts[slot] holds a materialised point, bit1 clear = aliased key
-    uint32_t _pad;
-};
-struct DevGridTable {
-    GridSlot *slots;
-    uint8_t *pts;         // 32-byte records: the winner's pcq_point (31 bytes used)
-    uint64_t cap;         // power of two
-    uint64_t *occupied;   // sharded device counters of used slots
-    uint64_t *n_alias;    // device counter of aliased points seen in the current scan
-};
-
 constexpr uint64_t PCQ_EMPTY_KEY = ~0ull;
 constexpr uint64_t PCQ_NO_INDEX = ~0ull;
 
 // ---------------------------------------------------------------------------------------------
 // host-side objects
 // ---------------------------------------------------------------------------------------------
+struct GridState;
+struct PoolBlock {
+    void *p = nullptr;
+    size_t bytes = 0;
+    bool used = false;
+};
 struct pcq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // compute stream
@@ -134,15 +141,17 @@ struct pcq_ctx {
     size_t segments_cap = 0;
     size_t segments_uploaded = 0;       // number of segments of the table currently in d_segments (0 = none)
     int segments_kind = -1;             // predicate kind of the uploaded table
-    // one retired grid hash table kept for reuse: per-file grids (main.rs:156) would otherwise
-    // hipMalloc/hipFree tens of GB per file, and a fresh 30 GB allocation right after a free was
-    // measured to stall for seconds (profiles/r01_grid_timeline.txt)
-    DevGridTable grid_cache[2] = {};    // retired grid tables, reused by later grids (grid.hip)
-    uint64_t *d_cand = nullptr;         // grid pass A -> B candidate bitmap (grid.hip)
-    uint64_t cand_words = 0;
-    int grid_guess = 1;                 // option: size grid tables from a guess first (grid.hip)
-    int64_t grid_overflows = 0, grid_regrows = 0;  // diagnostics: guesses that overflowed / were enlarged after pass A
-    bool grid_dense_hint = false;       // the last grid scan filled more than a sixteenth of its guaranteed bound (grid.hip)
+    // device-memory pool (pcq_pool_alloc / pcq_pool_free): the grid collector's tuple runs, partition buffers and
+    // winner arrays are gigabytes per file, and a device allocation of that size costs from tens of milliseconds to
+    // over a second (profiles/r01_grid_timeline.txt) — per-file grids (main.rs:156) reuse the blocks of the file before
+    std::vector<PoolBlock> pool;
+    uint64_t pool_limit = 96ull << 30;  // free bytes the pool may keep
+    uint32_t *d_grid_cnt = nullptr;     // grid pass 0: per-(block, bin) tuple counts of the run in flight (grid.hip)
+    // diagnostics of the grid collector (pcq_get_option): folds run, folds that needed a second partition level,
+    // folds repeated because a partition overflowed its LDS table, the last fold's second-level fan-out
+    int64_t grid_folds = 0, grid_level2 = 0, grid_refolds = 0, grid_last_f2 = 0;
+    int64_t grid_pending_budget = 0;    // option: tuples a grid collector may hold before it folds (0 = default)
+    int grid_f2 = 0;                    // option (tests): second-level fan-out a fold starts from (0 = from the measured estimate)
     // options
     int k1_variant = 12;          // per-file K1: one wave per workgroup, two adjacent 3 KiB tiles per step, software-pipelined (profiles/r01_k1_one_wave_blocks.log)
     int k1_waves_per_cu = 3;      // workgroups (= waves) per CU for the one-wave variants 8..14: 3 for the pipelined 12 (6-12 KiB outstanding per wave), 8 for 9
@@ -182,10 +191,7 @@ struct pcq_collector {
     double bmin[3], bmax[3], cell_size = 0;
     uint64_t dims[3], bits[3];
     DevGrid grid;
-    DevGridTable table;
-    uint64_t table_used_bound = 0;      // host-side count of occupied slots after the last scan
-    bool grid_dense = false;            // sticky: a guessed table size overflowed; this collector uses the guaranteed size
-    bool grid_has_alias = false;        // sticky: some key has seen an aliased cell (grid.hip pass R)
+    GridState *gs = nullptr;            // pending tuple runs + folded winners (grid.hip)
     uint64_t next_index = 0;            // file-order index the next scan starts at
     hipStream_t last_stream = nullptr;  // stream of the most recent scan: accessors wait on it
 };
@@ -208,8 +214,10 @@ int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pre
                            uint64_t out_base, uint64_t expected, hipStream_t s);
 int pcq_emit_prepare(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint64_t *matches, hipStream_t s);
 // grid.hip
-int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const DevPred &pred,
-                  uint64_t matches_upper_bound, hipStream_t s);
+int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const DevPred &pred, hipStream_t s);
 void pcq_grid_release(pcq_collector *c);
-void pcq_grid_cache_clear(pcq_ctx *ctx);
 int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_t cap, uint64_t *out_n);
+// pcq_api.hip: device-memory pool of the context.  A block may be freed only when the work that used it has completed.
+int pcq_pool_alloc(pcq_ctx *ctx, size_t bytes, void **out);
+void pcq_pool_free(pcq_ctx *ctx, void *p);
+void pcq_pool_clear(pcq_ctx *ctx);

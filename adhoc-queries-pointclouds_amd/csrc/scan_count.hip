@@ -1005,6 +1005,7 @@ static int batch_tiles_per_step(int v) { return v == 0 ? 1 : (v == 2 ? 3 : 2); }
 
 extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *preds,
                                         size_t nsegments, uint64_t *device_total, void *stream) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx || (!cols && nsegments) || (!preds && nsegments) || !device_total)
         return pcq_fail(PCQ_ERR_ARG, "pcq_scan_dev_count_batch: null argument");
     if (nsegments == 0) return PCQ_OK;

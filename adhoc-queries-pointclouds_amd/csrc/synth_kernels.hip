@@ -60,6 +60,7 @@ __global__ __launch_bounds__(256) void k_synth_fill(DevSynth s, uint64_t first, 
 
 extern "C" int pcq_synth_fill_dev(pcq_ctx *ctx, const pcq_synth_spec *spec, uint64_t first, uint64_t count, void *d_xyz,
                                   void *d_cls, void *stream) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx || !spec) return pcq_fail(PCQ_ERR_ARG, "pcq_synth_fill_dev: null argument");
     if (spec->n_classes > PCQ_SYNTH_MAX_CLASSES) return pcq_fail(PCQ_ERR_ARG, "pcq_synth_fill_dev: too many classes");
     if (first > spec->n || count > spec->n - first) return pcq_fail(PCQ_ERR_ARG, "pcq_synth_fill_dev: range outside the spec");

@@ -264,9 +264,11 @@ int pcq_bind_thread_near_device(pcq_ctx *ctx);
 /* Tuning knobs: "k1_variant" (bounds-count kernel variant 0..14), "k1_waves_per_cu", "batch_variant" (0..3),
  * "batch_waves_per_cu", "blocks_per_cu" (the 256-thread kernels), "chunk_points" (points per staging chunk of
  * the host paths), "copy_threads" (threads filling a staging chunk, default 8), "class_batch_loads" /
- * "class_batch_waves_per_cu" / "class_batch_pipe" (class-count kernels), "numa_local", "grid_guess" (grid tables
- * start from a guessed size, default 1).  pcq_get_option also reads "numa_node" and the grid diagnostics
- * "grid_overflows" (guesses that overflowed: pass A was re-run), "grid_regrows", "grid_dense_hint". */
+ * "class_batch_waves_per_cu" / "class_batch_pipe" (class-count kernels), "numa_local", "grid_pending_budget"
+ * (matches a grid collector may hold before it folds them; 0 = default), "grid_f2" (tests: the second-level fan-out a
+ * fold starts from; 0 = from the measured estimate).  pcq_get_option also reads "numa_node" and the grid diagnostics
+ * "grid_folds", "grid_level2" (folds that needed a second partition level), "grid_refolds" (folds repeated with more
+ * partitions), "grid_last_f2". */
 int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value);
 int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value);
 

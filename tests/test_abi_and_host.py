@@ -270,3 +270,47 @@ def test_run_query_experiments_driver_protocol(oracle, tmp_path):
     # a format the query cannot search fails the run, like the reference's `?` on the child's exit status
     rc, lines, err = subprocess.run([drv, "-i", str(root), "-e", "1", "--query", q, "--runs", "1"], capture_output=True, text=True).returncode, None, None
     assert rc == 1
+
+
+def test_copy_pool_under_thread_sanitizer(tmp_path):
+    """csrc/copy_pool.h hands a staging chunk to helper threads slice by slice.  Back-to-back jobs with different
+    slice counts (positions 12 n, class n, colour 6 n) must never let a helper that is still leaving one job draw a
+    ticket of the next: ThreadSanitizer build (CPU only), every copy compared with its source."""
+    import shutil
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "copy_pool_tsan")
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I" + os.path.join(PKG, "csrc"),
+           os.path.join(ROOT, "tests", "native", "copy_pool_tsan_driver.cpp"), "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0 and "sanitize" in r.stderr and "cannot find" in r.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([exe, "250", "7"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+    assert r.returncode == 0 and r.stdout.startswith("ok 250"), (r.stdout[-500:], r.stderr[-3000:])
+
+
+def test_every_entry_point_runs_on_the_context_device():
+    """A driver thread that never chose a device sits on device 0; draining the collectors of GPU k from it must
+    still allocate and launch on GPU k.  Every extern "C" function that takes a context, a collector or an index
+    and touches the HIP runtime opens with the device guard (pcq_internal.h), or sets the device itself."""
+    import re
+    exempt = {"pcq_last_error", "pcq_abi_version", "pcq_init", "pcq_get_device_info", "pcq_ctx_stream", "pcq_get_option",
+              "pcq_bind_thread_near_device", "pcq_box_to_local", "pcq_collector_has_points", "pcq_collector_grid_params",
+              "pcq_collector_new_buffer",  # new_collector() sets the device
+              "pcq_allreduce_sum_u64"}     # sets each rank's device around its own calls
+    checked = 0
+    for f in sorted(os.listdir(os.path.join(PKG, "csrc"))):
+        if not f.endswith(".hip"):
+            continue
+        text = open(os.path.join(PKG, "csrc", f)).read()
+        for m in re.finditer(r'extern "C"[^;{]*?\b(pcq_\w+)\s*\(', text):
+            name = m.group(1)
+            if name in exempt:
+                continue
+            body_start = text.index("{", m.end())
+            head = text[body_start:body_start + 400]
+            assert "PCQ_ON_DEVICE_OF_" in head, f"{f}: {name} does not open with the device guard"
+            checked += 1
+    assert checked >= 25

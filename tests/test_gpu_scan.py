@@ -266,11 +266,12 @@ def test_grid_collector_on_spatially_coherent_files(oracle, gpu_ctx, cell):
         f.free()
 
 
-def test_grid_table_guess_growth_and_overflow(oracle):
-    """The grid table is first sized from a guess (an eighth of the guaranteed bound, csrc/grid.hip pcq_grid_scan):
-    a coarse grid fits it, a medium one is enlarged after pass A, a dense one overflows and pass A is re-run on the
-    guaranteed size — after which the context starts the next grid at the guaranteed size.  Same cells and winners
-    as the oracle in every case, and with the guess switched off."""
+def test_grid_fold_levels_refold_and_forced_fanout(oracle):
+    """The grid collector partitions the matches by cell key and folds each partition in LDS (csrc/grid.hip): a coarse
+    grid folds its 512 level-1 bins directly (one 6400-slot table per workgroup), a dense one gets a second partition
+    level whose fan-out comes from a measured estimate, and a fan-out that turns out too small (forced here) makes
+    partitions overflow their LDS table and the fold is repeated with more partitions.  Same cells and winners as the
+    oracle in every case."""
     n = 3_000_000
     spec = small_spec(424242, n, fmt=2)
     image = oracle.synth_image(spec, transposed=True)
@@ -278,16 +279,20 @@ def test_grid_table_guess_growth_and_overflow(oracle):
     bmin, bmax = (-500.0, -500.0, -100.0), (500.0, 500.0, 100.0)  # wider than the data: the key space does not cap the bound
     lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
     expect = {}
-    for cell in (1.0, 0.72, 0.25):
+    for cell in (1.0, 0.72, 0.25, 0.2):
         og = oracle.grid_collector(bmin, bmax, cell)
         assert oracle.search_last_bounds(image, bmin, bmax, og) == 0
         expect[cell] = (og.point_count(), og.grid_cells().copy(), og.points().tobytes())
         og.free()
-    assert expect[1.0][0] <= n // 8 and 2**19 <= expect[0.72][0] < 2**20 * 5 // 8 < expect[0.25][0]  # the three regimes
+    per_bin = {cell: expect[cell][0] / 512 for cell in expect}  # cells per level-1 bin
+    assert per_bin[1.0] < per_bin[0.72] < 2000            # folded directly
+    assert 5000 < per_bin[0.25] < 5350                    # over the estimate's limit for a direct fold (4700): second level
+    assert 5480 < per_bin[0.2]                            # over what the big LDS table holds (5440 cells)
     with pkg.Context(0) as ctx:
         f = DevFile(ctx, image, hdr)
         try:
             def run(cell):
+                before = [ctx.get_option(k) for k in ("grid_folds", "grid_level2", "grid_refolds")]
                 gg = ctx.grid_collector(bmin, bmax, cell)
                 ctx.scan_dev(f.columns(True), pkg.Predicate.bounds(lmin, lmax), gg)
                 cnt, cells, pts = expect[cell]
@@ -297,31 +302,31 @@ def test_grid_table_guess_growth_and_overflow(oracle):
                 assert np.array_equal(gk[order], cells)
                 assert gp[order].tobytes() == pts
                 gg.free()
-                return ctx.get_option("grid_overflows"), ctx.get_option("grid_regrows"), ctx.get_option("grid_dense_hint")
+                after = [ctx.get_option(k) for k in ("grid_folds", "grid_level2", "grid_refolds")]
+                return tuple(a - b for a, b in zip(after, before)) + (ctx.get_option("grid_last_f2"),)
 
-            assert run(1.0) == (0, 0, 0)       # ~0.2 M cells in a table guessed for 0.375 M
-            # ~0.56 M cells: past load 1/2 of the guessed 2^20 slots -> enlarged before pass B; the overflow limit (load
-            # ~0.6, estimated from one occupancy shard) is close enough that an uneven run may take that road instead
-            o, r, hint = run(0.72)
-            assert o + r == 1 and hint == 1
-            ctx.set_option("grid_guess", 1)    # clears the hint
-            o2, r2, hint = run(0.25)           # ~2.7 M cells: overflow, pass A re-run on the guaranteed size
-            assert (o2, r2, hint) == (o + 1, r, 1)
-            assert run(0.25) == (o2, r2, 1)    # the hint: no second overflow
-            assert run(1.0) == (o2, r2, 0)     # guaranteed size, but it would have fitted: guessing again from here
-            assert run(1.0) == (o2, r2, 0)
-            ctx.set_option("grid_guess", 0)
-            for cell in (1.0, 0.72, 0.25):
-                assert run(cell)[:2] == (o2, r2)
+            assert run(1.0) == (1, 0, 0, 1)
+            assert run(0.72) == (1, 0, 0, 1)
+            assert run(0.25) == (1, 1, 0, 9)       # ~5270 cells per bin / 600 per partition
+            ctx.set_option("grid_f2", 1)           # forced direct fold: the bins overflow the table, the fold is repeated
+            folds, level2, refolds, f2 = run(0.2)
+            assert folds == 1 and level2 >= 1 and refolds >= 1 and f2 > 1
+            ctx.set_option("grid_f2", 3)           # forced, too few partitions: 1840 cells each against 870 slots
+            folds, level2, refolds, f2 = run(0.2)
+            assert refolds >= 1 and f2 >= 6
+            ctx.set_option("grid_f2", 13)          # a fan-out that is not a power of two, more partitions than needed
+            assert run(0.25) == (1, 1, 0, 13) and run(1.0) == (1, 1, 0, 13)
+            ctx.set_option("grid_f2", 0)
         finally:
             f.free()
 
 
 @pytest.mark.parametrize("cell", [1.0, 0.72, 0.25])
 def test_grid_shared_by_several_scans_with_guessed_tables(oracle, cell):
-    """Sequential mode (main.rs:129-133): ONE grid folds several files, first seen wins across them.  Large enough
-    scans for the guessed table size to be in play in every scan: the table carries cells over while it is enlarged
-    after a pass, re-hashed on overflow, or found large enough."""
+    """Sequential mode (main.rs:129-133): ONE grid folds several files, first seen wins across them — with the files
+    folded together (one fold at the end) and with a fold after every file (point_count in between): the earlier
+    winners are merged partition by partition, and at the densest cell size the second-level fan-out grows from fold
+    to fold, so they are re-cut."""
     n = 1_400_000
     bmin, bmax = (-500.0, -500.0, -100.0), (500.0, 500.0, 100.0)
     images, hdrs = [], []
@@ -350,6 +355,27 @@ def test_grid_shared_by_several_scans_with_guessed_tables(oracle, cell):
             order = np.argsort(gk, kind="stable")
             assert np.array_equal(gk[order], og.grid_cells())
             assert gp[order].tobytes() == og.points().tobytes()
+            # the same with a fold behind every file
+            g2 = ctx.grid_collector(bmin, bmax, cell)
+            first, f2s, seen = 0, [], 0
+            for f, hdr in zip(files, hdrs):
+                lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+                cols = f.columns(True)
+                cols.first_index = first
+                ctx.scan_dev(cols, pkg.Predicate.bounds(lmin, lmax), g2)
+                first += n
+                now = g2.point_count()
+                assert now >= seen
+                seen = now
+                f2s.append(ctx.get_option("grid_last_f2"))
+            assert seen == og.point_count()
+            gp, gk = g2.points(), g2.grid_cells()
+            order = np.argsort(gk, kind="stable")
+            assert np.array_equal(gk[order], og.grid_cells())
+            assert gp[order].tobytes() == og.points().tobytes()
+            if cell == 0.25:
+                assert f2s[0] < f2s[-1]  # the earlier winners were re-cut for a larger fan-out
+            g2.free()
         finally:
             gg.free()
             for f in files:
@@ -360,7 +386,8 @@ def test_grid_shared_by_several_scans_with_guessed_tables(oracle, cell):
 @pytest.mark.parametrize("cell", [1.0, 0.25])
 def test_grid_through_the_host_path_in_large_chunks(oracle, cell):
     """pcq_scan_host of a 4 M-point file in staging chunks of 1.3 M points: every chunk is a scan of its own into the
-    same grid, each large enough for the guessed table size (the CLI's path for files on disk)."""
+    same grid (the CLI's path for files on disk) — all chunks folded together, and with a pending budget so small
+    that every chunk is folded before the next one is scanned."""
     n = 4_000_003
     bmin, bmax = (-500.0, -500.0, -100.0), (500.0, 500.0, 100.0)
     image = oracle.synth_image(small_spec(31, n, fmt=2), transposed=True)
@@ -376,12 +403,17 @@ def test_grid_through_the_host_path_in_large_chunks(oracle, cell):
             cols = binding.make_columns(xyz=base, cls=base + 15 * n, rgb=base + 20 * n, n=n, scale=list(hdr.scale),
                                         offset=list(hdr.offset))
             lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
-            ctx.scan_host(cols, pkg.Predicate.bounds(lmin, lmax), gg)
-            assert gg.point_count() == og.point_count()
-            gp, gk = gg.points(), gg.grid_cells()
-            order = np.argsort(gk, kind="stable")
-            assert np.array_equal(gk[order], og.grid_cells())
-            assert gp[order].tobytes() == og.points().tobytes()
+            for budget in (0, 1_000_000):
+                ctx.set_option("grid_pending_budget", budget)
+                folds = ctx.get_option("grid_folds")
+                ctx.scan_host(cols, pkg.Predicate.bounds(lmin, lmax), gg)
+                assert gg.point_count() == og.point_count()
+                assert ctx.get_option("grid_folds") - folds == (4 if budget else 1)
+                gp, gk = gg.points(), gg.grid_cells()
+                order = np.argsort(gk, kind="stable")
+                assert np.array_equal(gk[order], og.grid_cells())
+                assert gp[order].tobytes() == og.points().tobytes()
+                gg.reset()
         finally:
             gg.free()
     og.free()

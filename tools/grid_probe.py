@@ -1,5 +1,5 @@
 """Developer probe: grid-collector scans of one resident file (for rocprofv3 --kernel-trace).
-usage: grid_probe.py QUERY CELL [POINTS] [REPEATS]; GRID_GUESS=0 switches the guessed table size off;
+usage: grid_probe.py QUERY CELL [POINTS] [REPEATS]; GRID_F2=<n> forces the second-level fan-out;
 COHERENT=<metres> reorders the file into x/y strips of that width (points sorted along each strip, like scan
 lines) instead of the generator's random order."""
 import importlib, os, sys, time
@@ -32,7 +32,7 @@ with pkg.Context(0) as ctx:
     cols = binding.make_columns(xyz=xyz, cls=cls, n=n, scale=list(spec.scale), offset=list(spec.offset))
     bmin, bmax = specs.box(q)
     lmin, lmax = pkg.box_to_local(bmin, bmax, list(spec.scale), list(spec.offset))
-    ctx.set_option("grid_guess", int(os.environ.get("GRID_GUESS", "1")))
+    ctx.set_option("grid_f2", int(os.environ.get("GRID_F2", "0")))
     for _ in range(int(sys.argv[4]) if len(sys.argv) > 4 else 2):
         t0 = time.perf_counter()
         g = ctx.grid_collector(bmin, bmax, cell)
@@ -45,4 +45,4 @@ with pkg.Context(0) as ctx:
         g.free()
         t4 = time.perf_counter()
         print(q, cell, "cells", k, "new %.1f scan %.1f count %.1f free %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3),
-              "overflows", ctx.get_option("grid_overflows"), "regrows", ctx.get_option("grid_regrows"), flush=True)
+              "f2", ctx.get_option("grid_last_f2"), "refolds", ctx.get_option("grid_refolds"), flush=True)
