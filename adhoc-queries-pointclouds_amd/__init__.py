@@ -23,6 +23,7 @@ from .binding import (  # noqa: F401
     Collector,
     lib_path,
     load_library,
+    hip_runtime_path,
     box_to_local,
     exported_symbols,
     declared_symbols,

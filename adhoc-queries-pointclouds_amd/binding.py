@@ -97,28 +97,56 @@ class SynthSpec(C.Structure):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libpcq.so")
-
-
-class Lz4Job(C.Structure):
-    """pcq_lz4_job: one LZ4 frame (behind its descriptor) to inflate on the device."""
-    _fields_ = [("src", C.c_void_p), ("src_len", C.c_uint64), ("dst", C.c_void_p), ("need", C.c_uint64),
-                ("content_size", C.c_uint64), ("block_size_id", C.c_uint8), ("independent_blocks", C.c_uint8),
-                ("block_checksum", C.c_uint8), ("has_content_size", C.c_uint8), ("status", C.c_int32)]
+    """libpcq.so — or, for the measurement tools in tools/ (PCQ_LAB=1), libpcq_lab.so: the same sources plus the
+    superseded kernel shapes and read microbenchmarks of csrc/lab/ (make -C csrc lab)."""
+    return os.path.join(_HERE, "libpcq_lab.so" if os.environ.get("PCQ_LAB") == "1" else "libpcq.so")
 
 
 _lib = None
 
 
+def _one_hip_runtime() -> Optional[str]:
+    """One HIP runtime per process.  libpcq.so needs `libamdhip64.so.7`; a PyTorch wheel ships its own copy of that
+    library (same SONAME, found through torch/lib's RUNPATH).  Two copies in one process means two HSA runtimes, and
+    the one that initialises second reports "no ROCm-capable device".  The dynamic loader reuses an already mapped
+    library with the SONAME a new one asks for, so: when PyTorch is installed, its copy is mapped first (without
+    importing torch) and libpcq.so binds to it — whichever of the two is imported first afterwards, there is one
+    runtime.  Without PyTorch (the `query` CLI, a Rust host) libpcq.so finds ROCm's through its RUNPATH.
+    PCQ_HIP_RUNTIME=rocm keeps ROCm's runtime even when PyTorch is installed."""
+    if os.environ.get("PCQ_HIP_RUNTIME", "") == "rocm":
+        return None
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    return cand
+
+
+_hip_runtime_path = None
+
+
+def hip_runtime_path() -> Optional[str]:
+    """The libamdhip64 mapped on behalf of libpcq.so by load_library() (None: ROCm's, through the RUNPATH)."""
+    return _hip_runtime_path
+
+
 def load_library() -> C.CDLL:
     """Loads libpcq.so; raises if it has not been built.  There is no fallback."""
-    global _lib
+    global _lib, _hip_runtime_path
     if _lib is not None:
         return _lib
     path = lib_path()
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: build the HIP library first (make -C {_HERE}/csrc, or "
                            "__graft_entry__.build()). This package has no CPU path.")
+    _hip_runtime_path = _one_hip_runtime()
     lib = C.CDLL(path)
     vp, u64, i64 = C.c_void_p, C.c_uint64, C.c_int64
     P = C.POINTER
@@ -160,9 +188,9 @@ def load_library() -> C.CDLL:
         "pcq_set_option": (C.c_int, [vp, C.c_char_p, i64]),
         "pcq_get_option": (C.c_int, [vp, C.c_char_p, P(i64)]),
         "pcq_bind_thread_near_device": (C.c_int, [vp]),
-        "pcq_lz4_inflate_dev": (C.c_int, [vp, P(Lz4Job), C.c_size_t, vp]),
-        "pcq_read_fd_to_device": (C.c_int, [vp, C.c_int, u64, u64, vp]),
         "pcq_synth_fill_dev": (C.c_int, [vp, P(SynthSpec), u64, u64, vp, vp, vp]),
+    }
+    lab_sig = {  # include/pcq_lab.h: present in libpcq_lab.so only
         "pcq_membench_read": (C.c_int, [vp, vp, u64, C.c_int, C.c_int, C.c_int, vp]),
         "pcq_membench_read_tiles": (C.c_int, [vp, vp, u64, C.c_int, C.c_int, C.c_int, vp]),
         "pcq_membench_read_xcd": (C.c_int, [vp, vp, u64, C.c_int, C.c_int, C.c_int, vp]),
@@ -171,6 +199,11 @@ def load_library() -> C.CDLL:
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    for name, (res, args) in lab_sig.items():
+        if hasattr(lib, name):
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
     _lib = lib
     return lib
 
@@ -334,13 +367,6 @@ class Context:
 
     def memset(self, dst: int, value: int, nbytes: int, stream: Optional[int] = None) -> None:
         _check(self.lib.pcq_device_memset(self.handle, C.c_void_p(dst), value, nbytes, C.c_void_p(stream)))
-
-    def lz4_inflate(self, jobs, stream: Optional[int] = None) -> None:
-        """jobs: a ctypes array of Lz4Job; statuses are filled in (0 = inflated, 1 = left to the caller)."""
-        _check(self.lib.pcq_lz4_inflate_dev(self.handle, jobs, len(jobs), C.c_void_p(stream)))
-
-    def read_fd_to_device(self, fd: int, offset: int, nbytes: int, dst: int) -> None:
-        _check(self.lib.pcq_read_fd_to_device(self.handle, fd, offset, nbytes, C.c_void_p(dst)))
 
     # scans ------------------------------------------------------------------------------------
     def scan_dev(self, cols: Columns, pred: Predicate, coll: Collector, stream: Optional[int] = None) -> None:

@@ -69,10 +69,16 @@ extern "C" int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, uint64_t *const *devi
     if (!ctxs || !device_counters || n < 1) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: bad arguments");
     for (int i = 0; i < n; i++)
         if (!ctxs[i] || !device_counters[i]) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: null entry %d", i);
-    if (n == 1) {  // a single rank: the sum is the value itself
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < i; j++)
+            if (ctxs[i]->device == ctxs[j]->device)
+                return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: entries %d and %d are both on device %d (one rank per GPU)", j, i, ctxs[i]->device);
+    if (n == 1 && !ctxs[0]->allreduce_single_rank) {  // a single rank: the sum is the value itself
+        PCQ_ON_DEVICE_OF_CTX(ctxs[0]);
         PCQ_HIP(hipStreamSynchronize(ctxs[0]->stream));
         return PCQ_OK;
     }
+    DeviceGuard restore(ctxs[0]->device);  // the calls below move the thread from device to device; put it back at the end
     std::lock_guard<std::mutex> lk(g_mu);
     int rc = load_rccl();
     if (rc) return rc;

@@ -56,6 +56,7 @@ constexpr int BIG_SLOTS = 6400, BIG_NT = 1024, BIG_LIMIT = 5440, BIG_DIRECT = 47
 constexpr int SMALL_SLOTS = 1024, SMALL_NT = 256, SMALL_LIMIT = 870, SMALL_TARGET = 600;
 constexpr int FOLD_K = 4;              // fold: tuples per thread and chunk
 constexpr int L2_NT = 512;             // second level: threads per workgroup (one workgroup per level-1 bin)
+constexpr int L2_UNROLL = 4;
 constexpr int PROBE_BINS = 2;          // bins whose distinct cells are counted to estimate the grid's density
 constexpr int MAX_RUNS = 1024;         // pending pass-0 runs per collector before a fold is forced
 constexpr uint64_t RUN_POINTS = 1ull << 30;  // points per pass-0 run (tuple offsets are 32-bit)
@@ -96,7 +97,20 @@ struct CellInfo {
     bool alias;
 };
 
-// grid_sampling.rs:51-70
+// grid_sampling.rs:51-70.  The cell is trunc(RN(num / extent)) — the correctly rounded quotient, truncated (Rust `as u64`).
+// A correctly rounded f64 division is ~15 instructions, three per point, in every pass over the matches; but the
+// quotient itself is not needed, only its integer part.  q = num * (1 / extent) lies within 2 ulp of the true
+// quotient x and RN(x) within half an ulp, so when q is further than q * 2^-50 (>= 4 ulp) from an integer — and
+// 0 <= q < 2^51 — no integer lies between them and trunc(q) IS trunc(RN(x)).  Everything else (a point within a few
+// ulp of a cell boundary, negative, huge, NaN) takes the division, so the result is the reference's in every case.
+__device__ __forceinline__ uint64_t cell_index(double num, double extent, double inv_extent) {
+    const double q = num * inv_extent;
+    const double fl = floor(q);
+    const double frac = q - fl, guard = q * 0x1p-50;
+    if (q >= 0.0 && q < 0x1p51 && frac > guard && 1.0 - frac > guard) return (uint64_t)fl;
+    return f64_as_u64(num / extent);
+}
+
 __device__ __forceinline__ CellInfo cell_of(const DevGrid &g, double px, double py, double pz) {
     const double p[3] = {px, py, pz};
     CellInfo ci;
@@ -105,8 +119,7 @@ __device__ __forceinline__ CellInfo cell_of(const DevGrid &g, double px, double 
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const double num = (p[a] - g.bmin[a]) * g.dims_f[a];
-        const double r = num / (g.bmax[a] - g.bmin[a]);
-        const uint64_t cell = f64_as_u64(r);
+        const uint64_t cell = cell_index(num, g.bmax[a] - g.bmin[a], g.inv_extent[a]);
         ci.cell[a] = cell;
         const uint64_t masked = cell & g.mask[a];
         ci.alias |= masked != cell;
@@ -145,12 +158,23 @@ __device__ __forceinline__ void st_tuple(GridTuple *p, const GridTuple &t) {
     q[2] = make_uint2(t.w0, t.w1);
 }
 
+// The entry table as the kernels see it: entry 0 (often the only one) travels in the kernel arguments, so that the
+// common case costs no dependent global load.
+struct EntryRef {
+    const GridEntryDev *table;
+    GridEntryDev e0;
+    __device__ __forceinline__ GridEntryDev get(uint32_t id) const {
+        if (id == 0) return e0;
+        return table[id];
+    }
+};
+
 struct TupleEval {
     uint64_t key, dbits;
     bool alias;
 };
-__device__ __forceinline__ TupleEval eval_tuple(const DevGrid &g, const GridEntryDev *__restrict__ entries, const GridTuple &t) {
-    const GridEntryDev &e = entries[(t.w0 >> 8) & 0xff];
+__device__ __forceinline__ TupleEval eval_tuple(const DevGrid &g, const EntryRef &entries, const GridTuple &t) {
+    const GridEntryDev e = entries.get((t.w0 >> 8) & 0xff);
     const double px = world(t.x, e.scale[0], e.offset[0]), py = world(t.y, e.scale[1], e.offset[1]), pz = world(t.z, e.scale[2], e.offset[2]);
     const CellInfo ci = cell_of(g, px, py, pz);
     TupleEval r;
@@ -187,7 +211,33 @@ __device__ __forceinline__ uint64_t point_hash(const DevCols &c, const DevGrid &
     return hash64(cell_of(g, px, py, pz).key);
 }
 
+// What the predicate reads of a point: its position (bounds kinds) or its class byte.
+template <int KIND>
+struct P0In {
+    RawPoint rp;
+    uint32_t cls;
+};
+template <int KIND>
+__device__ __forceinline__ P0In<KIND> p0_load(const DevCols &c, uint64_t i) {
+    P0In<KIND> in;
+    if (KIND == PCQ_PRED_CLASS) in.cls = c.cls[i * c.cls_stride];
+    else in.rp = ld_xyz(c, i);
+    return in;
+}
+template <int KIND>
+__device__ __forceinline__ bool p0_pass(const DevCols &c, const DevPred &pr, const P0In<KIND> &in) {
+    if (KIND == PCQ_PRED_CLASS) return in.cls == pr.cls;
+    const RawPoint &rp = in.rp;
+    if (KIND == PCQ_PRED_BOUNDS)
+        return (pr.empty == 0) & ((uint32_t)(rp.x - pr.lo[0]) <= pr.width[0]) & ((uint32_t)(rp.y - pr.lo[1]) <= pr.width[1]) &
+               ((uint32_t)(rp.z - pr.lo[2]) <= pr.width[2]);
+    const double wx = c.offset[0] + c.scale[0] * (double)rp.x, wy = c.offset[1] + c.scale[1] * (double)rp.y,
+                 wz = c.offset[2] + c.scale[2] * (double)rp.z;
+    return !((wx < pr.wmin[0]) | (wy < pr.wmin[1]) | (wz < pr.wmin[2]) | (wx > pr.wmax[0]) | (wy > pr.wmax[1]) | (wz > pr.wmax[2]));
+}
+
 // Workgroup b owns the points [b * per_block, (b + 1) * per_block): cnt[b][bin] = its matches per level-1 bin.
+// The inputs of the next tile are loaded before the current one is evaluated.
 template <int KIND>
 __global__ __launch_bounds__(P0_NT) void k_p0_hist(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, uint32_t *__restrict__ cnt) {
     __shared__ uint32_t hist[F1];
@@ -195,20 +245,30 @@ __global__ __launch_bounds__(P0_NT) void k_p0_hist(DevCols c, DevPred pr, DevGri
     __syncthreads();
     const uint64_t begin = (uint64_t)blockIdx.x * per_block;
     const uint64_t end = begin + per_block < c.n ? begin + per_block : c.n;
+    P0In<KIND> cur[P0_ITEMS], nxt[P0_ITEMS];
+#pragma unroll
+    for (int j = 0; j < P0_ITEMS; j++) {
+        const uint64_t i = begin + (uint64_t)j * P0_NT + threadIdx.x;
+        cur[j] = p0_load<KIND>(c, i < end ? i : end - 1);
+    }
     for (uint64_t base = begin; base < end; base += P0_TILE) {
-        RawPoint rps[P0_ITEMS];
-        bool passes[P0_ITEMS];
+        const uint64_t nbase = base + P0_TILE;
+        if (nbase < end) {
+#pragma unroll
+            for (int j = 0; j < P0_ITEMS; j++) {
+                const uint64_t i = nbase + (uint64_t)j * P0_NT + threadIdx.x;
+                nxt[j] = p0_load<KIND>(c, i < end ? i : end - 1);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < P0_ITEMS; j++) {
             const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
-            passes[j] = eval_pred_kind<KIND>(c, pr, i < end ? i : end - 1, rps[j]) & (i < end);
+            if (i >= end || !p0_pass<KIND>(c, pr, cur[j])) continue;
+            if (KIND == PCQ_PRED_CLASS) cur[j].rp = ld_xyz(c, i);
+            atomicAdd(&hist[bin_of(point_hash<KIND>(c, g, cur[j].rp))], 1u);
         }
 #pragma unroll
-        for (int j = 0; j < P0_ITEMS; j++) {
-            if (!passes[j]) continue;
-            if (KIND == PCQ_PRED_CLASS) rps[j] = ld_xyz(c, base + (uint64_t)j * P0_NT + threadIdx.x);
-            atomicAdd(&hist[bin_of(point_hash<KIND>(c, g, rps[j]))], 1u);
-        }
+        for (int j = 0; j < P0_ITEMS; j++) cur[j] = nxt[j];
     }
     __syncthreads();
     for (int t = threadIdx.x; t < F1; t += P0_NT) cnt[(size_t)blockIdx.x * F1 + t] = hist[t];
@@ -295,15 +355,15 @@ __global__ __launch_bounds__(1024) void k_excl_scan_u64(const uint64_t *__restri
 
 // The second reading of the scan: every match becomes a tuple at binoff[bin] + (workgroup's offset in the bin) + rank.
 // Per tile of 2560 points: the matches take a rank in their bin (LDS atomics), the tile's tuples are laid out in LDS
-// sorted by bin, and the sorted image is copied out 8 bytes per lane — consecutive lanes write consecutive words of a
-// bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.
+// sorted by bin, and the sorted image is copied out one tuple per lane — consecutive lanes write consecutive tuples of
+// a bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.
 template <int KIND>
 __global__ __launch_bounds__(P0_NT) void k_p0_scatter(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
                                                       const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out, uint32_t entry,
                                                       uint64_t idx_base) {
     static_assert(F1 == P0_NT, "one thread per bin in the per-tile scan");
     __shared__ uint2 s_stage[P0_TILE * 3];   // the tile's tuples, sorted by bin (three 8-byte words each)
-    __shared__ uint16_t s_tbin[P0_TILE];     // bin of the staged tuple
+    __shared__ uint32_t s_tpos[P0_TILE];     // where the staged tuple goes in the run
     __shared__ uint32_t s_cnt[F1], s_base[F1], s_gpos[F1], s_cur[F1], s_wsum[P0_NT / 64];
     __shared__ uint32_t s_total;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -312,20 +372,30 @@ __global__ __launch_bounds__(P0_NT) void k_p0_scatter(DevCols c, DevPred pr, Dev
     __syncthreads();
     const uint64_t begin = (uint64_t)blockIdx.x * per_block;
     const uint64_t end = begin + per_block < c.n ? begin + per_block : c.n;
+    P0In<KIND> cur[P0_ITEMS], nxt[P0_ITEMS];
+#pragma unroll
+    for (int j = 0; j < P0_ITEMS; j++) {
+        const uint64_t i = begin + (uint64_t)j * P0_NT + threadIdx.x;
+        cur[j] = p0_load<KIND>(c, i < end ? i : end - 1);
+    }
     for (uint64_t base = begin; base < end; base += P0_TILE) {
-        RawPoint rps[P0_ITEMS];
+        const uint64_t nbase = base + P0_TILE;
+        if (nbase < end) {  // the next tile's inputs are on their way while this one is sorted
+#pragma unroll
+            for (int j = 0; j < P0_ITEMS; j++) {
+                const uint64_t i = nbase + (uint64_t)j * P0_NT + threadIdx.x;
+                nxt[j] = p0_load<KIND>(c, i < end ? i : end - 1);
+            }
+        }
         bool passes[P0_ITEMS];
         uint32_t bins[P0_ITEMS], ranks[P0_ITEMS];
 #pragma unroll
         for (int j = 0; j < P0_ITEMS; j++) {
             const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
-            passes[j] = eval_pred_kind<KIND>(c, pr, i < end ? i : end - 1, rps[j]) & (i < end);
-        }
-#pragma unroll
-        for (int j = 0; j < P0_ITEMS; j++) {
+            passes[j] = i < end && p0_pass<KIND>(c, pr, cur[j]);
             if (!passes[j]) continue;
-            if (KIND == PCQ_PRED_CLASS) rps[j] = ld_xyz(c, base + (uint64_t)j * P0_NT + threadIdx.x);
-            bins[j] = bin_of(point_hash<KIND>(c, g, rps[j]));
+            if (KIND == PCQ_PRED_CLASS) cur[j].rp = ld_xyz(c, i);
+            bins[j] = bin_of(point_hash<KIND>(c, g, cur[j].rp));
             ranks[j] = atomicAdd(&s_cnt[bins[j]], 1u);
         }
         __syncthreads();
@@ -360,20 +430,23 @@ __global__ __launch_bounds__(P0_NT) void k_p0_scatter(DevCols c, DevPred pr, Dev
                 const uint8_t *q = c.rgb + i * c.rgb_stride;
                 r = ld_u16(q), gg = ld_u16(q + 2), b = ld_u16(q + 4);
             }
-            const uint32_t cls = c.cls ? c.cls[i * c.cls_stride] : 0;  // last.rs:138-142
+            const uint32_t cls = KIND == PCQ_PRED_CLASS ? cur[j].cls : (c.cls ? c.cls[i * c.cls_stride] : 0);  // last.rs:138-142
             const uint32_t at = s_base[bins[j]] + ranks[j];
-            s_stage[at * 3] = make_uint2((uint32_t)rps[j].x, (uint32_t)rps[j].y);
-            s_stage[at * 3 + 1] = make_uint2((uint32_t)rps[j].z, (uint32_t)(idx_base + i));
+            s_stage[at * 3] = make_uint2((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y);
+            s_stage[at * 3 + 1] = make_uint2((uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
             s_stage[at * 3 + 2] = make_uint2(cls | (entry << 8) | (r << 16), gg | (b << 16));
-            s_tbin[at] = (uint16_t)bins[j];
+            s_tpos[at] = s_gpos[bins[j]] + ranks[j];
         }
         __syncthreads();
-        const uint32_t words = s_total * 3;
+        const uint32_t total = s_total;
         uint2 *out2 = reinterpret_cast<uint2 *>(out);
-        for (uint32_t w = threadIdx.x; w < words; w += P0_NT) {
-            const uint32_t t = w / 3, k = w - t * 3, bin = s_tbin[t];
-            out2[(uint64_t)(s_gpos[bin] + (t - s_base[bin])) * 3 + k] = s_stage[w];
+        for (uint32_t t = threadIdx.x; t < total; t += P0_NT) {
+            const uint2 a = s_stage[t * 3], b = s_stage[t * 3 + 1], d = s_stage[t * 3 + 2];
+            uint2 *q = out2 + (uint64_t)s_tpos[t] * 3;
+            q[0] = a, q[1] = b, q[2] = d;
         }
+#pragma unroll
+        for (int j = 0; j < P0_ITEMS; j++) cur[j] = nxt[j];
         __syncthreads();  // the stage and the bases are rewritten by the next tile
     }
 }
@@ -451,7 +524,7 @@ __global__ __launch_bounds__(1024) void k_scan_pieces(const uint64_t *__restrict
 }
 
 // Distinct cells among the tuples of the first PROBE_BINS level-1 bins (a global hash set; one thread per tuple).
-__global__ __launch_bounds__(BLOCK) void k_probe_distinct(const GridSeg *__restrict__ segs, const GridEntryDev *__restrict__ entries, DevGrid g,
+__global__ __launch_bounds__(BLOCK) void k_probe_distinct(const GridSeg *__restrict__ segs, EntryRef entries, DevGrid g,
                                                           uint64_t *__restrict__ set, uint64_t mask, unsigned long long *__restrict__ distinct) {
     const GridSeg sg = segs[blockIdx.y];
     const uint32_t lo = sg.off[0], hi = sg.off[PROBE_BINS];
@@ -486,7 +559,7 @@ __global__ __launch_bounds__(BLOCK) void k_probe_distinct(const GridSeg *__restr
 struct Level2Params {
     const GridSeg *segs;
     int nsegs;
-    const GridEntryDev *entries;
+    EntryRef entries;
     DevGrid g;
     uint32_t f2;
     const uint32_t *binbase;  // [F1 + 1] tuples in front of each bin (prefix over all segments); nullptr: tuples are not moved
@@ -513,8 +586,17 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
         for (int r = 0; r < P.nsegs; r++) {
             const GridSeg sg = P.segs[r];
             const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
-            for (uint32_t i = lo + threadIdx.x; i < hi; i += L2_NT)
-                atomicAdd(&s_hist[sub_of(hash64(eval_tuple(P.g, P.entries, ld_tuple(sg.tuples + i)).key), f2)], 1u);
+            for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += L2_NT * L2_UNROLL) {  // the loads of four steps are issued together
+                GridTuple t[L2_UNROLL];
+#pragma unroll
+                for (int u = 0; u < L2_UNROLL; u++) {
+                    const uint32_t i = i0 + u * L2_NT;
+                    t[u] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
+                }
+#pragma unroll
+                for (int u = 0; u < L2_UNROLL; u++)
+                    if (i0 + u * L2_NT < hi) atomicAdd(&s_hist[sub_of(hash64(eval_tuple(P.g, P.entries, t[u]).key), f2)], 1u);
+            }
         }
     if (P.okeys)
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
@@ -543,10 +625,19 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
         for (int r = 0; r < P.nsegs; r++) {
             const GridSeg sg = P.segs[r];
             const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
-            for (uint32_t i = lo + threadIdx.x; i < hi; i += L2_NT) {
-                const GridTuple t = ld_tuple(sg.tuples + i);
-                const uint32_t pos = atomicAdd(&s_cur[sub_of(hash64(eval_tuple(P.g, P.entries, t).key), f2)], 1u);
-                st_tuple(P.out + pos, t);
+            for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += L2_NT * L2_UNROLL) {
+                GridTuple t[L2_UNROLL];
+#pragma unroll
+                for (int u = 0; u < L2_UNROLL; u++) {
+                    const uint32_t i = i0 + u * L2_NT;
+                    t[u] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
+                }
+#pragma unroll
+                for (int u = 0; u < L2_UNROLL; u++) {
+                    if (i0 + u * L2_NT >= hi) continue;
+                    const uint32_t pos = atomicAdd(&s_cur[sub_of(hash64(eval_tuple(P.g, P.entries, t[u]).key), f2)], 1u);
+                    st_tuple(P.out + pos, t[u]);
+                }
             }
         }
     if (P.okeys)
@@ -590,7 +681,7 @@ struct FoldParams {
     const GridSeg *segs;
     int nsegs;
     GridSeg seg0;                  // segs[0] again, in the kernel arguments: one dependent load fewer when nsegs == 1
-    const GridEntryDev *entries;
+    EntryRef entries;
     DevGrid g;
     // earlier winners by partition (okeys == nullptr: none)
     const uint64_t *okeys;
@@ -624,8 +715,15 @@ __device__ __forceinline__ int lds_find_or_insert(uint64_t *s_key, uint64_t key,
     return -1;
 }
 
-template <int NSLOT, int NT, int LIMIT, bool PAY_LDS>
-__global__ __launch_bounds__(NT) void k_fold(FoldParams P) {
+// Workgroups are persistent: each folds the partitions blockIdx.x, blockIdx.x + gridDim.x, ...  A small partition is a
+// chain of dependent round trips (its offsets, then its tuples, then the fold, then the stores), so the loop is
+// software-pipelined: the offsets of the partition after the next and the first chunk of tuples of the next one are
+// loaded while the current one is folded.
+// SMALL (XPART) keeps the next PARTITION's first chunk in flight and loads further chunks of a partition (rare: a partition
+// is about one chunk) on demand.  BIG loads chunk by chunk: with 16 waves on the CU a register prefetch of the next chunk
+// measured no faster and spilled.
+template <int NSLOT, int NT, int LIMIT, bool PAY_LDS, bool XPART, int MIN_WAVES>
+__global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t nparts) {
     constexpr int SPT = (NSLOT + NT - 1) / NT;   // slots per thread in the compaction
     constexpr int CHUNK = NT * FOLD_K;
     __shared__ uint64_t s_key[NSLOT];
@@ -634,173 +732,221 @@ __global__ __launch_bounds__(NT) void k_fold(FoldParams P) {
     __shared__ uint32_t s_pay_lds[PAY_LDS ? NSLOT * 5 : 1];  // winner's x, y, z, w0, w1 — or, for an earlier winner, its index (two words)
     __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32], s_oldbits[(NSLOT + 31) / 32];
     __shared__ uint32_t s_ncell, s_over, s_wsum[NT / 64];
-    const uint32_t p = blockIdx.x;
-    uint32_t *pay = PAY_LDS ? s_pay_lds : P.pay_scratch + (size_t)p * NSLOT * 5;
-    // everything that depends on p alone is loaded up front, together
-    const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
-    const uint64_t old_base = P.okeys ? P.obase[p] : 0;
-    const uint64_t out_base = P.wbase[p];
-    for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
-    for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0, s_oldbits[t] = 0;
-    if (threadIdx.x == 0) s_ncell = 0, s_over = 0;
-    __syncthreads();
-
-    // earlier winners first: their distance is recomputed from the record (same f64 expressions, same bits)
-    for (uint32_t i = threadIdx.x; i < n_old; i += NT) {
-        const uint64_t key = P.okeys[old_base + i];
-        const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, key, hash64(key), &s_ncell);
-        if (s < 0) {
-            s_over = 1;
-            continue;
-        }
-        const uint8_t *rec = P.orecs + (old_base + i) * 32;
-        atomicOr(&s_oldbits[s >> 5], 1u << (s & 31));
-        pay[s * 5] = (uint32_t)(old_base + i);
-        pay[s * 5 + 1] = (uint32_t)((old_base + i) >> 32);
-        if (rec[31] & R_ALIAS) {
-            atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
-        } else {
-            const double *pos = reinterpret_cast<const double *>(rec);
-            uint64_t cell[3];
-#pragma unroll
-            for (int a = 0; a < 3; a++) cell[a] = (key >> P.g.shift[a]) & P.g.mask[a];  // not aliased: unmasked == masked
-            s_dist[s] = (uint64_t)__double_as_longlong(centre_dist(P.g, cell, pos[0], pos[1], pos[2]));
-            s_ord[s] = 0;
-        }
-    }
-    __syncthreads();
-
-    for (int r = 0; r < P.nsegs; r++) {
-        const GridSeg sg = r == 0 ? P.seg0 : P.segs[r];
-        const uint32_t lo = sg.off[p], cnt = sg.off[p + 1] - lo;
-        for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
-            GridTuple tu[FOLD_K];
-            uint64_t dbits[FOLD_K];
-            int slot[FOLD_K];
-            // the chunk's tuples are loaded together, then folded
-#pragma unroll
-            for (int k = 0; k < FOLD_K; k++) {
-                const uint32_t i = c0 + k * NT + threadIdx.x;
-                tu[k] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
-            }
-            // phase 1: cells and their minimum distance
-#pragma unroll
-            for (int k = 0; k < FOLD_K; k++) {
-                const uint32_t i = c0 + k * NT + threadIdx.x;
-                slot[k] = -1;
-                if (i >= cnt) continue;
-                const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
-                dbits[k] = ev.dbits;
-                const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, hash64(ev.key), &s_ncell);
-                if (s < 0) {
-                    s_over = 1;
-                    continue;
-                }
-                slot[k] = s;
-                if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
-                // most tuples of a coarse grid cannot lower the minimum: a plain read first (a stale value is only too large)
-                if (ev.dbits < __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                    const uint64_t old = atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
-                    if (ev.dbits < old) s_ord[s] = ~0ull;  // a new minimum: whoever held the cell is out (racing writers store the same value)
-                }
-            }
-            __syncthreads();
-            // phase 2: among the tuples at the minimum, the earliest in file order
-#pragma unroll
-            for (int k = 0; k < FOLD_K; k++) {
-                if (slot[k] < 0) continue;
-                if (dbits[k] == s_dist[slot[k]]) atomicMin((unsigned long long *)&s_ord[slot[k]], (unsigned long long)ord_of(tu[k]));
-            }
-            __syncthreads();
-            // phase 3: a winner from this chunk parks its payload
-#pragma unroll
-            for (int k = 0; k < FOLD_K; k++) {
-                const int s = slot[k];
-                if (s < 0) continue;
-                if (dbits[k] == s_dist[s] && s_ord[s] == ord_of(tu[k])) {
-                    pay[s * 5] = (uint32_t)tu[k].x, pay[s * 5 + 1] = (uint32_t)tu[k].y, pay[s * 5 + 2] = (uint32_t)tu[k].z;
-                    pay[s * 5 + 3] = tu[k].w0, pay[s * 5 + 4] = tu[k].w1;
-                    atomicAnd(&s_oldbits[s >> 5], ~(1u << (s & 31)));
-                }
-            }
-            // no barrier here: the next chunk's phase 1 can only make this test fail for a slot whose winner is
-            // about to be replaced, and every thread passes the barrier behind it before anyone parks again
-        }
-    }
-    if (!PAY_LDS) __threadfence();  // the parked payloads are read back by other threads of the workgroup
-    __syncthreads();
-    if (s_over) {  // more cells than the table holds: the host repeats the fold with more partitions
-        if (threadIdx.x == 0) {
-            P.wcount[p] = 0;
-            atomicAdd(&P.stats[1], 1ull);
-        }
-        return;
-    }
-
-    // compaction: thread t owns slots [t * SPT, ...): winners leave in slot order
-    uint32_t mine = 0;
-    const int s0 = threadIdx.x * SPT;
-#pragma unroll
-    for (int j = 0; j < SPT; j++) mine += (s0 + j < NSLOT && s_key[s0 + j] != PCQ_EMPTY_KEY) ? 1 : 0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint32_t incl = mine;
+    const GridSeg sg0 = P.seg0;
+
+    // pipeline state: the first segment's range and the output base of the current and the next partition,
+    // and the first chunk of the current partition's tuples
+    uint32_t cur_lo = 0, cur_cnt = 0, nxt_lo = 0, nxt_cnt = 0;
+    uint64_t cur_out = 0, nxt_out = 0;
+    GridTuple first[FOLD_K];
+    uint32_t p = blockIdx.x;
+    if (p < nparts) {
+        cur_lo = sg0.off[p], cur_cnt = sg0.off[p + 1] - cur_lo, cur_out = P.wbase[p];
+        if (XPART) {
 #pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += up;
-    }
-    if (lane == 63) s_wsum[wave] = incl;
-    __syncthreads();
-    uint32_t before = incl - mine, total = 0;
-    for (int w = 0; w < NT / 64; w++) {
-        before += w < wave ? s_wsum[w] : 0;
-        total += s_wsum[w];
-    }
-    bool any_alias = false;
-    uint64_t o = out_base + before;
-#pragma unroll
-    for (int j = 0; j < SPT; j++) {
-        const int s = s0 + j;
-        if (s >= NSLOT || s_key[s] == PCQ_EMPTY_KEY) continue;
-        const uint64_t key = s_key[s];
-        P.wkeys[o] = key;
-        uint8_t *dst = P.wrecs + o * 32;
-        const bool alias = (s_aliasbits[s >> 5] >> (s & 31)) & 1, old = (s_oldbits[s >> 5] >> (s & 31)) & 1;
-        if (alias) {  // left to the exact replay: the state before this fold (the earlier winner, if there is one) + the flag
-            any_alias = true;
-            uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
-            for (uint32_t i = 0; i < n_old; i++)
-                if (P.okeys[old_base + i] == key) {
-                    const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + (old_base + i) * 32);
-                    a = sp[0], b = sp[1];
-                    b.w |= (uint32_t)R_ALIAS << 24;
-                    break;
-                }
-            reinterpret_cast<uint4 *>(dst)[0] = a;
-            reinterpret_cast<uint4 *>(dst)[1] = b;
-        } else {
-            uint32_t w[5];
-#pragma unroll
-            for (int q = 0; q < 5; q++)
-                w[q] = PAY_LDS ? pay[s * 5 + q] : __hip_atomic_load(&pay[s * 5 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old) {
-                const uint64_t oi = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-                const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + oi * 32);
-                reinterpret_cast<uint4 *>(dst)[0] = sp[0];
-                reinterpret_cast<uint4 *>(dst)[1] = sp[1];
-            } else {
-                st_record(dst, P.entries[(w[3] >> 8) & 0xff], (int32_t)w[0], (int32_t)w[1], (int32_t)w[2], w[3], w[4], R_HAS);
+            for (int k = 0; k < FOLD_K; k++) {
+                const uint32_t i = k * NT + threadIdx.x;
+                first[k] = ld_tuple(sg0.tuples + cur_lo + (i < cur_cnt ? i : (cur_cnt ? cur_cnt - 1 : 0)));
             }
         }
-        o++;
     }
-    if (__syncthreads_or(any_alias) && threadIdx.x == 0) {
-        P.palias[p] = 1;
-        atomicAdd(&P.stats[2], 1ull);
-    }
-    if (threadIdx.x == 0) {
-        P.wcount[p] = total;
-        if (total) atomicAdd(&P.stats[0], (unsigned long long)total);
+    for (; p < nparts; p += gridDim.x) {
+        const uint32_t pn = p + gridDim.x;
+        if (pn < nparts) nxt_lo = sg0.off[pn], nxt_cnt = sg0.off[pn + 1] - nxt_lo, nxt_out = P.wbase[pn];
+        uint32_t *pay = PAY_LDS ? s_pay_lds : P.pay_scratch + (size_t)p * NSLOT * 5;
+        const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
+        const uint64_t old_base = P.okeys ? P.obase[p] : 0;
+        const uint64_t out_base = cur_out;
+        for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
+        for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0, s_oldbits[t] = 0;
+        if (threadIdx.x == 0) s_ncell = 0, s_over = 0;
+        __syncthreads();
+
+        // earlier winners first: their distance is recomputed from the record (same f64 expressions, same bits)
+        for (uint32_t i = threadIdx.x; i < n_old; i += NT) {
+            const uint64_t key = P.okeys[old_base + i];
+            const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, key, hash64(key), &s_ncell);
+            if (s < 0) {
+                s_over = 1;
+                continue;
+            }
+            const uint8_t *rec = P.orecs + (old_base + i) * 32;
+            atomicOr(&s_oldbits[s >> 5], 1u << (s & 31));
+            pay[s * 5] = (uint32_t)(old_base + i);
+            pay[s * 5 + 1] = (uint32_t)((old_base + i) >> 32);
+            if (rec[31] & R_ALIAS) {
+                atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
+            } else {
+                const double *pos = reinterpret_cast<const double *>(rec);
+                uint64_t cell[3];
+#pragma unroll
+                for (int a = 0; a < 3; a++) cell[a] = (key >> P.g.shift[a]) & P.g.mask[a];  // not aliased: unmasked == masked
+                s_dist[s] = (uint64_t)__double_as_longlong(centre_dist(P.g, cell, pos[0], pos[1], pos[2]));
+                s_ord[s] = 0;
+            }
+        }
+        if (n_old) __syncthreads();
+
+        for (int r = 0; r < P.nsegs; r++) {
+            const GridSeg sg = r == 0 ? sg0 : P.segs[r];
+            const uint32_t lo = r == 0 ? cur_lo : sg.off[p], cnt = r == 0 ? cur_cnt : sg.off[p + 1] - lo;
+            if (cnt == 0) continue;
+            for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
+                GridTuple tu[FOLD_K];
+                uint64_t dbits[FOLD_K];
+                int slot[FOLD_K];
+                if (XPART) {
+                    if (r == 0 && c0 == 0) {
+#pragma unroll
+                        for (int k = 0; k < FOLD_K; k++) tu[k] = first[k];
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < FOLD_K; k++) {
+                            const uint32_t i = c0 + k * NT + threadIdx.x;
+                            tu[k] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
+                        }
+                    }
+                    if (r == 0 && c0 + CHUNK >= cnt && pn < nparts) {  // the next partition's first chunk is on its way while this one is folded
+#pragma unroll
+                        for (int k = 0; k < FOLD_K; k++) {
+                            const uint32_t i = k * NT + threadIdx.x;
+                            first[k] = ld_tuple(sg0.tuples + nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0)));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < FOLD_K; k++) {
+                        const uint32_t i = c0 + k * NT + threadIdx.x;
+                        tu[k] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
+                    }
+                }
+                // phase 1: cells and their minimum distance
+#pragma unroll
+                for (int k = 0; k < FOLD_K; k++) {
+                    const uint32_t i = c0 + k * NT + threadIdx.x;
+                    slot[k] = -1;
+                    if (i >= cnt) continue;
+                    const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
+                    dbits[k] = ev.dbits;
+                    const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, hash64(ev.key), &s_ncell);
+                    if (s < 0) {
+                        s_over = 1;
+                        continue;
+                    }
+                    slot[k] = s;
+                    if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
+                    // most tuples of a coarse grid cannot lower the minimum: a plain read first (a stale value is only too large)
+                    if (ev.dbits < __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        const uint64_t old = atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
+                        if (ev.dbits < old) s_ord[s] = ~0ull;  // a new minimum: whoever held the cell is out (racing writers store the same value)
+                    }
+                }
+                __syncthreads();
+                // phase 2: among the tuples at the minimum, the earliest in file order
+#pragma unroll
+                for (int k = 0; k < FOLD_K; k++) {
+                    if (slot[k] < 0) continue;
+                    if (dbits[k] == s_dist[slot[k]]) atomicMin((unsigned long long *)&s_ord[slot[k]], (unsigned long long)ord_of(tu[k]));
+                }
+                __syncthreads();
+                // phase 3: a winner from this chunk parks its payload
+#pragma unroll
+                for (int k = 0; k < FOLD_K; k++) {
+                    const int s = slot[k];
+                    if (s < 0) continue;
+                    if (dbits[k] == s_dist[s] && s_ord[s] == ord_of(tu[k])) {
+                        pay[s * 5] = (uint32_t)tu[k].x, pay[s * 5 + 1] = (uint32_t)tu[k].y, pay[s * 5 + 2] = (uint32_t)tu[k].z;
+                        pay[s * 5 + 3] = tu[k].w0, pay[s * 5 + 4] = tu[k].w1;
+                        atomicAnd(&s_oldbits[s >> 5], ~(1u << (s & 31)));
+                    }
+                }
+                // no barrier here: the next chunk's phase 1 can only make this test fail for a slot whose winner is
+                // about to be replaced, and every thread passes the barrier behind it before anyone parks again
+            }
+        }
+        if (XPART && cur_cnt == 0 && pn < nparts) {  // an empty first segment never reached the prefetch above
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) {
+                const uint32_t i = k * NT + threadIdx.x;
+                first[k] = ld_tuple(sg0.tuples + nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0)));
+            }
+        }
+        if (!PAY_LDS) __threadfence();  // the parked payloads are read back by other threads of the workgroup
+        __syncthreads();
+        if (s_over) {  // more cells than the table holds: the host repeats the fold with more partitions
+            if (threadIdx.x == 0) {
+                P.wcount[p] = 0;
+                atomicAdd(&P.stats[1], 1ull);
+            }
+        } else {
+            // compaction: thread t owns slots [t * SPT, ...): winners leave in slot order
+            uint32_t mine = 0;
+            const int s0 = threadIdx.x * SPT;
+#pragma unroll
+            for (int j = 0; j < SPT; j++) mine += (s0 + j < NSLOT && s_key[s0 + j] != PCQ_EMPTY_KEY) ? 1 : 0;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = incl - mine, total = 0;
+            for (int w = 0; w < NT / 64; w++) {
+                before += w < wave ? s_wsum[w] : 0;
+                total += s_wsum[w];
+            }
+            bool any_alias = false;
+            uint64_t o = out_base + before;
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                const int s = s0 + j;
+                if (s >= NSLOT || s_key[s] == PCQ_EMPTY_KEY) continue;
+                const uint64_t key = s_key[s];
+                P.wkeys[o] = key;
+                uint8_t *dst = P.wrecs + o * 32;
+                const bool alias = (s_aliasbits[s >> 5] >> (s & 31)) & 1, old = (s_oldbits[s >> 5] >> (s & 31)) & 1;
+                if (alias) {  // left to the exact replay: the state before this fold (the earlier winner, if there is one) + the flag
+                    any_alias = true;
+                    uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
+                    for (uint32_t i = 0; i < n_old; i++)
+                        if (P.okeys[old_base + i] == key) {
+                            const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + (old_base + i) * 32);
+                            a = sp[0], b = sp[1];
+                            b.w |= (uint32_t)R_ALIAS << 24;
+                            break;
+                        }
+                    reinterpret_cast<uint4 *>(dst)[0] = a;
+                    reinterpret_cast<uint4 *>(dst)[1] = b;
+                } else {
+                    uint32_t w[5];
+#pragma unroll
+                    for (int q = 0; q < 5; q++)
+                        w[q] = PAY_LDS ? pay[s * 5 + q] : __hip_atomic_load(&pay[s * 5 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (old) {
+                        const uint64_t oi = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+                        const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + oi * 32);
+                        reinterpret_cast<uint4 *>(dst)[0] = sp[0];
+                        reinterpret_cast<uint4 *>(dst)[1] = sp[1];
+                    } else {
+                        st_record(dst, P.entries.get((w[3] >> 8) & 0xff), (int32_t)w[0], (int32_t)w[1], (int32_t)w[2], w[3], w[4], R_HAS);
+                    }
+                }
+                o++;
+            }
+            if (__syncthreads_or(any_alias) && threadIdx.x == 0) {
+                P.palias[p] = 1;
+                atomicAdd(&P.stats[2], 1ull);
+            }
+            if (threadIdx.x == 0) {
+                P.wcount[p] = total;
+                if (total) atomicAdd(&P.stats[0], (unsigned long long)total);
+            }
+        }
+        cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
+        __syncthreads();  // the table is cleared for the next partition
     }
 }
 
@@ -883,7 +1029,7 @@ __global__ __launch_bounds__(BLOCK) void k_alias_replay(const AliasItem *__restr
     AliasItem best = sorted[e];
     for (uint64_t q = e; q < n && sorted[q].key == key; q++) {
         const AliasItem it = sorted[q];
-        const GridEntryDev &en = P.entries[(it.w0 >> 8) & 0xff];
+        const GridEntryDev en = P.entries.get((it.w0 >> 8) & 0xff);
         const double px = world(it.x, en.scale[0], en.offset[0]), py = world(it.y, en.scale[1], en.offset[1]), pz = world(it.z, en.scale[2], en.offset[2]);
         bool take;
         if (!has) {
@@ -898,7 +1044,7 @@ __global__ __launch_bounds__(BLOCK) void k_alias_replay(const AliasItem *__restr
             changed = true;
         }
     }
-    if (changed) st_record(rec, P.entries[(best.w0 >> 8) & 0xff], best.x, best.y, best.z, best.w0, best.w1, R_HAS | R_ALIAS);
+    if (changed) st_record(rec, P.entries.get((best.w0 >> 8) & 0xff), best.x, best.y, best.z, best.w0, best.w1, R_HAS | R_ALIAS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1152,6 +1298,9 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     if (rc) return rc;
     PCQ_HIP(hipMemcpyAsync(d_segs, hsegs.data(), nruns * sizeof(GridSeg), hipMemcpyHostToDevice, s));
     PCQ_HIP(hipMemcpyAsync(d_entries, gs->entries.data(), gs->entries.size() * sizeof(GridEntryDev), hipMemcpyHostToDevice, s));
+    EntryRef eref;
+    eref.table = d_entries;
+    eref.e0 = gs->entries[0];
     hipLaunchKernelGGL(k_part_totals, dim3(F1 / BLOCK), dim3(BLOCK), 0, s, d_segs, nruns, (uint32_t)F1, d_bintot);
     hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, d_bintot, d_binbase, (uint32_t)F1);
     uint32_t h_probe[2] = {0, 0};  // tuples in the probe bins, tuples in all
@@ -1181,7 +1330,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         unsigned per_seg = (unsigned)((h_probe[0] / (unsigned)nruns + BLOCK - 1) / BLOCK);
         if (per_seg < 1) per_seg = 1;
         if (per_seg > 4096) per_seg = 4096;
-        hipLaunchKernelGGL(k_probe_distinct, dim3(per_seg, (unsigned)nruns), dim3(BLOCK), 0, s, d_segs, d_entries, g, d_set, cap - 1, d_stats);
+        hipLaunchKernelGGL(k_probe_distinct, dim3(per_seg, (unsigned)nruns), dim3(BLOCK), 0, s, d_segs, eref, g, d_set, cap - 1, d_stats);
         unsigned long long distinct = 0;
         PCQ_HIP(hipMemcpyAsync(&distinct, d_stats, 8, hipMemcpyDeviceToHost, s));
         PCQ_HIP(hipStreamSynchronize(s));
@@ -1206,7 +1355,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         const bool recut_old = w_old && gs->f2 != f2;
         if (f2 > 1 || recut_old) {
             Level2Params L{};
-            L.segs = d_segs, L.nsegs = nruns, L.entries = d_entries, L.g = g, L.f2 = f2;
+            L.segs = d_segs, L.nsegs = nruns, L.entries = eref, L.g = g, L.f2 = f2;
             GridTuple *d_t2 = nullptr;
             uint32_t *d_off2 = nullptr;
             if (f2 > 1) {
@@ -1279,11 +1428,15 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         PCQ_HIP(hipMemsetAsync(d_palias, 0, (size_t)nparts * 4, s));
         PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
         FoldParams F{};
-        F.segs = fold_segs, F.nsegs = fold_nsegs, F.seg0 = fold_seg0, F.entries = d_entries, F.g = g;
+        F.segs = fold_segs, F.nsegs = fold_nsegs, F.seg0 = fold_seg0, F.entries = eref, F.g = g;
         if (w_old) F.okeys = okeys, F.orecs = orecs, F.obase = obase, F.ocount = ocount;
         F.wkeys = n_wkeys, F.wrecs = n_wrecs, F.wbase = n_wbase, F.wcount = n_wcount, F.palias = d_palias, F.pay_scratch = d_pay, F.stats = d_stats;
-        if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_LIMIT, false>), dim3(nparts), dim3(BIG_NT), 0, s, F);
-        else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_LIMIT, true>), dim3(nparts), dim3(SMALL_NT), 0, s, F);
+        {
+            uint32_t resident = (uint32_t)ctx->num_cus * (big ? 1u : 3u);  // what fits the LDS: the rest of the partitions is looped over
+            if (resident > nparts) resident = nparts;
+            if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_LIMIT, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
+            else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_LIMIT, true, true, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
+        }
         PCQ_HIP(hipGetLastError());
         unsigned long long st[4] = {0, 0, 0, 0};
         PCQ_HIP(hipMemcpyAsync(st, d_stats, sizeof st, hipMemcpyDeviceToHost, s));

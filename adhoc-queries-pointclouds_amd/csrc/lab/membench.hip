@@ -1,9 +1,9 @@
-// membench.hip — read-only HBM streaming reference kernels (developer tool, include/pcq_synth.h).
+// membench.hip — read-only HBM streaming reference kernels (developer tool, include/pcq_lab.h; built only into libpcq_lab.so).
 // They do nothing but load and XOR, with the SAME access shapes the scan kernels use, so that the
 // scan kernels' achieved GB/s can be compared with what the memory system delivers for a pure read
 // stream on the same device (a measured ceiling instead of an assumed one).
 #include "pcq_internal.h"
-#include "pcq_synth.h"
+#include "pcq_lab.h"
 
 namespace {
 

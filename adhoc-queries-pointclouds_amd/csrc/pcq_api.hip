@@ -119,6 +119,7 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) ctx->copy_threads = v;
     }
+#ifdef PCQ_LAB
     if (const char *e = getenv("PCQ_BATCH_VARIANT")) {
         const int v = atoi(e);
         if (v >= 0 && v <= 3) ctx->batch_variant = v;
@@ -135,6 +136,7 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
         const int v = atoi(e);
         if (v >= 0 && v <= 14) ctx->k1_variant = v;
     }
+#endif
     *out_ctx = ctx;
     return PCQ_OK;
 }
@@ -275,13 +277,14 @@ extern "C" int pcq_bind_thread_near_device(pcq_ctx *ctx) {
 extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx || !key) return pcq_fail(PCQ_ERR_ARG, "pcq_set_option: null argument");
-    if (!strcmp(key, "k1_variant")) {
-        if (value < 0 || value > 14) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..14");
-        ctx->k1_variant = (int)value;
-    } else if (!strcmp(key, "blocks_per_cu")) {
+    if (!strcmp(key, "blocks_per_cu")) {
         if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "blocks_per_cu must be 1..32");
         ctx->grid_blocks_per_cu = (int)value;
+#ifdef PCQ_LAB
         ctx->batch_blocks_per_cu = (int)value;
+    } else if (!strcmp(key, "k1_variant")) {
+        if (value < 0 || value > 14) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..14");
+        ctx->k1_variant = (int)value;
     } else if (!strcmp(key, "class_batch_loads")) {
         if (value != 0 && value != 4 && value != 6 && value != 8 && value != 12) return pcq_fail(PCQ_ERR_ARG, "class_batch_loads must be 0, 4, 6, 8 or 12");
         ctx->class_batch_loads = (int)value;
@@ -302,9 +305,9 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "batch_waves_per_cu")) {
         if (value < 1 || value > 32) return pcq_fail(PCQ_ERR_ARG, "batch_waves_per_cu must be 1..32");
         ctx->batch_waves_per_cu = (int)value;
-    } else if (!strcmp(key, "grid_pending_budget")) {
-        if (value < 0) return pcq_fail(PCQ_ERR_ARG, "grid_pending_budget must be >= 0");
-        ctx->grid_pending_budget = value;
+#endif
+    } else if (!strcmp(key, "allreduce_single_rank")) {
+        ctx->allreduce_single_rank = value != 0;
     } else if (!strcmp(key, "grid_f2")) {
         if (value < 0 || value > 256) return pcq_fail(PCQ_ERR_ARG, "grid_f2 must be 0..256");
         ctx->grid_f2 = (int)value;
@@ -337,16 +340,19 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
 
 extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     if (!ctx || !key || !value) return pcq_fail(PCQ_ERR_ARG, "pcq_get_option: null argument");
-    if (!strcmp(key, "k1_variant")) *value = ctx->k1_variant;
+    if (!strcmp(key, "blocks_per_cu")) *value = ctx->grid_blocks_per_cu;
+#ifdef PCQ_LAB
+    else if (!strcmp(key, "k1_variant")) *value = ctx->k1_variant;
     else if (!strcmp(key, "k1_waves_per_cu")) *value = ctx->k1_waves_per_cu;
     else if (!strcmp(key, "batch_variant")) *value = ctx->batch_variant;
     else if (!strcmp(key, "batch_waves_per_cu")) *value = ctx->batch_waves_per_cu;
-    else if (!strcmp(key, "blocks_per_cu")) *value = ctx->grid_blocks_per_cu;
+#endif
     else if (!strcmp(key, "chunk_points")) *value = (int64_t)ctx->chunk_points;
     else if (!strcmp(key, "copy_threads")) *value = ctx->copy_threads;
     else if (!strcmp(key, "numa_local")) *value = ctx->numa_local;
     else if (!strcmp(key, "numa_node")) *value = ctx->numa_node;
     else if (!strcmp(key, "grid_pending_budget")) *value = ctx->grid_pending_budget;
+    else if (!strcmp(key, "allreduce_single_rank")) *value = ctx->allreduce_single_rank;
     else if (!strcmp(key, "grid_f2")) *value = ctx->grid_f2;
     else if (!strcmp(key, "grid_folds")) *value = ctx->grid_folds;
     else if (!strcmp(key, "grid_level2")) *value = ctx->grid_level2;
@@ -537,6 +543,7 @@ extern "C" int pcq_collector_new_grid(pcq_ctx *ctx, const double bmin[3], const 
         g.bmin[a] = bmin[a];
         g.bmax[a] = bmax[a];
         g.dims_f[a] = (double)c->dims[a];
+        g.inv_extent[a] = 1.0 / (bmax[a] - bmin[a]);
         g.mask[a] = (1ull << (c->bits[a] & 63)) - 1;  // Rust release `1u64 << n` masks n to 6 bits
     }
     g.cell_size = cell_size;

@@ -101,6 +101,7 @@ struct DevGrid {
     double bmin[3], bmax[3];
     double cell_size;
     double dims_f[3];     // dims as f64 (`self.dimensions.x as f64`, grid_sampling.rs:51)
+    double inv_extent[3]; // 1 / (bmax - bmin): only to find the cell WITHOUT the division when that is provably safe (grid.hip cell_of)
     uint64_t mask[3];     // (1 << bits) - 1
     uint32_t shift[3];    // 0, bits_x, bits_x + bits_y  (already & 63)
 };
@@ -151,19 +152,22 @@ struct pcq_ctx {
     // folds repeated because a partition overflowed its LDS table, the last fold's second-level fan-out
     int64_t grid_folds = 0, grid_level2 = 0, grid_refolds = 0, grid_last_f2 = 0;
     int64_t grid_pending_budget = 0;    // option: tuples a grid collector may hold before it folds (0 = default)
+    int allreduce_single_rank = 0;      // option: pcq_allreduce_sum_u64 with ONE rank still goes through RCCL (communicator of one
+                                        // device, ncclAllReduce) — exercises the run-time binding on a single-GPU box
     int grid_f2 = 0;                    // option (tests): second-level fan-out a fold starts from (0 = from the measured estimate)
     // options
-    int k1_variant = 12;          // per-file K1: one wave per workgroup, two adjacent 3 KiB tiles per step, software-pipelined (profiles/r01_k1_one_wave_blocks.log)
-    int k1_waves_per_cu = 3;      // workgroups (= waves) per CU for the one-wave variants 8..14: 3 for the pipelined 12 (6-12 KiB outstanding per wave), 8 for 9
-    int grid_blocks_per_cu = 2;   // persistent blocks per CU of the streaming count kernels: 8 waves x 3 KiB in flight per CU measured best (profiles/r01_k1_variant_sweep_interleaved.log)
-    int batch_blocks_per_cu = 3;  // the batched K1 measured best at 3 (same log)
-    int k1_grid = 0;              // experiments: absolute number of workgroups for the one-wave per-file kernels (0 = num_cus x k1_waves_per_cu)
-    int batch_variant = 3;        // batched K1: 0 = 256-thread blocks, one tile per wave step; 1 / 2 = one wave per workgroup, 2 / 3 tiles per step;
-                                  // 3 = one wave per workgroup, 2 tiles per step, software-pipelined
-    int batch_waves_per_cu = 3;   // 3 for batch_variant 3 (7.07 TB/s in the bench); variant 2 is flat from 5 to 8 (6.93-7.03) (profiles/r01_k1_one_wave_blocks.log)
-    int class_batch_loads = 4;        // batched K2: 0 = 256-thread kernel; 4 / 6 / 8 / 12 = one-wave workgroups with that many 1 KiB loads per step
-    int class_batch_waves_per_cu = 4; // pipelined: 4 waves x 4-8 KiB outstanding measured best, 7.15 TB/s; not pipelined: 8 x 4 KiB, 7.0 (profiles/r01_k2_sweep.log)
-    int class_batch_pipe = 1;         // 1: the software-pipelined form of the one-wave batched K2
+    int grid_blocks_per_cu = 2;   // persistent blocks per CU of the generic (strided) count kernels and the chunk index
+#ifdef PCQ_LAB                    // libpcq_lab.so only: the kernel shapes of csrc/lab/scan_count_lab.hip
+    int k1_variant = 12;          // per-file K1: 12 = one wave per workgroup, two adjacent 3 KiB tiles per step, software-pipelined (= the product's)
+    int k1_waves_per_cu = 3;
+    int batch_blocks_per_cu = 3;
+    int k1_grid = 0;              // absolute number of workgroups for the one-wave per-file kernels (0 = num_cus x k1_waves_per_cu)
+    int batch_variant = 3;        // batched K1: 0 = 256-thread blocks · 1 / 2 = one wave per workgroup, 2 / 3 tiles per step · 3 = pipelined (= the product's)
+    int batch_waves_per_cu = 3;
+    int class_batch_loads = 4;
+    int class_batch_waves_per_cu = 4;
+    int class_batch_pipe = 1;
+#endif
     int numa_node = -1;               // NUMA node the GPU hangs off (sysfs), -1 if unknown
     cpu_set_t node_cpus;              // its CPUs (empty if unknown)
     int numa_local = 1;               // option "numa_local": staging buffers and copy helpers on that node

@@ -82,23 +82,23 @@ static int make_collector(int device, pcq_host_collector **out, F &&create) {
     Status st = thread_context(device, &ctx);
     if (!st.ok()) return done(st);
     auto hc = std::make_unique<pcq_host_collector>();
-    st = create(ctx, &hc->c);
+    st = create(ctx, nullptr, &hc->c);
     if (!st.ok()) return done(st);
     *out = hc.release();
     return PCQ_OK;
 }
 
 extern "C" int pcq_query_collector_new_count(int device, pcq_host_collector **out) {
-    return make_collector(device, out, [](pcq_ctx *ctx, std::unique_ptr<ResultCollector> *o) { return CountCollector::create(ctx, o); });
+    return make_collector(device, out, [](pcq_ctx *ctx, uint64_t *, std::unique_ptr<ResultCollector> *o) { return CountCollector::create(ctx, o); });
 }
 extern "C" int pcq_query_collector_new_buffer(int device, pcq_host_collector **out) {
-    return make_collector(device, out, [](pcq_ctx *ctx, std::unique_ptr<ResultCollector> *o) { return BufferCollector::create(ctx, o); });
+    return make_collector(device, out, [](pcq_ctx *ctx, uint64_t *, std::unique_ptr<ResultCollector> *o) { return BufferCollector::create(ctx, o); });
 }
 extern "C" int pcq_query_collector_new_grid(int device, const double bmin[3], const double bmax[3], double cell_size,
                                             pcq_host_collector **out) {
     if (!bmin || !bmax) return done(Status::Err(PCQ_ERR_ARG, "null argument"));
     const AABB b = AABB::from_min_max_unchecked(bmin, bmax);
-    return make_collector(device, out, [&](pcq_ctx *ctx, std::unique_ptr<ResultCollector> *o) {
+    return make_collector(device, out, [&](pcq_ctx *ctx, uint64_t *, std::unique_ptr<ResultCollector> *o) {
         return GridSampledCollector::create(ctx, b, cell_size, o);
     });
 }

@@ -302,110 +302,20 @@ Status impossible_point_count(const LazerFile &lz) {
 
 }  // namespace
 
-// ---- inflate on the device -------------------------------------------------------------------------------
-// The whole block region of the file goes to HBM compressed; every column blob becomes one job of
-// pcq_lz4_inflate_dev (one wave per LZ4 frame).  A frame the kernel does not take — block checksums,
-// damage, anything unusual — is inflated here with the host reader, which also yields the reference's
-// error for it.  Errors surface in the order a sequential reader meets them: block by block, positions,
-// classifications, colours; a block whose tables cannot be read ends the walk.
+// ---- columns in HBM -----------------------------------------------------------------------------------------
+// (A device-side LZ4 inflater — one wave per frame — was built and measured in round 1: 25 x slower than host
+// threads on real columns, because the lz4 crate writes linked blocks and a frame is one sequential job
+// (profiles/r01_lz4_device_rate.log).  It is not part of the product.)
 struct DeviceColumns {
     pcq_ctx *ctx = nullptr;
-    void *comp = nullptr, *xyz = nullptr, *cls = nullptr, *rgb = nullptr;
+    void *xyz = nullptr, *cls = nullptr, *rgb = nullptr;
     ~DeviceColumns() {
-        for (void *p : {comp, xyz, cls, rgb})
+        for (void *p : {xyz, cls, rgb})
             if (p) pcq_device_free(ctx, p);
     }
 };
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-
-static Status inflate_on_device(const LazerFile &lz, pcq_ctx *ctx, DeviceColumns *dc) {
-    dc->ctx = ctx;
-    const bool timing = getenv("PCQ_TIMING") != nullptr;
-    const double t0 = now_ms();
-    const uint64_t n = lz.header.number_of_points, fsz = lz.file.size(), region = lz.block_offsets[0];
-    std::vector<BlockBlobs> blobs;
-    blobs.reserve(lz.num_blocks);
-    Status walk_end = Status::Ok();
-    for (size_t b = 0; b < lz.num_blocks; b++) {
-        BlockBlobs bl;
-        Status st = lz.locate(b, &bl);
-        if (!st.ok()) {
-            walk_end = st;
-            break;
-        }
-        blobs.push_back(bl);
-    }
-    int r = pcq_device_alloc(ctx, fsz - region, &dc->comp);
-    if (!r) r = pcq_device_alloc(ctx, n * 12, &dc->xyz);
-    if (!r) r = pcq_device_alloc(ctx, n, &dc->cls);
-    if (!r && lz.has_colors) r = pcq_device_alloc(ctx, n * 6, &dc->rgb);
-    const double t1 = now_ms();
-    if (!r) r = pcq_read_fd_to_device(ctx, lz.file.fd(), region, fsz - region, dc->comp);
-    if (r) return Status::FromLib(r);
-    const double t2 = now_ms();
-
-    struct Piece {
-        const Blob *blob;
-        uint64_t need;
-        size_t unit;
-        uint8_t *dst;
-    };
-    std::vector<Piece> pieces;
-    std::vector<pcq_lz4_job> jobs;
-    const uint8_t *region_base = lz.file.data() + region;
-    for (size_t b = 0; b < blobs.size(); b++) {
-        const uint64_t at = (uint64_t)b * lz.block_size, count = lz.points_in_block(b);
-        const Piece three[3] = {{&blobs[b].positions, count * 12, 4, (uint8_t *)dc->xyz + at * 12},      // :598-600 read_i32 x3
-                                {&blobs[b].classifications, count, 1, (uint8_t *)dc->cls + at},           // :665 read_u8
-                                {&blobs[b].colors, count * 6, 2, (uint8_t *)dc->rgb + at * 6}};           // :693-695 read_u16 x3
-        for (int k = 0; k < (lz.has_colors ? 3 : 2); k++) {
-            const Piece &pc = three[k];
-            pcq_lz4_job j{};
-            Lz4FrameInfo fi;
-            if (lz4_frame_descriptor(pc.blob->p, pc.blob->n, &fi).ok()) {
-                j.src = (const uint8_t *)dc->comp + (pc.blob->p - region_base) + fi.payload;
-                j.src_len = pc.blob->n - fi.payload;
-                j.dst = pc.dst;
-                j.need = pc.need;
-                j.content_size = fi.content_size;
-                j.block_size_id = (uint8_t)fi.block_size_id;
-                j.independent_blocks = fi.independent;
-                j.block_checksum = fi.block_checksum;
-                j.has_content_size = fi.has_size;
-            }  // else: src stays null, the library leaves the job alone and the host reader reports the descriptor's fault
-            j.status = 1;
-            pieces.push_back(pc);
-            jobs.push_back(j);
-        }
-    }
-    const double t3 = now_ms();
-    r = pcq_lz4_inflate_dev(ctx, jobs.data(), jobs.size(), nullptr);
-    if (r) return Status::FromLib(r);
-    const double t4 = now_ms();
-    size_t handed_back = 0;
-    for (const auto &j : jobs) handed_back += j.status != 0;
-    if (timing)
-        fprintf(stderr, "[pcq] lazer device inflate: alloc %.1f ms, upload %.1f ms (%.1f MB), jobs %.1f ms, kernel %.1f ms (%zu frames, %zu handed back)\n",
-                t1 - t0, t2 - t1, (double)(fsz - region) / 1e6, t3 - t2, t4 - t3, jobs.size(), handed_back);
-    std::vector<uint8_t> tmp;
-    for (size_t i = 0; i < jobs.size(); i++) {
-        if (jobs[i].status == 0) continue;
-        tmp.resize((size_t)pieces[i].need);
-        Status st = lz4_frame_decode_into(pieces[i].blob->p, pieces[i].blob->n, (size_t)pieces[i].need, pieces[i].unit, tmp.data());
-        if (!st.ok()) return st;
-        r = pcq_copy_to_device(ctx, pieces[i].dst, tmp.data(), pieces[i].need);
-        if (r) return Status::FromLib(r);
-    }
-    return walk_end;
-}
-
-// Where the LZ4 work happens: PCQ_LAZER_INFLATE=device | host.  Default: host threads — measured faster
-// today (profiles/r01_lazer_rate.log); the device inflater is correct but not yet tuned.
-static bool inflate_on_host() {
-    const char *e = getenv("PCQ_LAZER_INFLATE");
-    return !(e && !strcmp(e, "device"));
-}
 
 static void device_columns(const LazerFile &lz, const DeviceColumns &dc, pcq_columns *cols) {
     *cols = pcq_columns{};
@@ -433,9 +343,8 @@ Status search_lazer_file_by_bounds(const std::string &path, const AABB &bounds, 
     pcq_predicate pred{};
     pred.kind = PCQ_PRED_BOUNDS_F64;  // :69
     for (int a = 0; a < 3; a++) pred.wmin[a] = bounds.min[a], pred.wmax[a] = bounds.max[a];
-    pcq_columns cols;
     int r;
-    if (inflate_on_host()) {
+    {
         const double t0 = now_ms();
         double scan_ms = 0;
         const uint64_t first_index = rc.next_index;
@@ -463,15 +372,6 @@ Status search_lazer_file_by_bounds(const std::string &path, const AABB &bounds, 
         if (getenv("PCQ_TIMING"))
             fprintf(stderr, "[pcq] lazer: %zu blocks inflated and scanned in %.1f ms (scans from host columns: %.1f ms of it)\n",
                     (size_t)lz.num_blocks, now_ms() - t0, scan_ms);
-    } else {
-        DeviceColumns dc;
-        st = inflate_on_device(lz, rc.context(), &dc);
-        if (!st.ok()) return st;
-        device_columns(lz, dc, &cols);
-        cols.n = n;
-        cols.first_index = rc.next_index;
-        r = pcq_scan_dev(rc.context(), &cols, &pred, rc.handle(), nullptr);
-        if (!r) r = pcq_ctx_synchronize(rc.context());  // the columns are released when dc goes out of scope
     }
     rc.next_index += n;
     return Status::FromLib(r);
@@ -492,7 +392,7 @@ Status search_lazer_file_by_classification(const std::string &path, uint8_t cls,
 
     pcq_ctx *ctx = rc.context();
     DeviceColumns dc;
-    if (inflate_on_host()) {
+    {
         // every block is inflated by read_into (:101); only block 0 is ever looked at: it goes to the device as soon
         // as it is there, the rest is inflated for the errors it may raise
         dc.ctx = ctx;
@@ -506,9 +406,6 @@ Status search_lazer_file_by_classification(const std::string &path, uint8_t cls,
             if (!r && lz.has_colors) r = pcq_copy_to_device(ctx, dc.rgb, rgb, n0 * 6);
             return Status::FromLib(r);
         });
-        if (!st.ok()) return st;
-    } else {
-        st = inflate_on_device(lz, ctx, &dc);  // all blocks (:101 reads every chunk); block 0 sits at the front
         if (!st.ok()) return st;
     }
     pcq_predicate pred{};

@@ -119,7 +119,9 @@ protected:
 
 class CountCollector : public ResultCollector {  // collect_points.rs:72-98
 public:
-    static Status create(pcq_ctx *ctx, std::unique_ptr<ResultCollector> *out);
+    // device_counter (optional): 8 bytes in the context's HBM that this collector ADDS to instead of owning a
+    // counter — the per-GPU counter all files of that GPU accumulate into (main.rs:164-180 as one all-reduce)
+    static Status create(pcq_ctx *ctx, std::unique_ptr<ResultCollector> *out, uint64_t *device_counter = nullptr);
 };
 class BufferCollector : public ResultCollector {  // collect_points.rs:14-44
 public:
@@ -137,6 +139,22 @@ public:
 struct SearchLog {  // side output the reference prints from inside the scans
     int las_record_size = -1;  // las.rs:73 `println!("Point record size: {}")`
 };
+// What the host knows about one input file before any GPU work — the prologue of the four optimized searches:
+// open + mmap, header parse, block offsets, the header-AABB early-out (last.rs:92-94), the f64 -> local integer box.
+// A query whose files are all resolved here (skipped, empty, or in error) never wakes the GPU.
+struct FilePlan {
+    Status status;               // an error the reference raises before its per-point loop
+    bool needs_gpu = false;      // false: resolved on the host
+    int las_record_size = -1;    // las.rs:73 (printed even for a file that is then skipped)
+    std::unique_ptr<MappedFile> file;
+    pcq_columns cols{};          // column pointers inside the mapping (execute_plan turns them into file offsets)
+    pcq_predicate pred{};
+};
+FilePlan plan_last_file_by_bounds_optimized(const std::string &path, const AABB &bounds);
+FilePlan plan_last_file_by_classification_optimized(const std::string &path, uint8_t cls);
+FilePlan plan_las_file_by_bounds_optimized(const std::string &path, const AABB &bounds);
+FilePlan plan_las_file_by_classification_optimized(const std::string &path, uint8_t cls);
+Status execute_plan(FilePlan &plan, ResultCollector &rc);  // the per-point loop: pcq_scan_fd into the collector
 Status search_last_file_by_bounds_optimized(const std::string &path, const AABB &bounds, ResultCollector &rc);
 Status search_last_file_by_classification_optimized(const std::string &path, uint8_t cls, ResultCollector &rc);
 Status search_las_file_by_bounds_optimized(const std::string &path, const AABB &bounds, ResultCollector &rc, SearchLog *log);
@@ -154,12 +172,15 @@ public:
     virtual ~Searcher() = default;
     virtual Status search_file(const std::string &path, SearchImplementation impl, ResultCollector &collector,
                                SearchLog *log = nullptr) const = 0;
+    // the host-only part of search_file where there is one (nullopt: search_file does everything)
+    virtual std::optional<FilePlan> plan_file(const std::string &path, SearchImplementation impl) const = 0;
 };
 class BoundsSearcher : public Searcher {
 public:
     explicit BoundsSearcher(const AABB &bounds) : bounds_(bounds) {}
     Status search_file(const std::string &path, SearchImplementation impl, ResultCollector &collector,
                        SearchLog *log = nullptr) const override;
+    std::optional<FilePlan> plan_file(const std::string &path, SearchImplementation impl) const override;
 
 private:
     AABB bounds_;
@@ -169,6 +190,7 @@ public:
     explicit ClassSearcher(uint8_t cls) : class_(cls) {}
     Status search_file(const std::string &path, SearchImplementation impl, ResultCollector &collector,
                        SearchLog *log = nullptr) const override;
+    std::optional<FilePlan> plan_file(const std::string &path, SearchImplementation impl) const override;
 
 private:
     uint8_t class_;
@@ -199,12 +221,15 @@ private:
 };
 class FileDumper : public PointDumper {
 public:
-    static Status create(const std::string &root_dir, std::unique_ptr<PointDumper> *out);
+    // `print` receives the "Writing N points" line (dump_points.rs:108); default: stdout
+    static Status create(const std::string &root_dir, std::unique_ptr<PointDumper> *out,
+                         std::function<void(const std::string &)> print = nullptr);
     Status dump_points(const Point *points, size_t n) override;
     size_t num_dumped_points() const override { return dumped_; }
 
 private:
     std::string root_;
+    std::function<void(const std::string &)> print_;
     size_t file_index_ = 0, dumped_ = 0;
 };
 
@@ -215,7 +240,8 @@ Status parse_aabb(const std::string &s, AABB *out);
 Status get_total_bounds(const std::vector<std::string> &files, AABB *out);
 
 // Creates the collector for one worker: Result<Box<dyn ResultCollector>> of main.rs:24.
-using CollectorFactoryFn = std::function<Status(pcq_ctx *, std::unique_ptr<ResultCollector> *)>;
+// `shared_counter` (may be null): the per-GPU device counter a count collector should add to.
+using CollectorFactoryFn = std::function<Status(pcq_ctx *, uint64_t *shared_counter, std::unique_ptr<ResultCollector> *)>;
 
 struct FileStat {  // filled by the drivers when RunOptions::stats is set (extra flag --stats-json)
     std::string path;
@@ -228,6 +254,9 @@ struct RunOptions {
     // the staging copy over its own helper threads and reaches the PCIe rate from a single caller, while a
     // second context on the same GPU costs another ~100-200 ms of HIP start-up (profiles/r01_cli_fixed_cost.log)
     int threads_per_device = 1;
+    // false: the factory makes count collectors (points() is None, main.rs:171-179) — the parallel driver then gives
+    // every GPU one device counter and merges the counters with one all-reduce
+    bool collectors_yield_points = true;
     std::vector<FileStat> *stats = nullptr;
 };
 // stdout lines go through `print` (so tests can capture them).

@@ -110,12 +110,14 @@ Status get_total_bounds(const std::vector<std::string> &files, AABB *out) {
 }
 
 // ---- dump_points.rs ------------------------------------------------------------------------------------------
-Status FileDumper::create(const std::string &root_dir, std::unique_ptr<PointDumper> *out) {  // :45-60
+Status FileDumper::create(const std::string &root_dir, std::unique_ptr<PointDumper> *out,
+                          std::function<void(const std::string &)> print) {  // :45-60
     struct stat st;
     if (stat(root_dir.c_str(), &st) != 0) return Status::Err(PCQ_ERR_IO, "Path " + root_dir + " does not exist!");
     if (!S_ISDIR(st.st_mode)) return Status::Err(PCQ_ERR_IO, "Path " + root_dir + " is no directory!");
     auto d = std::make_unique<FileDumper>();
     d->root_ = root_dir;
+    d->print_ = std::move(print);
     *out = std::move(d);
     return Status::Ok();
 }
@@ -147,8 +149,12 @@ Status FileDumper::dump_points(const Point *points, size_t n) {
     if (scale < 0.001) scale = 0.001;                                                     // :86-88
     if (!(scale >= 0.001)) scale = 0.001;  // NaN (single point: log10(0) = -inf -> 10^-inf = 0 -> clamped)
 
-    printf("Writing %zu points\n", n);  // :108
-    fflush(stdout);
+    if (print_) {  // :108 — through the same channel as the other stdout lines, so their order is the program order
+        print_("Writing " + std::to_string(n) + " points");
+    } else {
+        printf("Writing %zu points\n", n);
+        fflush(stdout);
+    }
     FILE *f = fopen(path.c_str(), "wb");
     if (!f) return Status::Err(PCQ_ERR_IO, path + ": " + strerror(errno));
     uint8_t hdr[227];
@@ -231,7 +237,7 @@ Status run_search_sequential(const std::vector<std::string> &files, const Search
     Status st = thread_context(opt.devices.empty() ? 0 : opt.devices[0], &ctx);
     if (!st.ok()) return st;
     std::unique_ptr<ResultCollector> collector;
-    st = factory(ctx, &collector);  // :129
+    st = factory(ctx, nullptr, &collector);  // :129
     if (!st.ok()) return st;
     for (const auto &f : files) {  // :131-133
         SearchLog log;
@@ -254,19 +260,48 @@ Status run_search_sequential(const std::vector<std::string> &files, const Search
 // host threads pulling file indices from a shared queue, `threads_per_device` per GPU; each thread
 // owns a GPU context (stream + pinned staging), so host staging copies of one file overlap the
 // kernels of another.  Results are merged in input-file order (rayon's collect preserves order).
+//
+// Host first: every rayon task of the reference starts with the same host-only prologue (open, header,
+// block offsets, the header-AABB early-out of last.rs:92-94, the box conversion).  That prologue runs here
+// for ALL files before any GPU context exists; a file it resolves (skipped, empty, in error) never reaches a
+// worker, and a query it resolves completely never wakes the GPU (HIP start-up is 0.13-0.3 s,
+// profiles/r01_hip_init_probe.log).
+//
+// Count queries: every GPU owns ONE device counter; all files of that GPU add to it (the kernels' finishing
+// step is an atomic add), and the global count is the all-reduce of the per-GPU counters — main.rs:164-180
+// as a single RCCL all-reduce(sum, u64) — read back once.  With one GPU the all-reduce is the identity.
 Status run_search_parallel(const std::vector<std::string> &files, const Searcher &searcher, SearchImplementation impl,
                            const CollectorFactoryFn &factory, PointDumper &dumper, const RunOptions &opt, const PrintFn &print) {
     const size_t nfiles = files.size();
-    std::vector<std::unique_ptr<ResultCollector>> collectors(nfiles);
+    std::vector<std::optional<FilePlan>> plans(nfiles);
     std::vector<Status> results(nfiles);
     std::vector<SearchLog> logs(nfiles);
-    std::vector<int> file_device(nfiles, 0);
+    std::vector<size_t> work;  // files that need a GPU
+    for (size_t i = 0; i < nfiles; i++) {
+        plans[i] = searcher.plan_file(files[i], impl);
+        if (plans[i]) {
+            logs[i].las_record_size = plans[i]->las_record_size;
+            results[i] = plans[i]->status;
+            if (plans[i]->status.ok() && plans[i]->needs_gpu) work.push_back(i);
+        } else {
+            work.push_back(i);  // no host-only prologue for this format: search_file does everything
+        }
+    }
+    if (getenv("PCQ_TIMING")) fprintf(stderr, "[pcq] %zu of %zu files need the GPU\n", work.size(), nfiles);
+
+    std::vector<std::unique_ptr<ResultCollector>> collectors(nfiles);
+    std::vector<int> file_device(nfiles, -1);
     std::vector<double> file_ms(nfiles, 0.0);
     std::atomic<size_t> next{0};
     std::vector<int> devices = opt.devices.empty() ? std::vector<int>{0} : opt.devices;
     const int tpd = opt.threads_per_device < 1 ? 1 : opt.threads_per_device;
     size_t nthreads = devices.size() * (size_t)tpd;
-    if (nthreads > nfiles) nthreads = nfiles;  // README.md:12
+    if (nthreads > work.size()) nthreads = work.size();  // README.md:12
+    const bool counting = !opt.collectors_yield_points;
+    // per-GPU device counters (count queries): owned by the first worker of the device
+    std::vector<uint64_t *> dev_counter(devices.size(), nullptr);
+    std::vector<pcq_ctx *> dev_ctx(devices.size(), nullptr);
+    std::vector<Status> dev_status(devices.size());
     // Collectors hold device memory owned by the worker's context; workers therefore stay alive
     // until the results have been drained.
     std::mutex mu;
@@ -275,30 +310,49 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
     size_t finished = 0;
     std::vector<std::thread> pool;
     for (size_t t = 0; t < nthreads; t++) {
-        const int device = devices[t % devices.size()];
-        pool.emplace_back([&, device]() {
+        const size_t dslot = t % devices.size();
+        const int device = devices[dslot];
+        pool.emplace_back([&, device, dslot]() {
             pcq_ctx *ctx = nullptr;
             const auto t_a = std::chrono::steady_clock::now();
             Status cst = thread_context(device, &ctx);
             if (getenv("PCQ_TIMING"))
                 fprintf(stderr, "[pcq] context on device %d ready after %.1f ms\n", device,
                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count());
+            uint64_t *counter = nullptr;
+            if (cst.ok() && counting) {
+                std::lock_guard<std::mutex> g(mu);
+                if (!dev_counter[dslot]) {
+                    void *p = nullptr;
+                    Status st = Status::FromLib(pcq_device_alloc(ctx, 16, &p));
+                    if (st.ok()) st = Status::FromLib(pcq_device_memset(ctx, p, 0, 16, nullptr));
+                    if (st.ok()) st = Status::FromLib(pcq_ctx_synchronize(ctx));
+                    if (st.ok()) dev_counter[dslot] = (uint64_t *)p, dev_ctx[dslot] = ctx;
+                    else cst = st;
+                }
+                counter = dev_counter[dslot];
+            }
             for (;;) {
-                const size_t i = next.fetch_add(1);
-                if (i >= nfiles) break;
+                const size_t w = next.fetch_add(1);
+                if (w >= work.size()) break;
+                const size_t i = work[w];
                 if (!cst.ok()) {
                     results[i] = cst;
                     continue;
                 }
                 file_device[i] = device;
                 const auto t_f = std::chrono::steady_clock::now();
-                Status st = factory(ctx, &collectors[i]);  // :156
-                if (st.ok()) st = searcher.search_file(files[i], impl, *collectors[i], &logs[i]);  // :158
+                Status st = factory(ctx, counter, &collectors[i]);  // :156
+                if (st.ok()) st = plans[i] ? execute_plan(*plans[i], *collectors[i]) : searcher.search_file(files[i], impl, *collectors[i], &logs[i]);  // :158
+                plans[i].reset();  // unmaps the file
                 results[i] = st;
                 file_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f).count();
-                if (getenv("PCQ_TIMING"))
-                    fprintf(stderr, "[pcq] file %zu searched in %.1f ms\n", i,
-                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f).count());
+                if (getenv("PCQ_TIMING")) fprintf(stderr, "[pcq] file %zu searched in %.1f ms\n", i, file_ms[i]);
+            }
+            if (cst.ok()) {  // everything this worker enqueued has run before the counters are merged
+                const Status sst = Status::FromLib(pcq_ctx_synchronize(ctx));
+                std::lock_guard<std::mutex> g(mu);
+                if (!sst.ok() && dev_status[dslot].ok()) dev_status[dslot] = sst;
             }
             std::unique_lock<std::mutex> lk(mu);
             finished++;
@@ -307,6 +361,7 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
             // collectors created on this thread's context must be destroyed before the context
             for (size_t i = 0; i < nfiles; i++)
                 if (collectors[i] && collectors[i]->context() == ctx) collectors[i].reset();
+            if (counter && dev_ctx[dslot] == ctx) pcq_device_free(ctx, counter);
         });
     }
     {
@@ -318,37 +373,37 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         if (logs[i].las_record_size >= 0) print("Point record size: " + std::to_string(logs[i].las_record_size));
     for (size_t i = 0; i < nfiles && final_status.ok(); i++)
         if (!results[i].ok()) final_status = results[i];  // :161-163 first Err aborts
+    for (size_t d = 0; d < devices.size() && final_status.ok(); d++)
+        if (!dev_status[d].ok()) final_status = dev_status[d];
     std::optional<size_t> matches;
-    if (final_status.ok()) {
-        std::vector<uint64_t> partial(devices.size(), 0);  // per-GPU partial match counts
-        for (size_t i = 0; i < nfiles && final_status.ok(); i++) {  // :165-176, input-file order
-            std::optional<size_t> one;
-            final_status = drain(*collectors[i], dumper, &one);
-            if (one) {
-                matches = matches.value_or(0) + *one;
-                for (size_t d = 0; d < devices.size(); d++)
-                    if (devices[d] == file_device[i]) partial[d] += *one;
+    if (final_status.ok() && counting) {
+        // :164-180 — the sum over the collectors is the sum over the per-GPU counters: one all-reduce
+        uint64_t total = 0;
+        std::vector<pcq_ctx *> ctxs;
+        std::vector<uint64_t *> counters;
+        for (size_t d = 0; d < devices.size(); d++)
+            if (dev_counter[d]) ctxs.push_back(dev_ctx[d]), counters.push_back(dev_counter[d]);
+        if (!ctxs.empty()) {
+            Status ast = Status::FromLib(pcq_allreduce_sum_u64(ctxs.data(), counters.data(), (int)ctxs.size()));
+            if (ast.ok()) {
+                final_status = Status::FromLib(pcq_copy_to_host(ctxs[0], &total, counters[0], 8));
+            } else {
+                // RCCL missing or unusable must not turn a correct answer into an error: the per-GPU counters are
+                // exact, so they are read one by one and summed here
+                fprintf(stderr, "warning: all-reduce of the per-GPU counts failed (%s); summing on the host\n", ast.message.c_str());
+                for (size_t k = 0; k < ctxs.size() && final_status.ok(); k++) {
+                    uint64_t part = 0;
+                    final_status = Status::FromLib(pcq_copy_to_host(ctxs[k], &part, counters[k], 8));
+                    total += part;
+                }
             }
         }
-        // With several GPUs the global count is the all-reduce of the per-GPU partial counts
-        // (main.rs:171-179 across devices): one RCCL all-reduce(sum, u64) over xGMI.
-        if (final_status.ok() && matches && devices.size() > 1) {
-            std::vector<pcq_ctx *> ctxs(devices.size(), nullptr);
-            std::vector<uint64_t *> counters(devices.size(), nullptr);
-            for (size_t d = 0; d < devices.size() && final_status.ok(); d++) {
-                final_status = thread_context(devices[d], &ctxs[d]);
-                void *p = nullptr;
-                if (final_status.ok()) final_status = Status::FromLib(pcq_device_alloc(ctxs[d], 16, &p));
-                counters[d] = (uint64_t *)p;
-                if (final_status.ok()) final_status = Status::FromLib(pcq_copy_to_device(ctxs[d], p, &partial[d], 8));
-            }
-            if (final_status.ok())
-                final_status = Status::FromLib(pcq_allreduce_sum_u64(ctxs.data(), counters.data(), (int)devices.size()));
-            uint64_t total = 0;
-            if (final_status.ok()) final_status = Status::FromLib(pcq_copy_to_host(ctxs[0], &total, counters[0], 8));
-            for (size_t d = 0; d < devices.size(); d++)
-                if (counters[d]) pcq_device_free(ctxs[d], counters[d]);
-            if (final_status.ok()) matches = (size_t)total;
+        if (nfiles) matches = (size_t)total;  // no collector at all: num_matches stays None (main.rs:164)
+    } else if (final_status.ok()) {
+        for (size_t i = 0; i < nfiles && final_status.ok(); i++) {  // :165-176, input-file order
+            if (!collectors[i]) continue;  // resolved on the host: an empty collector, nothing to dump
+            std::optional<size_t> none;
+            final_status = drain(*collectors[i], dumper, &none);
         }
     }
     {
@@ -372,6 +427,7 @@ int query_main(int argc, const char *const *argv, const PrintFn &out, const Prin
     bool parallel = false, optimized = false;
     RunOptions opt;
     opt.devices = {0};
+    opt.collectors_yield_points = true;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         std::optional<std::string> *dst = nullptr;
@@ -505,16 +561,17 @@ int query_main(int argc, const char *const *argv, const PrintFn &out, const Prin
             }
         }
         const double cell = *maybe_density;
-        factory = [gb, cell](pcq_ctx *ctx, std::unique_ptr<ResultCollector> *o) { return GridSampledCollector::create(ctx, gb, cell, o); };
+        factory = [gb, cell](pcq_ctx *ctx, uint64_t *, std::unique_ptr<ResultCollector> *o) { return GridSampledCollector::create(ctx, gb, cell, o); };
     } else if (output) {
-        factory = [](pcq_ctx *ctx, std::unique_ptr<ResultCollector> *o) { return BufferCollector::create(ctx, o); };
+        factory = [](pcq_ctx *ctx, uint64_t *, std::unique_ptr<ResultCollector> *o) { return BufferCollector::create(ctx, o); };
     } else {
-        factory = [](pcq_ctx *ctx, std::unique_ptr<ResultCollector> *o) { return CountCollector::create(ctx, o); };
+        factory = [](pcq_ctx *ctx, uint64_t *shared, std::unique_ptr<ResultCollector> *o) { return CountCollector::create(ctx, o, shared); };
+        opt.collectors_yield_points = false;
     }
 
     std::unique_ptr<PointDumper> dumper;  // :275-281
     if (output) {
-        st = FileDumper::create(*output, &dumper);
+        st = FileDumper::create(*output, &dumper, out);
         if (!st.ok()) {
             err("Error: " + st.message);
             return 1;

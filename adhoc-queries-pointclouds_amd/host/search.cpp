@@ -36,10 +36,10 @@ Status ResultCollector::fetch() {
     return Status::Ok();
 }
 
-Status CountCollector::create(pcq_ctx *ctx, std::unique_ptr<ResultCollector> *out) {
+Status CountCollector::create(pcq_ctx *ctx, std::unique_ptr<ResultCollector> *out, uint64_t *device_counter) {
     auto c = std::make_unique<CountCollector>();
     c->ctx_ = ctx;
-    const int rc = pcq_collector_new_count(ctx, &c->handle_);
+    const int rc = device_counter ? pcq_collector_new_count_at(ctx, device_counter, &c->handle_) : pcq_collector_new_count(ctx, &c->handle_);
     if (rc) return Status::FromLib(rc);
     *out = std::move(c);
     return Status::Ok();
@@ -96,11 +96,16 @@ Status eof() { return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer"); }
 // validated up front ("deviations").
 bool block_ok(const MappedFile &f, uint64_t off, uint64_t bytes) { return off <= f.size() && bytes <= f.size() - off; }
 
+}  // namespace
+
 // The column blocks were located in the mapped file (header parse, offsets: exactly as the reference
 // does); the bytes themselves are streamed by the library with pread from the same file, so `cols`
 // carries file offsets instead of addresses inside the mapping.
-Status run_scan(const MappedFile &file, ResultCollector &rc, pcq_columns &cols, const pcq_predicate &pred) {
+Status execute_plan(FilePlan &plan, ResultCollector &rc) {
+    if (!plan.status.ok() || !plan.needs_gpu) return plan.status;
+    pcq_columns cols = plan.cols;
     cols.first_index = rc.next_index;
+    const MappedFile &file = *plan.file;
     auto to_offset = [&](const void *p) -> const void * {
         return p ? (const void *)(uintptr_t)((const uint8_t *)p - file.data()) : nullptr;
     };
@@ -108,42 +113,50 @@ Status run_scan(const MappedFile &file, ResultCollector &rc, pcq_columns &cols, 
     cols.xyz = to_offset(cols.xyz);
     cols.cls = to_offset(cols.cls);
     cols.rgb = to_offset(cols.rgb);
-    const int r = pcq_scan_fd(rc.context(), file.fd(), &cols, &pred, rc.handle());
+    const int r = pcq_scan_fd(rc.context(), file.fd(), &cols, &plan.pred, rc.handle());
     rc.next_index += cols.n;
     return Status::FromLib(r);
 }
 
+namespace {
+// plan helpers: `done` = resolved on the host (no GPU work), `gpu` = the scan is ready to be issued
+FilePlan done(Status st = Status::Ok()) {
+    FilePlan p;
+    p.status = std::move(st);
+    return p;
+}
 }  // namespace
 
 // ---- last.rs:46-166 -------------------------------------------------------------------------------------
-Status search_last_file_by_bounds_optimized(const std::string &path, const AABB &bounds, ResultCollector &rc) {
-    MappedFile file;
+FilePlan plan_last_file_by_bounds_optimized(const std::string &path, const AABB &bounds) {
+    auto holder = std::make_unique<MappedFile>();
+    MappedFile &file = *holder;
     Status st = file.open(path);  // :51
-    if (!st.ok()) return st;
+    if (!st.ok()) return done(st);
     LasHeader h;
     st = parse_las_header(file.data(), file.size(), /*mask_format=*/false, &h);  // :53-54
-    if (!st.ok()) return st;
+    if (!st.ok()) return done(st);
     const uint8_t fmt = h.point_data_record_format;  // :68
     uint64_t cls_in_point;
     if (fmt <= 5) cls_in_point = 15;  // :69-79
     else if (fmt <= 10) cls_in_point = 16;
-    else return invalid_format(fmt, path);
+    else return done(invalid_format(fmt, path));
     const uint64_t n = h.number_of_points;
     const uint64_t otp = h.offset_to_point_data;
     const uint64_t cls_block = otp + n * cls_in_point;  // :80-81
     const auto col_in_point = las_offset_to_color(fmt);  // :83-88
     const std::optional<uint64_t> col_block = col_in_point ? std::optional<uint64_t>(otp + n * *col_in_point) : std::nullopt;  // :89-90
 
-    if (!h.bounds.intersects(bounds)) return Status::Ok();  // :92-94
+    if (!h.bounds.intersects(bounds)) return done();  // :92-94: resolved from the header alone
 
     pcq_predicate pred{};
     pred.kind = PCQ_PRED_BOUNDS;
     const int brc = pcq_box_to_local(bounds.min, bounds.max, h.scale, h.offset, pred.lmin, pred.lmax);  // :98-109
-    if (brc) return Status::FromLib(brc);
-    if (n == 0) return Status::Ok();
+    if (brc) return done(Status::FromLib(brc));
+    if (n == 0) return done();
 
     if (!block_ok(file, otp, n * 12) || !block_ok(file, cls_block, n) || (col_block && !block_ok(file, *col_block, n * 6)))
-        return eof();
+        return done(eof());
     pcq_columns cols{};
     cols.xyz = file.data() + otp;  // :114-121
     cols.xyz_stride = 12;
@@ -153,31 +166,41 @@ Status search_last_file_by_bounds_optimized(const std::string &path, const AABB 
     cols.rgb_stride = 6;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :156-160
-    return run_scan(file, rc, cols, pred);
+    FilePlan plan;
+    plan.needs_gpu = true;
+    plan.file = std::move(holder);
+    plan.cols = cols;
+    plan.pred = pred;
+    return plan;
+}
+Status search_last_file_by_bounds_optimized(const std::string &path, const AABB &bounds, ResultCollector &rc) {
+    FilePlan plan = plan_last_file_by_bounds_optimized(path, bounds);
+    return execute_plan(plan, rc);
 }
 
 // ---- last.rs:213-293 -------------------------------------------------------------------------------------
-Status search_last_file_by_classification_optimized(const std::string &path, uint8_t cls, ResultCollector &rc) {
-    MappedFile file;
+FilePlan plan_last_file_by_classification_optimized(const std::string &path, uint8_t cls) {
+    auto holder = std::make_unique<MappedFile>();
+    MappedFile &file = *holder;
     Status st = file.open(path);  // :218
-    if (!st.ok()) return st;
+    if (!st.ok()) return done(st);
     LasHeader h;
     st = parse_las_header(file.data(), file.size(), /*mask_format=*/true, &h);  // :220-223
-    if (!st.ok()) return st;
+    if (!st.ok()) return done(st);
     const uint8_t fmt = h.point_data_record_format;  // :225
     uint64_t cls_in_point;
     if (fmt <= 5) cls_in_point = 15;  // :226-236
     else if (fmt <= 10) cls_in_point = 16;
-    else return invalid_format(fmt, path);
+    else return done(invalid_format(fmt, path));
     const auto col_in_point = las_offset_to_color(fmt);  // :238-243
     const uint64_t n = h.number_of_points;
     const uint64_t otp = h.offset_to_point_data;
     const uint64_t cls_block = cls_in_point * n + otp;  // :245-246, :254-256
     const std::optional<uint64_t> col_block = col_in_point ? std::optional<uint64_t>(otp + n * *col_in_point) : std::nullopt;  // :249-250
-    if (n == 0) return Status::Ok();
+    if (n == 0) return done();
 
     if (!block_ok(file, cls_block, n) || !block_ok(file, otp, n * 12) || (col_block && !block_ok(file, *col_block, n * 6)))
-        return eof();
+        return done(eof());
     pcq_predicate pred{};
     pred.kind = PCQ_PRED_CLASS;
     pred.cls = cls;  // :259-262 whole byte
@@ -190,31 +213,45 @@ Status search_last_file_by_classification_optimized(const std::string &path, uin
     cols.rgb_stride = 6;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :283-287
-    return run_scan(file, rc, cols, pred);
+    FilePlan plan;
+    plan.needs_gpu = true;
+    plan.file = std::move(holder);
+    plan.cols = cols;
+    plan.pred = pred;
+    return plan;
+}
+Status search_last_file_by_classification_optimized(const std::string &path, uint8_t cls, ResultCollector &rc) {
+    FilePlan plan = plan_last_file_by_classification_optimized(path, cls);
+    return execute_plan(plan, rc);
 }
 
 // ---- las.rs:52-148 ---------------------------------------------------------------------------------------
-Status search_las_file_by_bounds_optimized(const std::string &path, const AABB &bounds, ResultCollector &rc, SearchLog *log) {
-    MappedFile file;
+FilePlan plan_las_file_by_bounds_optimized(const std::string &path, const AABB &bounds) {
+    auto holder = std::make_unique<MappedFile>();
+    MappedFile &file = *holder;
     Status st = file.open(path);  // :57
-    if (!st.ok()) return st;
+    if (!st.ok()) return done(st);
     LasHeader h;
     st = parse_las_header(file.data(), file.size(), /*mask_format=*/false, &h);  // :59-60
-    if (!st.ok()) return st;
-    if (log) log->las_record_size = h.point_data_record_length;  // :73
+    if (!st.ok()) return done(st);
+    const int rec = h.point_data_record_length;  // :73 — printed before the early-out below
+    auto with_rec = [rec](FilePlan p) {
+        p.las_record_size = rec;
+        return p;
+    };
     const auto color_offset = las_offset_to_color(h.point_data_record_format);  // :74-80
 
-    if (!h.bounds.intersects(bounds)) return Status::Ok();  // :82-84
+    if (!h.bounds.intersects(bounds)) return with_rec(done());  // :82-84: resolved from the header alone
 
     pcq_predicate pred{};
     pred.kind = PCQ_PRED_BOUNDS;
     const int brc = pcq_box_to_local(bounds.min, bounds.max, h.scale, h.offset, pred.lmin, pred.lmax);  // :88-99
-    if (brc) return Status::FromLib(brc);
+    if (brc) return with_rec(done(Status::FromLib(brc)));
     const uint64_t n = h.number_of_points, rl = h.point_data_record_length, otp = h.offset_to_point_data;
-    if (n == 0) return Status::Ok();
+    if (n == 0) return with_rec(done());
     // every record up to its last needed byte: XYZ +0..12, class +15, colour +off..off+6
     const uint64_t last_needed = color_offset ? *color_offset + 6 : 16;
-    if (!block_ok(file, otp, (n - 1) * rl + last_needed)) return eof();
+    if (!block_ok(file, otp, (n - 1) * rl + last_needed)) return with_rec(done(eof()));
     pcq_columns cols{};
     cols.xyz = file.data() + otp;  // :102-104
     cols.cls = file.data() + otp + 15;  // :121-124 — seek(Current(3)): always +15 on this path
@@ -222,27 +259,39 @@ Status search_las_file_by_bounds_optimized(const std::string &path, const AABB &
     cols.xyz_stride = cols.cls_stride = cols.rgb_stride = rl;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :138-142
-    return run_scan(file, rc, cols, pred);
+    FilePlan plan;
+    plan.needs_gpu = true;
+    plan.file = std::move(holder);
+    plan.cols = cols;
+    plan.pred = pred;
+    plan.las_record_size = rec;
+    return plan;
+}
+Status search_las_file_by_bounds_optimized(const std::string &path, const AABB &bounds, ResultCollector &rc, SearchLog *log) {
+    FilePlan plan = plan_las_file_by_bounds_optimized(path, bounds);
+    if (log) log->las_record_size = plan.las_record_size;
+    return execute_plan(plan, rc);
 }
 
 // ---- las.rs:192-261 --------------------------------------------------------------------------------------
-Status search_las_file_by_classification_optimized(const std::string &path, uint8_t cls, ResultCollector &rc) {
-    MappedFile file;
+FilePlan plan_las_file_by_classification_optimized(const std::string &path, uint8_t cls) {
+    auto holder = std::make_unique<MappedFile>();
+    MappedFile &file = *holder;
     Status st = file.open(path);  // :197
-    if (!st.ok()) return st;
+    if (!st.ok()) return done(st);
     LasHeader h;
     st = parse_las_header(file.data(), file.size(), /*mask_format=*/false, &h);  // :199-200
-    if (!st.ok()) return st;
+    if (!st.ok()) return done(st);
     const uint8_t fmt = h.point_data_record_format;  // raw, unmasked (:202)
     uint64_t cls_in_point;
     if (fmt <= 5) cls_in_point = 15;
     else if (fmt <= 10) cls_in_point = 16;
-    else return invalid_format(fmt, path);
+    else return done(invalid_format(fmt, path));
     const auto color_offset = las_offset_to_color(fmt);  // :214-219
     const uint64_t n = h.number_of_points, rl = h.point_data_record_length, otp = h.offset_to_point_data;
-    if (n == 0) return Status::Ok();
+    if (n == 0) return done();
     const uint64_t last_needed = color_offset ? *color_offset + 6 : cls_in_point + 1;
-    if (!block_ok(file, otp, (n - 1) * rl + last_needed)) return eof();
+    if (!block_ok(file, otp, (n - 1) * rl + last_needed)) return done(eof());
     pcq_predicate pred{};
     pred.kind = PCQ_PRED_CLASS;
     pred.cls = cls;
@@ -253,7 +302,16 @@ Status search_las_file_by_classification_optimized(const std::string &path, uint
     cols.xyz_stride = cols.cls_stride = cols.rgb_stride = rl;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :251-255
-    return run_scan(file, rc, cols, pred);
+    FilePlan plan;
+    plan.needs_gpu = true;
+    plan.file = std::move(holder);
+    plan.cols = cols;
+    plan.pred = pred;
+    return plan;
+}
+Status search_las_file_by_classification_optimized(const std::string &path, uint8_t cls, ResultCollector &rc) {
+    FilePlan plan = plan_las_file_by_classification_optimized(path, cls);
+    return execute_plan(plan, rc);
 }
 
 // ---- searcher.rs ---------------------------------------------------------------------------------------------
@@ -269,6 +327,23 @@ Status out_of_scope(const std::string &what, const std::string &path) {
     return Status::Err(PCQ_ERR_UNSUPPORTED, what + " is outside the MI355X hot path (SURVEY.md §2): " + path);
 }
 }  // namespace
+
+// The host-only prologue of search_file for the formats whose prologue needs no GPU (LAS / LAST --optimized): everything
+// the reference does before its per-point loop.  Other formats (and errors of the dispatch itself) are left to search_file.
+std::optional<FilePlan> BoundsSearcher::plan_file(const std::string &path, SearchImplementation impl) const {
+    const auto ext = extension_of(path);
+    if (!ext || impl != SearchImplementation::Optimized) return std::nullopt;
+    if (*ext == "las") return plan_las_file_by_bounds_optimized(path, bounds_);
+    if (*ext == "last") return plan_last_file_by_bounds_optimized(path, bounds_);
+    return std::nullopt;
+}
+std::optional<FilePlan> ClassSearcher::plan_file(const std::string &path, SearchImplementation impl) const {
+    const auto ext = extension_of(path);
+    if (!ext || impl != SearchImplementation::Optimized) return std::nullopt;
+    if (*ext == "las") return plan_las_file_by_classification_optimized(path, class_);
+    if (*ext == "last") return plan_last_file_by_classification_optimized(path, class_);
+    return std::nullopt;
+}
 
 Status BoundsSearcher::search_file(const std::string &path, SearchImplementation impl, ResultCollector &collector,
                                    SearchLog *log) const {  // searcher.rs:43-90

@@ -236,13 +236,7 @@ def main():
     alg_bytes = BYTES_PER_POINT * (sum(launch_pts) / max(1, len(launch_pts)))
     achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
 
-    k1v, bv = ctx.get_option("k1_variant"), ctx.get_option("batch_variant")
-    if args.per_file_launch:
-        kernel_name = (f"k_bounds_count_w1_pipe<{ {12: 2, 13: 1, 14: 3}[k1v] }>" if k1v >= 12 else
-                       f"k_bounds_count_w1<{k1v - 7}>" if k1v >= 8 else f"k_bounds_count_xyz12<{k1v}>")
-    else:
-        kernel_name = {0: "k_bounds_count_batch", 1: "k_bounds_count_batch_w1<2>", 2: "k_bounds_count_batch_w1<3>",
-                       3: "k_bounds_count_batch_pipe<2>"}[bv]
+    kernel_name = "k_bounds_count_w1_pipe<2>" if args.per_file_launch else "k_bounds_count_batch_pipe<2>"
     result = None
     if rank == 0:
         traffic = None

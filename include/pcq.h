@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PCQ_ABI_VERSION 2
+#define PCQ_ABI_VERSION 3
 
 typedef enum pcq_status {
     PCQ_OK = 0,
@@ -222,7 +222,9 @@ int pcq_scan_dev_indexed(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predic
 /* The one collective of the path (main.rs:164-180) for callers that drive n GPUs from ONE process:
  * device_counters[i] (8 bytes in ctxs[i]'s HBM, e.g. of pcq_collector_new_count_at) all become the sum
  * over i — a single RCCL all-reduce(sum, u64, count = 1) over an intra-node communicator (xGMI).
- * Synchronous.  n == 1 is a no-op.  RCCL is bound at run time; failure to find it is an error. */
+ * Synchronous.  One rank per GPU (two entries on one device are refused).  n == 1 is a no-op unless option
+ * "allreduce_single_rank" is set on ctxs[0] (then the one-rank communicator and the all-reduce really run).
+ * RCCL is bound at run time; failure to find it is an error. */
 int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, uint64_t *const *device_counters, int n);
 
 /* Device memory helpers for callers that keep column blocks resident in HBM. */
@@ -232,43 +234,18 @@ int pcq_copy_to_device(pcq_ctx *ctx, void *dst_device, const void *src_host, uin
 int pcq_copy_to_host(pcq_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
 int pcq_device_memset(pcq_ctx *ctx, void *dst_device, int value, uint64_t bytes, void *stream);
 
-/* ---- LAZER support (query/src/search/lazer.rs over readers/src/lazer_reader.rs) ----
- * The column blobs of a LAZER file are LZ4 frames.  The host layer parses each frame descriptor and hands
- * the block sequence behind it to the device, one job per blob; the kernel inflates the first `need`
- * bytes into `dst` exactly as the reference's streaming reader (lz4::Decoder over LZ4F_decompress,
- * lazer_reader.rs:590-716) would produce them.  status = 0: done.  status = 1: not handled on the device
- * (block checksums, damage, a frame that ends early, ...) — the caller inflates that blob with its own
- * reader, which also decides which error the reference would raise.  Synchronous. */
-typedef struct pcq_lz4_job {
-    const void *src;            /* device: first block header of the frame (behind the frame descriptor) */
-    uint64_t src_len;           /* bytes from src to the end of the blob */
-    void *dst;                  /* device: receives the first `need` inflated bytes */
-    uint64_t need;
-    uint64_t content_size;      /* frame descriptor: content size, if present */
-    uint8_t block_size_id;      /* frame descriptor BD: 4..7 = 64 KiB, 256 KiB, 1 MiB, 4 MiB */
-    uint8_t independent_blocks; /* FLG bit 5 */
-    uint8_t block_checksum;     /* FLG bit 4 (such frames are left to the caller) */
-    uint8_t has_content_size;   /* FLG bit 3 */
-    int32_t status;             /* out */
-} pcq_lz4_job;
-int pcq_lz4_inflate_dev(pcq_ctx *ctx, pcq_lz4_job *jobs, size_t njobs, void *stream);
-/* Reads [file_offset, file_offset + bytes) of an open file into device memory at the rate of the host
- * block path (pinned double buffering, parallel pread).  Synchronous. */
-int pcq_read_fd_to_device(pcq_ctx *ctx, int fd, uint64_t file_offset, uint64_t bytes, void *d_dst);
-
 /* Restricts the CALLING thread to the CPUs of the NUMA node the context's GPU is attached to (no-op when the
  * node is unknown or option "numa_local" is 0).  For caller threads that produce the bytes a scan will read —
  * memory they touch first then sits next to the GPU's staging buffers. */
 int pcq_bind_thread_near_device(pcq_ctx *ctx);
 
-/* Tuning knobs: "k1_variant" (bounds-count kernel variant 0..14), "k1_waves_per_cu", "batch_variant" (0..3),
- * "batch_waves_per_cu", "blocks_per_cu" (the 256-thread kernels), "chunk_points" (points per staging chunk of
- * the host paths), "copy_threads" (threads filling a staging chunk, default 8), "class_batch_loads" /
- * "class_batch_waves_per_cu" / "class_batch_pipe" (class-count kernels), "numa_local", "grid_pending_budget"
- * (matches a grid collector may hold before it folds them; 0 = default), "grid_f2" (tests: the second-level fan-out a
- * fold starts from; 0 = from the measured estimate).  pcq_get_option also reads "numa_node" and the grid diagnostics
- * "grid_folds", "grid_level2" (folds that needed a second partition level), "grid_refolds" (folds repeated with more
- * partitions), "grid_last_f2". */
+/* Options: "blocks_per_cu" (persistent blocks per CU of the strided count kernels), "chunk_points" (points per staging
+ * chunk of the host paths), "copy_threads" (threads filling a staging chunk, default 8), "numa_local",
+ * "allreduce_single_rank", "grid_pending_budget" (matches a grid collector may hold before it folds them; 0 = default),
+ * "grid_f2" (tests: the second-level fan-out a fold starts from; 0 = from the measured estimate).  pcq_get_option also
+ * reads "numa_node" and the grid diagnostics "grid_folds", "grid_level2" (folds that needed a second partition level),
+ * "grid_refolds" (folds repeated with more partitions), "grid_last_f2".  (The kernel-shape experiments of round 1 —
+ * "k1_variant", "batch_variant", ... — are options of libpcq_lab.so only: include/pcq_lab.h.) */
 int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value);
 int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value);
 

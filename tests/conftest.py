@@ -18,14 +18,6 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box)")
-    # PyTorch ships its own HIP runtime.  When both are wanted in one process (as in bench.py, which
-    # imports torch first), torch's runtime must be the one that initialises the device: a second
-    # runtime loaded after libpcq.so's reports "no ROCm-capable device".  Harmless without a GPU.
-    try:
-        import torch
-        torch.cuda.is_available()
-    except Exception:
-        pass
 
 
 def _build_oracle():

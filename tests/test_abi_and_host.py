@@ -38,7 +38,7 @@ def test_libpcq_exports_every_declared_symbol():
     exported = pkg.exported_symbols(pkg.lib_path())
     assert [s for s in declared if s not in exported] == []
     lib = pkg.load_library()  # dlopen resolves libamdhip64 etc.
-    assert lib.pcq_abi_version() == 2
+    assert lib.pcq_abi_version() == 3
 
 
 def test_libpcq_query_exports_every_declared_symbol():
@@ -49,6 +49,22 @@ def test_libpcq_query_exports_every_declared_symbol():
     exported = pkg.exported_symbols(path)
     assert [s for s in declared if s not in exported] == []
     C.CDLL(path)
+
+
+def test_product_library_ships_no_lab_code():
+    """libpcq.so = the shipped kernels; the superseded kernel shapes, the HBM read microbenchmarks and the device LZ4
+    inflater measured in round 1 are not in it (csrc/lab/ -> libpcq_lab.so, loaded only by tools/ with PCQ_LAB=1)."""
+    syms = subprocess.run(["nm", "-D", "--defined-only", pkg.lib_path()], capture_output=True, text=True).stdout
+    assert "pcq_scan_dev" in syms
+    for name in ("membench", "lz4_inflate", "pcq_read_fd_to_device"):
+        assert name not in syms, name
+    all_syms = subprocess.run(["nm", "-C", pkg.lib_path()], capture_output=True, text=True).stdout
+    for kernel in ("k_bounds_count_xyz12", "k_bounds_count_w1<", "k_bounds_count_batch_w1", "k_class_count_batch_w1", "k_class_count_u8"):
+        assert kernel not in all_syms, kernel
+    for kernel in ("k_bounds_count_w1_pipe<2>", "k_bounds_count_batch_pipe<2>", "k_class_count_pipe<4>", "k_class_count_batch_pipe<4>"):
+        assert kernel in all_syms, kernel
+    ctx_opts = open(os.path.join(ROOT, "include", "pcq.h")).read()
+    assert '"k1_variant" (bounds-count kernel variant' not in ctx_opts
 
 
 def test_no_oracle_in_the_product_binaries():

@@ -39,15 +39,11 @@ class Resident:
             self.ctx.free(self.cls)
 
 
-def count_bounds(ctx, r, lmin, lmax, variant=None):
-    if variant is not None:
-        ctx.set_option("k1_variant", variant)
+def count_bounds(ctx, r, lmin, lmax):
     cc = ctx.count_collector()
     ctx.scan_dev(r.cols(), pkg.Predicate.bounds(lmin, lmax), cc)
     n = cc.point_count()
     cc.free()
-    if variant is not None:
-        ctx.set_option("k1_variant", 12)  # the default (csrc/pcq_internal.h)
     return n
 
 
@@ -105,7 +101,7 @@ def ca13(gpu_ctx):
 
 def test_config5_ca13_full_size_properties(gpu_ctx, ca13):
     """ca13 (2 608 Mpoints): XL matches everything (run_query_experiments.rs:140); an integer box splits
-    exactly; the batched launch, the per-file launches and all kernel variants agree."""
+    exactly; the batched launch and the per-file launches agree."""
     bmin, bmax = specs.box("ca13_XL")
     cols, preds, total_n = [], [], 0
     per_file = []
@@ -125,7 +121,7 @@ def test_config5_ca13_full_size_properties(gpu_ctx, ca13):
     gpu_ctx.to_host(host, tot)
     gpu_ctx.free(tot)
     assert int(host[0]) == sum(per_file) == total_n
-    # exact integer partition of the L box of one file along every axis, with every kernel variant
+    # exact integer partition of the L box of one file along every axis, through the per-file kernel
     r = ca13[5]
     bl, bh = specs.box("ca13_L")
     lmin, lmax = pkg.box_to_local(bl, bh, r.h["scale"], r.h["offset"])
@@ -136,9 +132,7 @@ def test_config5_ca13_full_size_properties(gpu_ctx, ca13):
         mid = (lo + hi) // 2
         a_max, b_min = list(lmax), list(lmin)
         a_max[axis], b_min[axis] = mid, mid + 1
-        for variant in (0, 1, 2, 3):
-            assert count_bounds(gpu_ctx, r, lmin, a_max, variant) + count_bounds(gpu_ctx, r, b_min, lmax, variant) == whole
-    assert count_bounds(gpu_ctx, r, lmin, lmax, 1) == whole
+        assert count_bounds(gpu_ctx, r, lmin, a_max) + count_bounds(gpu_ctx, r, b_min, lmax) == whole
 
 
 def test_config4_ca13_density_full_size(oracle, gpu_ctx, ca13):
@@ -213,7 +207,6 @@ def test_single_block_beyond_2_pow_32_points(gpu_ctx):
         bmin, bmax = specs.box("ca13_XL")
         lmin, lmax = pkg.box_to_local(bmin, bmax, h["scale"], h["offset"])
         assert count_bounds(gpu_ctx, r, lmin, lmax) == n                       # the default one-wave kernel
-        assert count_bounds(gpu_ctx, r, lmin, lmax, variant=0) == n            # the 256-thread kernel
         # a thin slab: x partition of the file's own extent (three disjoint pieces sum to n), per kernel family
         x0, x1 = lmin[0], lmax[0]
         lo, hi = int(h["min"][0] / h["scale"][0]), int(h["max"][0] / h["scale"][0])
@@ -222,14 +215,12 @@ def test_single_block_beyond_2_pow_32_points(gpu_ctx):
         got = [count_bounds(gpu_ctx, r, [a, lmin[1], lmin[2]], [b, lmax[1], lmax[2]]) for a, b in parts]
         assert sum(got) == n and all(g > 0 for g in got)
         total = gpu_ctx.alloc(16)
-        for bv in (0, 2, 3):
-            gpu_ctx.set_option("batch_variant", bv)
+        for bv in (3,):
             gpu_ctx.memset(total, 0, 16)
             gpu_ctx.scan_dev_count_batch([r.cols()] * 3, [pkg.Predicate.bounds([a, lmin[1], lmin[2]], [b, lmax[1], lmax[2]]) for a, b in parts], total)
             host = np.zeros(1, dtype=np.uint64)
             gpu_ctx.to_host(host, total)
             assert int(host[0]) == n, bv
-        gpu_ctx.set_option("batch_variant", 3)  # the default
         # the strided (generic) kernel: the same block addressed 4 bytes later with the last point dropped
         shifted = binding.make_columns(xyz=r.xyz + 12, n=n - 1, scale=h["scale"], offset=h["offset"])
         cc = gpu_ctx.count_collector()

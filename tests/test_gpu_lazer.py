@@ -25,14 +25,6 @@ def q():
     return Q()
 
 
-@pytest.fixture(autouse=True, params=["device", "host"])
-def inflate_mode(request, monkeypatch):
-    """Every test runs twice: LZ4 inflate on the GPU (PCQ_LAZER_INFLATE=device; damaged or unusual frames fall
-    back to the host reader) and entirely on host threads (the default)."""
-    monkeypatch.setenv("PCQ_LAZER_INFLATE", request.param)
-    return request.param
-
-
 def _make(oracle, d, name, fmt, n, block, flags=4, block_id=4, seed=0):
     spec = specs._spec(7000 + fmt + seed, n, fmt, (0.01, 0.02, 0.05), (100.0, -200.0, 7.5), (-5000, -5000, -1000),
                        (10001, 10001, 2001), classes=[(1, 0.4), (2, 0.3), (6, 0.2), (134, 0.1)])

@@ -158,7 +158,6 @@ def test_random_lazer_files_and_queries(oracle, tmp_path, seed):
     pass exactly through points included; n = 0 panics on both sides (lazer_reader.rs:123,143)."""
     rng = np.random.default_rng(7000 + seed)
     q = Q()
-    os.environ["PCQ_LAZER_INFLATE"] = "host" if seed % 4 == 3 else "device"  # LZ4 inflate on the GPU / on host threads
     image, world, meta = build(rng, True)
     if meta["n"] == 0:
         blocks = [1]
@@ -208,4 +207,3 @@ def test_random_lazer_files_and_queries(oracle, tmp_path, seed):
             assert q.count(hc) == oc.point_count(), (meta, cls)
             assert q.points(hb).tobytes() == ob.points().tobytes(), (meta, cls)
         q.free(hc), q.free(hb), oc.free(), ob.free()
-    os.environ.pop("PCQ_LAZER_INFLATE", None)

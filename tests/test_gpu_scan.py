@@ -56,17 +56,12 @@ BOXES = [
 ]
 
 
-K1_DEFAULT, BATCH_DEFAULT = 12, 3  # csrc/pcq_internal.h
-
-
 @pytest.mark.parametrize("n", [0, 1, 3, 255, 256, 257, 511, 512, 513, 1000, 4099, 100_003, 1_000_003])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14])
-def test_bounds_count_dev_matches_oracle(oracle, gpu_ctx, n, variant):
+def test_bounds_count_dev_matches_oracle(oracle, gpu_ctx, n):
     spec = small_spec(1234 + n, n)
     image = oracle.synth_image(spec, transposed=True)
     hdr = oracle.parse_header(image[:400].tobytes())
-    gpu_ctx.set_option("k1_variant", variant)
-    try:
+    if True:
         for pad in (0, 4, 8, 12):  # positions block at every 4-byte phase of a 16-byte line
             f = DevFile(gpu_ctx, image, hdr, pad=pad + 5)  # 227 + 5 = 232 = 8 mod 16, then +pad
             try:
@@ -81,12 +76,10 @@ def test_bounds_count_dev_matches_oracle(oracle, gpu_ctx, n, variant):
                     # the oracle applies the header-AABB early-out (last.rs:92-94) before scanning;
                     # the column scan has no header: compare only when the file is not skipped
                     if oracle.aabb_intersects(list(hdr.min), list(hdr.max), bmin, bmax):
-                        assert got == oc.point_count(), (n, variant, pad, bmin)
+                        assert got == oc.point_count(), (n, pad, bmin)
                     oc.free()
             finally:
                 f.free()
-    finally:
-        gpu_ctx.set_option("k1_variant", K1_DEFAULT)
 
 
 @pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 31, 1000, 65_537, 1_000_003])
@@ -100,15 +93,12 @@ def test_class_count_dev_matches_oracle(oracle, gpu_ctx, n):
             for cls in (1, 2, 6, 19, 0, 255):
                 oc = oracle.count_collector()
                 assert oracle.search_last_class(image, cls, oc) == 0
-                for pipe in (1, 0):  # the one-wave pipelined kernel (default) and the 256-thread one
-                    gpu_ctx.set_option("class_batch_pipe", pipe)
-                    cc = gpu_ctx.count_collector()
-                    gpu_ctx.scan_dev(f.columns(True), pkg.Predicate.classification(cls), cc)
-                    assert cc.point_count() == oc.point_count(), (n, pad, cls, pipe)
-                    cc.free()
+                cc = gpu_ctx.count_collector()
+                gpu_ctx.scan_dev(f.columns(True), pkg.Predicate.classification(cls), cc)
+                assert cc.point_count() == oc.point_count(), (n, pad, cls)
+                cc.free()
                 oc.free()
         finally:
-            gpu_ctx.set_option("class_batch_pipe", 1)
             f.free()
 
 
@@ -138,11 +128,9 @@ def test_count_collector_accumulates_and_external_counter(oracle, gpu_ctx):
         f.free()
 
 
-@pytest.mark.parametrize("batch_variant", [0, 1, 2, 3])
-def test_count_batch_matches_sum_of_files(oracle, gpu_ctx, batch_variant):
+def test_count_batch_matches_sum_of_files(oracle, gpu_ctx):
     files, cols, preds, expect = [], [], [], 0
     bmin, bmax = (-20.0, -30.0, -3.0), (15.0, 45.0, 4.0)
-    gpu_ctx.set_option("batch_variant", batch_variant)
     try:
         for i, n in enumerate([100_003, 0, 255, 256, 70_001, 1_000_003, 511, 512, 513, 767, 768, 769, 1535, 1536, 1537]):
             spec = small_spec(500 + i, n, offset=(float(i), 0.0, 0.0))
@@ -166,7 +154,6 @@ def test_count_batch_matches_sum_of_files(oracle, gpu_ctx, batch_variant):
         gpu_ctx.free(total)
         assert int(host[0]) == 2 * expect
     finally:
-        gpu_ctx.set_option("batch_variant", BATCH_DEFAULT)
         for f in files:
             f.free()
 
@@ -408,7 +395,8 @@ def test_grid_through_the_host_path_in_large_chunks(oracle, cell):
                 folds = ctx.get_option("grid_folds")
                 ctx.scan_host(cols, pkg.Predicate.bounds(lmin, lmax), gg)
                 assert gg.point_count() == og.point_count()
-                assert ctx.get_option("grid_folds") - folds == (4 if budget else 1)
+                # 19 staged bytes per point -> 5 chunks of ~0.82 M points: one fold in all, or one per chunk
+                assert ctx.get_option("grid_folds") - folds == (5 if budget else 1)
                 gp, gk = gg.points(), gg.grid_cells()
                 order = np.argsort(gk, kind="stable")
                 assert np.array_equal(gk[order], og.grid_cells())
@@ -448,12 +436,8 @@ def test_allreduce_entry_point_single_rank(gpu_ctx):
     assert int(out[0]) == 12345678901234567
 
 
-@pytest.mark.parametrize("pipe", [0, 1])
-@pytest.mark.parametrize("loads", [0, 4, 6, 8, 12])
-def test_class_count_batch_matches_sum_of_files(oracle, gpu_ctx, loads, pipe):
+def test_class_count_batch_matches_sum_of_files(oracle, gpu_ctx):
     files, cols, preds, expect = [], [], [], 0
-    gpu_ctx.set_option("class_batch_loads", loads)
-    gpu_ctx.set_option("class_batch_pipe", pipe)
     try:
         for i, (n, pad) in enumerate([(100_003, 0), (0, 3), (15, 7), (4096 + 17, 1), (70_001, 13), (1_000_003, 5), (6143, 2), (6144 + 16, 9),
                                       (12_288 + 31, 4)]):
@@ -481,8 +465,6 @@ def test_class_count_batch_matches_sum_of_files(oracle, gpu_ctx, loads, pipe):
             gpu_ctx.scan_dev_count_batch(cols[:2], [preds[0], pkg.Predicate.bounds([0, 0, 0], [1, 1, 1])], total)
         gpu_ctx.free(total)
     finally:
-        gpu_ctx.set_option("class_batch_loads", 4)  # the defaults (csrc/pcq_internal.h)
-        gpu_ctx.set_option("class_batch_pipe", 1)
         for f in files:
             f.free()
 

@@ -1,4 +1,6 @@
 """Developer tool: read-only stream rate vs launch geometry (waves per CU, loads in flight per wave)."""
+import os
+os.environ.setdefault("PCQ_LAB", "1")  # the kernel shapes / microbenchmarks swept here live in libpcq_lab.so (make -C csrc lab)
 import ctypes as C, importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

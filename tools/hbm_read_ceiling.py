@@ -1,5 +1,7 @@
 """Measured read-only HBM streaming ceiling on this device, next to K1 (developer tool).
 Rotates over 8 x 2 GB buffers (no Infinity-Cache re-reads), interleaved rounds, HIP events."""
+import os
+os.environ.setdefault("PCQ_LAB", "1")  # the kernel shapes / microbenchmarks swept here live in libpcq_lab.so (make -C csrc lab)
 import ctypes as C, importlib, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,4 +1,6 @@
 """Developer tool: the software-pipelined per-file K1 (variant 12) by absolute grid size (workgroups of one wave)."""
+import os
+os.environ.setdefault("PCQ_LAB", "1")  # the kernel shapes / microbenchmarks swept here live in libpcq_lab.so (make -C csrc lab)
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

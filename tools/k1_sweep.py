@@ -8,6 +8,8 @@ The working set rotates over `--files` device-resident synthetic files (default 
 15.6 GB) so that no launch re-reads data the 256 MiB Infinity Cache could still hold: a sweep that
 re-reads ONE 2 GB file reports ~10 % more than the HBM stream really delivers.
 """
+import os
+os.environ.setdefault("PCQ_LAB", "1")  # the kernel shapes / microbenchmarks swept here live in libpcq_lab.so (make -C csrc lab)
 import argparse
 import importlib
 import json

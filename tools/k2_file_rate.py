@@ -1,5 +1,7 @@
 """Developer tool: per-file class count (K2) — the one-wave pipelined kernel vs the 256-thread kernel, on 6
 resident classification blocks of 163 M bytes visited round-robin (978 MB, beyond the Infinity Cache)."""
+import os
+os.environ.setdefault("PCQ_LAB", "1")  # the kernel shapes / microbenchmarks swept here live in libpcq_lab.so (make -C csrc lab)
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

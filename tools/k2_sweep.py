@@ -1,5 +1,7 @@
 """Developer tool: batched class count (K2) — the 256-thread kernel vs one-wave workgroups with 4-12 KiB per
 step, by waves per CU; 16 classification blocks of 163 M bytes resident (2.6 GB, beyond the Infinity Cache)."""
+import os
+os.environ.setdefault("PCQ_LAB", "1")  # the kernel shapes / microbenchmarks swept here live in libpcq_lab.so (make -C csrc lab)
 import importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,8 @@
 """Developer tool: does an XCD-aware workgroup -> tile mapping change the read-stream rate?
 Workgroups are dealt round-robin to the 8 XCDs (each with its own L2).  K1 streams every byte once, so
 there is no reuse for an L2 to capture; this measures whether locality per XCD matters anyway."""
+import os
+os.environ.setdefault("PCQ_LAB", "1")  # the kernel shapes / microbenchmarks swept here live in libpcq_lab.so (make -C csrc lab)
 import ctypes as C, importlib, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
