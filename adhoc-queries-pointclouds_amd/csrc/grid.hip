@@ -58,6 +58,7 @@ constexpr int FOLD_K = 4;              // fold: tuples per thread and chunk
 constexpr int L2_NT = 512;             // second level: threads per workgroup (one workgroup per level-1 bin)
 constexpr int L2_UNROLL = 4;
 constexpr int PROBE_BINS = 2;          // bins whose distinct cells are counted to estimate the grid's density
+constexpr uint64_t ALIAS_QUADRATIC = 8192;  // aliased tuples up to which the replay order comes from the quadratic rank kernel
 constexpr int MAX_RUNS = 1024;         // pending pass-0 runs per collector before a fold is forced
 constexpr uint64_t RUN_POINTS = 1ull << 30;  // points per pass-0 run (tuple offsets are 32-bit)
 
@@ -85,7 +86,7 @@ struct GridSeg {
     const uint32_t *off;
 };
 
-struct AliasItem {  // a tuple of an aliased key, for the exact replay
+struct AliasItem {  // a tuple of an aliased key, for the exact replay (key at +0, order at +8: alias_sort.hip)
     uint64_t key, ord;
     int32_t x, y, z;
     uint32_t w0, w1, _pad;
@@ -1460,7 +1461,12 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 if (rc) return rc;
                 PCQ_HIP(hipMemsetAsync(d_stats + 4, 0, 8, s));
                 hipLaunchKernelGGL(k_alias_gather<true>, dim3(nparts), dim3(L2_NT), 0, s, F, d_list, d_stats + 4);
-                hipLaunchKernelGGL(k_alias_rank, dim3((unsigned)((na + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, d_list, (uint64_t)na, d_sorted);
+                if (na <= ALIAS_QUADRATIC) {
+                    hipLaunchKernelGGL(k_alias_rank, dim3((unsigned)((na + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, d_list, (uint64_t)na, d_sorted);
+                } else {  // massive aliasing: a real sort (alias_sort.hip)
+                    rc = pcq_sort_by_key_then_order(ctx, d_list, sizeof(AliasItem), na, d_sorted, s);
+                    if (rc) return rc;
+                }
                 hipLaunchKernelGGL(k_alias_replay, dim3((unsigned)((na + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, d_sorted, (uint64_t)na, F, f2);
                 PCQ_HIP(hipGetLastError());
                 PCQ_HIP(hipStreamSynchronize(s));

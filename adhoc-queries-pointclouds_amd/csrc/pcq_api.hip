@@ -308,8 +308,11 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
 #endif
     } else if (!strcmp(key, "allreduce_single_rank")) {
         ctx->allreduce_single_rank = value != 0;
+    } else if (!strcmp(key, "grid_pending_budget")) {
+        if (value < 0) return pcq_fail(PCQ_ERR_ARG, "grid_pending_budget must be >= 0");
+        ctx->grid_pending_budget = value;
     } else if (!strcmp(key, "grid_f2")) {
-        if (value < 0 || value > 256) return pcq_fail(PCQ_ERR_ARG, "grid_f2 must be 0..256");
+        if (value < 0 || value > 4096) return pcq_fail(PCQ_ERR_ARG, "grid_f2 must be 0..4096");
         ctx->grid_f2 = (int)value;
     } else if (!strcmp(key, "numa_local")) {
         ctx->numa_local = value != 0;
@@ -501,7 +504,22 @@ extern "C" int pcq_collector_new_count_at(pcq_ctx *ctx, uint64_t *device_counter
     return PCQ_OK;
 }
 
-extern "C" int pcq_collector_new_buffer(pcq_ctx *ctx, pcq_collector **out) { return new_collector(ctx, COLL_BUFFER, out); }
+extern "C" int pcq_collector_new_buffer(pcq_ctx *ctx, pcq_collector **out) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
+    int rc = new_collector(ctx, COLL_BUFFER, out);
+    if (rc) return rc;
+    pcq_collector *c = *out;
+    hipError_t e = hipMalloc((void **)&c->d_count, 16);  // the point count (see pcq_internal.h)
+    if (e == hipSuccess) e = hipMemsetAsync(c->d_count, 0, 16, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // scans may be enqueued on a caller's stream
+    if (e != hipSuccess) {
+        delete c;
+        *out = nullptr;
+        return pcq_fail(PCQ_ERR_HIP, "buffer collector: %s", hipGetErrorString(e));
+    }
+    c->owns_count = true;
+    return PCQ_OK;
+}
 
 // SparseGrid::new — grid_sampling.rs:18-47
 extern "C" int pcq_collector_new_grid(pcq_ctx *ctx, const double bmin[3], const double bmax[3], double cell_size,
@@ -562,7 +580,7 @@ extern "C" int pcq_collector_free(pcq_collector *c) {
         if (c->last_stream && c->last_stream != c->ctx->stream) (void)hipStreamSynchronize(c->last_stream);  // scans enqueued on a caller's stream
     }
     if (c->owns_count && c->d_count) (void)hipFree(c->d_count);
-    if (c->d_points) (void)hipFree(c->d_points);
+    if (c->d_points && c->ctx) pcq_pool_free(c->ctx, c->d_points);
     if (c->kind == COLL_GRID) pcq_grid_release(c);
     delete c;
     return PCQ_OK;
@@ -574,7 +592,10 @@ extern "C" int pcq_collector_reset(pcq_collector *c) {
     hipStream_t s = c->ctx->stream;
     c->next_index = 0;
     if (c->kind == COLL_COUNT) PCQ_HIP(hipMemsetAsync(c->d_count, 0, 8, s));
-    if (c->kind == COLL_BUFFER) c->n_points = 0;
+    if (c->kind == COLL_BUFFER) {
+        PCQ_HIP(hipMemsetAsync(c->d_count, 0, 8, s));
+        c->n_upper = 0;
+    }
     if (c->kind == COLL_GRID) {
         PCQ_HIP(hipStreamSynchronize(s));
         if (c->last_stream && c->last_stream != s) PCQ_HIP(hipStreamSynchronize(c->last_stream));
@@ -597,8 +618,10 @@ extern "C" int pcq_collector_point_count(pcq_collector *c, uint64_t *out) {
         *out = ctx->h_scalars[0];
         return PCQ_OK;
     case COLL_BUFFER:
+        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
         PCQ_HIP(hipStreamSynchronize(ctx->stream));
-        *out = c->n_points;
+        *out = ctx->h_scalars[0];
+        c->n_upper = ctx->h_scalars[0];
         return PCQ_OK;
     default:
         return pcq_grid_drain(c, nullptr, nullptr, 0, out);
@@ -613,13 +636,16 @@ extern "C" int pcq_collector_points(pcq_collector *c, pcq_point *out, uint64_t c
     if (c->kind == COLL_COUNT) return PCQ_OK;  // points() is None (collect_points.rs:87-93)
     if (c->last_stream && c->last_stream != ctx->stream) PCQ_HIP(hipStreamSynchronize(c->last_stream));
     if (c->kind == COLL_BUFFER) {
+        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
         PCQ_HIP(hipStreamSynchronize(ctx->stream));
-        *out_n = c->n_points;
-        if (!out || c->n_points == 0) return PCQ_OK;
-        if (cap < c->n_points)
+        const uint64_t n_points = ctx->h_scalars[0];
+        c->n_upper = n_points;
+        *out_n = n_points;
+        if (!out || n_points == 0) return PCQ_OK;
+        if (cap < n_points)
             return pcq_fail(PCQ_ERR_CAPACITY, "buffer collector holds %llu points, capacity %llu",
-                            (unsigned long long)c->n_points, (unsigned long long)cap);
-        PCQ_HIP(hipMemcpy(out, c->d_points, c->n_points * 31, hipMemcpyDeviceToHost));
+                            (unsigned long long)n_points, (unsigned long long)cap);
+        PCQ_HIP(hipMemcpy(out, c->d_points, n_points * 31, hipMemcpyDeviceToHost));
         return PCQ_OK;
     }
     return pcq_grid_drain(c, out, nullptr, cap, out_n);
@@ -699,16 +725,28 @@ static int count_into(pcq_ctx *ctx, const DevCols &dc, const DevPred &dp, uint64
     return pcq_launch_generic_count(ctx, dc, dp, d_count, s);
 }
 
-static int buffer_reserve(pcq_collector *c, uint64_t need, hipStream_t s) {
-    if (need <= c->cap_points) return PCQ_OK;
-    uint64_t cap = c->cap_points ? c->cap_points : 4096;
-    while (cap < need) cap *= 2;
-    uint8_t *nb = nullptr;
-    PCQ_HIP(hipMalloc((void **)&nb, cap * 31));
-    if (c->n_points) PCQ_HIP(hipMemcpyAsync(nb, c->d_points, c->n_points * 31, hipMemcpyDeviceToDevice, s));
+// Room for `incoming` more points.  The host knows only an upper bound of the points held (every scanned point may have
+// matched); while that bound fits the buffer nothing is asked of the device.  When it does not, the true count is read
+// (one synchronisation), and the buffer grows only if the truth needs it.
+static int buffer_reserve(pcq_collector *c, uint64_t incoming, hipStream_t s) {
+    if (c->n_upper + incoming <= c->cap_points) return PCQ_OK;
+    pcq_ctx *ctx = c->ctx;
+    if (c->last_stream && c->last_stream != s) PCQ_HIP(hipStreamSynchronize(c->last_stream));
+    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->d_count, 8, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipStreamSynchronize(s));
-    if (c->d_points) PCQ_HIP(hipFree(c->d_points));
-    c->d_points = nb;
+    const uint64_t have = ctx->h_scalars[0];
+    c->n_upper = have;
+    if (have + incoming <= c->cap_points) return PCQ_OK;
+    uint64_t cap = 2 * c->cap_points;  // geometric growth, but never beyond what is asked for when that is more
+    if (cap < have + incoming) cap = have + incoming;
+    if (cap < 4096) cap = 4096;
+    void *nb = nullptr;
+    int rc = pcq_pool_alloc(ctx, cap * 31 + 16, &nb);
+    if (rc) return rc;
+    if (have) PCQ_HIP(hipMemcpyAsync(nb, c->d_points, have * 31, hipMemcpyDeviceToDevice, s));
+    PCQ_HIP(hipStreamSynchronize(s));
+    pcq_pool_free(ctx, c->d_points);
+    c->d_points = (uint8_t *)nb;
     c->cap_points = cap;
     return PCQ_OK;
 }
@@ -727,14 +765,11 @@ static int scan_dev_impl(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predic
         return count_into(ctx, dc, dp, c->d_count, s);
     case COLL_BUFFER: {
         if (dp.kind == PCQ_PRED_BOUNDS && dp.empty) return PCQ_OK;
-        uint64_t matches = 0;
-        rc = pcq_emit_prepare(ctx, dc, dp, &matches, s);
-        if (rc || matches == 0) return rc;
-        rc = buffer_reserve(c, c->n_points + matches, s);
+        rc = buffer_reserve(c, dc.n, s);
         if (rc) return rc;
-        rc = pcq_launch_emit_points(ctx, dc, dp, c->d_points, c->n_points, matches, s);
+        rc = pcq_launch_emit_points(ctx, dc, dp, c->d_points, c->d_count, s);  // asynchronous: one pass, no count first
         if (rc) return rc;
-        c->n_points += matches;
+        c->n_upper += dc.n;
         return PCQ_OK;
     }
     case COLL_GRID: {
@@ -809,6 +844,13 @@ int pcq_stream_fd_to_device(pcq_ctx *ctx, int fd, uint64_t offset, uint64_t byte
     }
     PCQ_HIP(hipStreamSynchronize(cs));
     return PCQ_OK;
+}
+
+extern "C" int pcq_read_fd_to_device(pcq_ctx *ctx, int fd, uint64_t file_offset, uint64_t bytes, void *d_dst) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
+    if (!ctx || fd < 0 || (!d_dst && bytes)) return pcq_fail(PCQ_ERR_ARG, "pcq_read_fd_to_device: bad argument");
+    if (bytes == 0) return PCQ_OK;
+    return pcq_stream_fd_to_device(ctx, fd, file_offset, bytes, (uint8_t *)d_dst);
 }
 
 struct StagePlan {

@@ -188,9 +188,11 @@ struct pcq_collector {
     // count
     uint64_t *d_count = nullptr;
     bool owns_count = false;
-    // buffer: packed 31-byte points in HBM
+    // buffer: packed 31-byte points in HBM.  The number of points lives on the device (d_count): every scan reads it as
+    // its base and moves it on, so scans need no round trip.  The host only knows an upper bound (one match per
+    // scanned point) and asks the device for the truth when that bound outgrows the buffer.
     uint8_t *d_points = nullptr;
-    uint64_t n_points = 0, cap_points = 0;
+    uint64_t n_upper = 0, cap_points = 0;
     // grid
     double bmin[3], bmax[3], cell_size = 0;
     uint64_t dims[3], bits[3];
@@ -214,13 +216,13 @@ int pcq_launch_class_count_u8(pcq_ctx *ctx, const void *d_cls, uint64_t n, uint8
 // scan_generic.hip
 int pcq_launch_generic_count(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred,
                              uint64_t *d_count, hipStream_t s);
-int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint8_t *d_out31,
-                           uint64_t out_base, uint64_t expected, hipStream_t s);
-int pcq_emit_prepare(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint64_t *matches, hipStream_t s);
+int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint8_t *d_out31, uint64_t *d_npoints, hipStream_t s);
 // grid.hip
 int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const DevPred &pred, hipStream_t s);
 void pcq_grid_release(pcq_collector *c);
 int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_t cap, uint64_t *out_n);
+// alias_sort.hip: sorted[i] = the i-th of n records (u64 key at +0, u64 order at +8) by (key, order)
+int pcq_sort_by_key_then_order(pcq_ctx *ctx, const void *items, size_t stride, uint64_t n, void *sorted, hipStream_t s);
 // pcq_api.hip: device-memory pool of the context.  A block may be freed only when the work that used it has completed.
 int pcq_pool_alloc(pcq_ctx *ctx, size_t bytes, void **out);
 void pcq_pool_free(pcq_ctx *ctx, void *p);

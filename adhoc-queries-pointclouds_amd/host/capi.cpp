@@ -153,3 +153,38 @@ extern "C" int pcq_query_main(int argc, const char *const *argv) {
             fputc('\n', stderr);
         });
 }
+
+// ---- resident dataset -------------------------------------------------------------------------------------
+struct pcq_host_resident {
+    std::unique_ptr<ResidentDataset> ds;
+};
+extern "C" int pcq_query_resident_load(int device, const char *const *files, size_t nfiles, pcq_host_resident **out) {
+    if (!out || (!files && nfiles)) return done(Status::Err(PCQ_ERR_ARG, "null argument"));
+    *out = nullptr;
+    pcq_ctx *ctx = nullptr;
+    Status st = thread_context(device, &ctx);
+    if (!st.ok()) return done(st);
+    std::vector<std::string> v;
+    for (size_t i = 0; i < nfiles; i++) v.emplace_back(files[i]);
+    auto h = std::make_unique<pcq_host_resident>();
+    st = ResidentDataset::load(ctx, v, &h->ds);
+    if (!st.ok()) return done(st);
+    *out = h.release();
+    return PCQ_OK;
+}
+extern "C" int pcq_query_resident_free(pcq_host_resident *r) {
+    delete r;
+    return PCQ_OK;
+}
+extern "C" int pcq_query_resident_count_bounds(pcq_host_resident *r, const double bmin[3], const double bmax[3], uint64_t *matches,
+                                               uint64_t *points_scanned) {
+    if (!r || !bmin || !bmax || !matches) return done(Status::Err(PCQ_ERR_ARG, "null argument"));
+    AABB b;
+    Status st = AABB::from_min_max(bmin, bmax, &b);
+    if (!st.ok()) return done(st);
+    return done(r->ds->count_bounds(b, matches, points_scanned));
+}
+extern "C" int pcq_query_resident_count_class(pcq_host_resident *r, uint8_t cls, uint64_t *matches, uint64_t *points_scanned) {
+    if (!r || !matches) return done(Status::Err(PCQ_ERR_ARG, "null argument"));
+    return done(r->ds->count_class(cls, matches, points_scanned));
+}

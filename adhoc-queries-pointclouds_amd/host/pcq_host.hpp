@@ -266,6 +266,34 @@ Status run_search_sequential(const std::vector<std::string> &files, const Search
 Status run_search_parallel(const std::vector<std::string> &files, const Searcher &searcher, SearchImplementation impl,
                            const CollectorFactoryFn &factory, PointDumper &dumper, const RunOptions &opt, const PrintFn &print);
 
+// ---- a dataset resident in HBM (resident.cpp) -----------------------------------------------------------
+// Not in the reference (it re-reads the files for every query): the positions and classification blocks of a set of
+// LAST files are loaded into one GPU's HBM once, and every count query over them is ONE batched launch.
+struct ResidentFile {
+    std::string path;
+    LasHeader header;
+    void *xyz = nullptr, *cls = nullptr;  // device blocks
+};
+class ResidentDataset {
+public:
+    ~ResidentDataset();
+    ResidentDataset(const ResidentDataset &) = delete;
+    ResidentDataset &operator=(const ResidentDataset &) = delete;
+    static Status load(pcq_ctx *ctx, const std::vector<std::string> &paths, std::unique_ptr<ResidentDataset> *out);
+    Status count_bounds(const AABB &bounds, uint64_t *matches, uint64_t *points_scanned = nullptr);
+    Status count_class(uint8_t cls, uint64_t *matches, uint64_t *points_scanned = nullptr);
+    size_t files() const { return files_.size(); }
+    uint64_t points() const { return points_; }
+
+private:
+    ResidentDataset() = default;
+    Status run(const std::vector<pcq_columns> &cols, const std::vector<pcq_predicate> &preds, uint64_t *matches);
+    pcq_ctx *ctx_ = nullptr;
+    std::vector<ResidentFile> files_;
+    uint64_t *counter_ = nullptr;
+    uint64_t points_ = 0;
+};
+
 // The whole CLI (main.rs:191-319): returns the process exit code; stdout/stderr text via callbacks.
 int query_main(int argc, const char *const *argv, const PrintFn &out, const PrintFn &err);
 

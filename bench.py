@@ -37,6 +37,15 @@ import torch  # noqa: E402  (device memory, streams, torch.distributed — plumb
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def kernel_source_id():
+    """Identity of the timed kernel's source (stable across rebuilds): sha256 of the files it is compiled from."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in ("adhoc-queries-pointclouds_amd/csrc/scan_count.hip", "adhoc-queries-pointclouds_amd/csrc/pcq_internal.h"):
+        h.update(open(os.path.join(ROOT, rel), "rb").read())
+    return h.hexdigest()[:16]
 BYTES_PER_POINT = 12   # SURVEY.md §8(d): bounds count reads N x {i32 x,y,z}
 
 
@@ -64,7 +73,7 @@ def cpu_baseline(specs_mod, bmin, bmax, sample_points_per_file, nfiles):
         times.append(time.perf_counter() - t0)
     times.sort()
     med = times[len(times) // 2]
-    return {"value": total_pts / med / 1e6, "unit": "Mpoints/s", "cores": threads, "kind": "port",
+    return oracle, threads, {"value": total_pts / med / 1e6, "unit": "Mpoints/s", "cores": threads, "kind": "port",
             "sample": f"oracle (C restatement of last.rs:46-166 + CountCollector), {nfiles} synthetic ca13 LAST files x "
                       f"{sample_points_per_file} points in host memory, warm, one thread per file, median of 5; "
                       f"matches {count}/{total_pts}; host has {cores} cores"}, images, sample, count
@@ -119,6 +128,18 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    rank_devices = [local_rank]
+    if use_dist:
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"torch.distributed world size {dist.get_world_size()} != --gpus {args.gpus}")
+        # one rank per GPU: two ranks on one device would halve the per-GPU rate and report it as scaling
+        ident = (os.uname().nodename, local_rank, str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")))
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ident)
+        if not args.rehearse_on_one_gpu and len(set(gathered)) != world:
+            raise SystemExit(f"ranks share a device: {gathered}")
+        rank_devices = [g[1] for g in gathered]
 
     pkg = importlib.import_module("adhoc-queries-pointclouds_amd")
     binding = importlib.import_module("adhoc-queries-pointclouds_amd.binding")
@@ -223,11 +244,14 @@ def main():
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
-        sc = torch.tensor([scanned_local], dtype=torch.int64, device=dev)
-        dist.all_reduce(sc, op=dist.ReduceOp.SUM)
-        scanned_global = int(sc.item())
+        per_rank = torch.zeros(world, dtype=torch.int64, device=dev)
+        per_rank[rank] = scanned_local
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)  # every rank's share, through the same communicator as the counts
+        scanned_per_rank = [int(v) for v in per_rank.cpu().tolist()]
+        scanned_global = sum(scanned_per_rank)
     else:
         scanned_global = scanned_local
+        scanned_per_rank = [scanned_local]
 
     # kernel-only roofline (this rank's launches; HIP events on the launch stream)
     launch_ms = [e0.elapsed_time(e1) for e0, e1, _ in events]
@@ -239,13 +263,21 @@ def main():
     kernel_name = "k_bounds_count_w1_pipe<2>" if args.per_file_launch else "k_bounds_count_batch_pipe<2>"
     result = None
     if rank == 0:
-        traffic = None
+        # HBM traffic of the timed kernel from PMC counters.  A process cannot profile itself: the figure comes from the
+        # committed summary of tools/pmc_traffic.py (bench.py under rocprofv3 --pmc, separate passes) and is reported
+        # only if that summary was taken on THIS kernel (same name, same source files, same points per launch).
+        traffic, traffic_source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_latest.json")
         if os.path.exists(pmc_path):
             try:
                 pmc = json.load(open(pmc_path))
-                if pmc.get("points_per_launch") == (sum(launch_pts) // max(1, len(launch_pts))):
+                same = (pmc.get("points_per_launch") == (sum(launch_pts) // max(1, len(launch_pts)))
+                        and kernel_name in str(pmc.get("kernel_name", "")) and pmc.get("kernel_source_id") == kernel_source_id())
+                if same:
                     traffic = pmc.get("hbm_bytes_per_launch")
+                    traffic_source = f"profiles/pmc_latest.json@{pmc.get('git_head', '?')} (tools/pmc_traffic.py, not measured by this run)"
+                else:
+                    traffic_source = "profiles/pmc_latest.json is from another kernel build: not reported"
             except Exception:
                 traffic = None
         result = {
@@ -273,6 +305,9 @@ def main():
                            "enqueued back to back, one result slot each; all answers read and checked after the timed region",
                 "device": info["name"] + " " + info["gcn_arch"],
             },
+            "rccl_ranks": dist.get_world_size() if use_dist and not args.rehearse_on_one_gpu else 0,
+            "rank_devices": rank_devices,
+            "scanned_per_rank": scanned_per_rank,
             "matches": matches,
             "roofline": {
                 "bound": "hbm",
@@ -281,7 +316,9 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": traffic_source,
                 "kernel": kernel_name,
+                "kernel_source_id": kernel_source_id(),
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": avg_ms,
                 "launches_timed": len(launch_ms),
@@ -290,8 +327,31 @@ def main():
 
     # CPU baseline: rank 0 at N=1 only, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base, images, sample, cpu_count = cpu_baseline(specs_mod, bmin, bmax, args.cpu_sample_points, args.files)
+        oracle, threads, base, images, sample, cpu_count = cpu_baseline(specs_mod, bmin, bmax, args.cpu_sample_points, args.files)
         result["cpu_baseline"] = base
+        # The TIMED kernel with a selective predicate: one untimed `--bounds ca13_L` query over the sample, resident in HBM,
+        # through the same batched launch as the timed region, against the oracle's count for that box.
+        lb_min, lb_max = specs_mod.box("ca13_L")
+        want_l = oracle.count_files_parallel(images, 0, lb_min, lb_max, 0, threads)
+        dcols, dpreds, keep = [], [], []
+        for s_, im in zip(sample, images):
+            h = specs_mod.header_fields(s_)
+            if not specs_mod.aabb_intersects(h["min"], h["max"], lb_min, lb_max):  # last.rs:92-94
+                continue
+            t = torch.from_numpy(im[227:227 + 12 * h["n"]]).to(dev)  # the positions block (offset_to_point_data = 227)
+            keep.append(t)
+            lmin, lmax = pkg.box_to_local(lb_min, lb_max, h["scale"], h["offset"])
+            dcols.append(binding.make_columns(xyz=t.data_ptr(), n=h["n"], scale=h["scale"], offset=h["offset"]))
+            dpreds.append(pkg.Predicate.bounds(lmin, lmax))
+        slot = torch.zeros(2, dtype=torch.int64, device=dev)
+        if dcols:
+            ctx.scan_dev_count_batch(dcols, dpreds, slot.data_ptr(), stream)
+        got_l = int(slot[0].item())
+        del keep
+        result["parity_batched_on_sample"] = {"query": "ca13_L", "kernel": kernel_name, "gpu": got_l, "oracle": int(want_l),
+                                              "files_scanned": len(dcols), "equal": bool(got_l == want_l)}
+        if got_l != want_l:
+            raise SystemExit(f"PARITY FAILURE of the batched kernel on the sample (ca13_L): gpu {got_l} != oracle {want_l}")
         # the same sample through the GPU path must give the same count (bit-exact parity on the bench inputs)
         gpu_total = 0
         for s, im in zip(sample, images):

@@ -234,6 +234,10 @@ int pcq_copy_to_device(pcq_ctx *ctx, void *dst_device, const void *src_host, uin
 int pcq_copy_to_host(pcq_ctx *ctx, void *dst_host, const void *src_device, uint64_t bytes);
 int pcq_device_memset(pcq_ctx *ctx, void *dst_device, int value, uint64_t bytes, void *stream);
 
+/* Reads [file_offset, file_offset + bytes) of an open file into device memory at the rate of the host block path (pinned
+ * double buffering, parallel pread) — for callers that keep column blocks resident in HBM.  Synchronous. */
+int pcq_read_fd_to_device(pcq_ctx *ctx, int fd, uint64_t file_offset, uint64_t bytes, void *d_dst);
+
 /* Restricts the CALLING thread to the CPUs of the NUMA node the context's GPU is attached to (no-op when the
  * node is unknown or option "numa_local" is 0).  For caller threads that produce the bytes a scan will read —
  * memory they touch first then sits next to the GPU's staging buffers. */

@@ -69,6 +69,17 @@ int pcq_query_search_file_bounds(const char *path, const double bmin[3], const d
                                  pcq_host_collector *c, int *las_record_size);
 int pcq_query_search_file_class(const char *path, uint8_t cls, int optimized, pcq_host_collector *c);
 
+/* A dataset resident in HBM (host/resident.cpp; not in the reference, which re-reads the files for every query): the
+ * positions and classification blocks of LAST files are loaded into `device`'s HBM once; every count query over them
+ * is the reference's per-file host prologue (early-out last.rs:92-94, box conversion :98-109) + ONE batched launch
+ * (pcq_scan_dev_count_batch).  Same counts as `query --bounds|--class ... --optimized --parallel` on those files. */
+typedef struct pcq_host_resident pcq_host_resident;
+int pcq_query_resident_load(int device, const char *const *files, size_t nfiles, pcq_host_resident **out);
+int pcq_query_resident_free(pcq_host_resident *r);
+int pcq_query_resident_count_bounds(pcq_host_resident *r, const double bmin[3], const double bmax[3], uint64_t *matches,
+                                    uint64_t *points_scanned);
+int pcq_query_resident_count_class(pcq_host_resident *r, uint8_t cls, uint64_t *matches, uint64_t *points_scanned);
+
 /* The whole CLI in-process (main.rs:191-319); returns the exit code. */
 int pcq_query_main(int argc, const char *const *argv);
 

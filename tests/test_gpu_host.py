@@ -8,6 +8,7 @@ import json
 import os
 import struct
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -403,3 +404,94 @@ def test_cli_single_file_and_output_dir(oracle, files, tmp_path):
     assert np.array_equal(rec["rgb"], np.stack([want["r"], want["g"], want["b"]], axis=1))
     for a, k in enumerate("xyz"):
         assert np.all(np.abs(rec["xyz"][:, a] * scale[a] + offset[a] - want[k]) <= 0.5 * scale[a] + 1e-9)
+
+
+def test_cli_query_resolved_on_the_host_never_wakes_the_gpu(files):
+    """Host first (run_search.cpp): the header prologue of every file runs before any GPU context exists.  A box that
+    misses every file's header AABB (last.rs:92-94) is answered without HIP start-up — no context is created — while a
+    box that hits at least one file creates exactly one (one GPU, one host thread per GPU)."""
+    d = os.path.dirname(files[0])
+    miss = ["-i", d, "--optimized", "--parallel", "--bounds", "500;500;500;600;600;600"]
+    rc_p, body_p, _, err_p = _cli(QUERY, miss, env={"PCQ_TIMING": "1"})
+    rc_o, body_o, _, _ = _cli(ORACLE_CLI, miss)
+    assert rc_p == rc_o == 0 and sorted(body_p) == sorted(body_o)
+    assert "Found 0 matching points" in body_p
+    assert "0 of 8 files need the GPU" in err_p and "context on device" not in err_p
+    hit = ["-i", d, "--optimized", "--parallel", "--bounds", "90;-250;0;120;-150;20"]
+    rc_p, body_p, _, err_p = _cli(QUERY, hit, env={"PCQ_TIMING": "1"})
+    rc_o, body_o, _, _ = _cli(ORACLE_CLI, hit)
+    assert rc_p == rc_o == 0 and sorted(body_p) == sorted(body_o)
+    assert err_p.count("context on device") == 1
+    # the same with an output directory and with a density: collectors that yield points
+    for extra in (["--density", "5"],):
+        rc_p, body_p, _, err_p = _cli(QUERY, miss + extra, env={"PCQ_TIMING": "1"})
+        rc_o, body_o, _, _ = _cli(ORACLE_CLI, miss + extra)
+        assert rc_p == rc_o == 0 and sorted(body_p) == sorted(body_o) and "context on device" not in err_p
+
+
+def test_package_before_torch_shares_one_hip_runtime(tmp_path):
+    """PyTorch ships its own libamdhip64 (same SONAME as ROCm's).  Whichever is imported first, the process must end up
+    with ONE runtime: the package maps torch's copy before libpcq.so when torch is installed (binding._one_hip_runtime)."""
+    code = r'''
+import importlib, os, sys
+sys.path.insert(0, %r)
+pkg = importlib.import_module("adhoc-queries-pointclouds_amd")   # before torch
+ctx = pkg.Context(0)
+info = ctx.device_info()
+import torch
+assert torch.cuda.is_available(), "torch lost the device"
+t = torch.arange(1000, device="cuda").sum().item()
+assert t == 499500
+d = ctx.alloc(64); ctx.memset(d, 0, 64); ctx.synchronize(); ctx.free(d)
+ctx.close()
+paths = sorted({l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l})
+print("RUNTIMES", len(paths), info["gcn_arch"])
+''' % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "RUNTIMES 1 gfx950" in r.stdout
+
+
+def test_resident_dataset_batched_counts_equal_per_file_searches(oracle, q, files):
+    """host/resident.cpp: the LAST files of a dataset loaded into HBM once; every count query is the per-file host
+    prologue (early-out, box conversion) plus ONE batched launch.  Same totals as the per-file searches of the oracle."""
+    lasts = [f for f in files if f.endswith(".last")]
+    lib = q.lib
+    lib.pcq_query_resident_load.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(C.c_void_p)]
+    lib.pcq_query_resident_free.argtypes = [C.c_void_p]
+    lib.pcq_query_resident_count_bounds.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint64),
+                                                    C.POINTER(C.c_uint64)]
+    lib.pcq_query_resident_count_class.argtypes = [C.c_void_p, C.c_uint8, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    arr = (C.c_char_p * len(lasts))(*[p.encode() for p in lasts])
+    h = C.c_void_p()
+    assert lib.pcq_query_resident_load(0, arr, len(lasts), C.byref(h)) == 0, lib.pcq_query_last_error()
+    try:
+        for bmin, bmax in BOXES:
+            want = scanned_want = 0
+            for path in lasts:
+                oc = oracle.count_collector()
+                assert oracle.search_file(path, 0, bmin, bmax, 0, oc)[0] == 0
+                want += oc.point_count()
+                oc.free()
+            got, scanned = C.c_uint64(), C.c_uint64()
+            for _ in range(2):  # the second time the segment table is already in HBM
+                assert lib.pcq_query_resident_count_bounds(h, q.d3(bmin), q.d3(bmax), C.byref(got), C.byref(scanned)) == 0
+                assert got.value == want, (bmin, bmax)
+        for cls in (6, 134, 2, 19):
+            want = 0
+            for path in lasts:
+                oc = oracle.count_collector()
+                assert oracle.search_file(path, 1, None, None, cls, oc)[0] == 0
+                want += oc.point_count()
+                oc.free()
+            got, scanned = C.c_uint64(), C.c_uint64()
+            assert lib.pcq_query_resident_count_class(h, cls, C.byref(got), C.byref(scanned)) == 0
+            assert got.value == want and scanned.value == sum(70_001 + 13 * f for f in (0, 1, 2, 3))
+        # a box whose min exceeds its max panics like AABB::from_min_max (main.rs:80-91)
+        assert lib.pcq_query_resident_count_bounds(h, q.d3((1, 1, 1)), q.d3((0, 2, 2)), C.byref(got), C.byref(scanned)) == -7
+        # a .las file is refused: the batched kernels read LAST column blocks
+        h2 = C.c_void_p()
+        bad = (C.c_char_p * 1)([f for f in files if f.endswith(".las")][0].encode())
+        assert lib.pcq_query_resident_load(0, bad, 1, C.byref(h2)) == -4
+    finally:
+        lib.pcq_query_resident_free(h)

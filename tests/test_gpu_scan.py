@@ -423,6 +423,29 @@ def test_synth_device_generator_is_bit_identical(oracle, gpu_ctx):
         assert np.array_equal(gc, cls_h)
 
 
+def test_allreduce_single_rank_through_the_real_rccl_calls(gpu_ctx):
+    """With option "allreduce_single_rank" a ONE-rank all-reduce still binds RCCL at run time (dlopen, the six symbols),
+    builds a communicator of one device and runs ncclAllReduce(sum, ncclUint64 = 5, count 1) on the context's stream:
+    the whole call path of the multi-GPU merge (main.rs:164-180), minus a second GPU.  Two entries on one device are
+    refused (one rank per GPU)."""
+    d = gpu_ctx.alloc(16)
+    gpu_ctx.to_device(d, np.array([98765432109876543], dtype=np.uint64))
+    ctxs = (C.c_void_p * 2)(gpu_ctx.handle.value, gpu_ctx.handle.value)
+    ptrs = (C.c_void_p * 2)(d, d)
+    gpu_ctx.set_option("allreduce_single_rank", 1)
+    try:
+        for _ in range(3):  # the communicator is built once and reused
+            assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, ptrs, 1) == 0, gpu_ctx.lib.pcq_last_error()
+        out = np.zeros(1, dtype=np.uint64)
+        gpu_ctx.to_host(out, d)
+        assert int(out[0]) == 98765432109876543
+        assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, ptrs, 2) == -8  # PCQ_ERR_ARG: both on device 0
+        assert b"one rank per GPU" in gpu_ctx.lib.pcq_last_error()
+    finally:
+        gpu_ctx.set_option("allreduce_single_rank", 0)
+        gpu_ctx.free(d)
+
+
 def test_allreduce_entry_point_single_rank(gpu_ctx):
     """pcq_allreduce_sum_u64 with one rank is the identity (the n > 1 RCCL path needs several GPUs)."""
     d = gpu_ctx.alloc(16)
@@ -538,3 +561,45 @@ def test_scan_host_nowait_lets_the_caller_reuse_its_buffer(oracle, gpu_ctx):
         cc.free(), bc.free()
     finally:
         gpu_ctx.set_option("chunk_points", 2 << 20)
+
+
+@pytest.mark.parametrize("n", [3_000, 400_003])
+def test_grid_massive_aliasing_is_replayed_exactly(oracle, gpu_ctx, n):
+    """A grid box much smaller than the data it is fed: almost every matched point lands in a cell >= 2^bits, whose key
+    aliases onto another cell's while the distance is taken to its OWN centre (grid_sampling.rs:62-82) — the fold's
+    result then depends on the visiting order, and every aliased key is replayed in file order.  The short list goes
+    through the quadratic rank kernel, the long one (n = 400 003: ~10^5 aliased tuples) through the radix sort."""
+    spec = small_spec(4711 + n, n, fmt=2)
+    image = oracle.synth_image(spec, transposed=True)
+    hdr = oracle.parse_header(image[:400].tobytes())
+    f = DevFile(gpu_ctx, image, hdr)
+    try:
+        pbox = ((-60.0, -60.0, -12.0), (60.0, 60.0, 12.0))          # the predicate: (nearly) everything
+        for gmin, gmax, cell in [((-3.0, -3.0, -1.0), (5.0, 5.0, 1.0), 1.0),     # dims 8 x 8 x 2: powers of two, masks alias
+                                 ((0.0, 0.0, 0.0), (3.0, 2.5, 0.7), 0.4)]:        # dims 8 x 7 x 2
+            og = oracle.grid_collector(gmin, gmax, cell)
+            assert oracle.search_last_bounds(image, pbox[0], pbox[1], og) == 0
+            lmin, lmax = pkg.box_to_local(pbox[0], pbox[1], list(hdr.scale), list(hdr.offset))
+            for pieces in (1, 3):  # one scan, and three scans into the same collector with a fold in between
+                gg = gpu_ctx.grid_collector(gmin, gmax, cell)
+                assert gg.grid_params() == og.grid_params()
+                step = (n + pieces - 1) // pieces
+                for k in range(pieces):
+                    first, count = k * step, min(step, n - k * step)
+                    cols = f.columns(True)
+                    cols.xyz += 12 * first
+                    cols.cls += first
+                    cols.rgb += 6 * first
+                    cols.n, cols.first_index = count, first
+                    gpu_ctx.scan_dev(cols, pkg.Predicate.bounds(lmin, lmax), gg)
+                    if pieces > 1:
+                        gg.point_count()
+                assert gg.point_count() == og.point_count()
+                gp, gk = gg.points(), gg.grid_cells()
+                order = np.argsort(gk, kind="stable")
+                assert np.array_equal(gk[order], og.grid_cells())
+                assert gp[order].tobytes() == og.points().tobytes()
+                gg.free()
+            og.free()
+    finally:
+        f.free()

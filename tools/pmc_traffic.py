@@ -37,7 +37,7 @@ def run_pass(counter, outdir, bench_args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "pmc.json"))
-    ap.add_argument("--kernel", default="k_bounds_count_batch")
+    ap.add_argument("--kernel", default="k_bounds_count_batch_pipe<2>")
     ap.add_argument("--steps", type=int, default=3)
     args = ap.parse_args()
     bench_args = ["--steps", str(args.steps), "--warmup", "1", "--no-cpu-baseline"]
@@ -48,7 +48,12 @@ def main():
         for line in out.splitlines():
             if line.startswith("{") and '"metric"' in line:
                 bench_line = json.loads(line)
-        vals = [float(r["Counter_Value"]) for r in rows if args.kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter]
+        hits = [r for r in rows if args.kernel in r.get("Kernel_Name", "") and r.get("Counter_Name") == counter]
+        vals = [float(r["Counter_Value"]) for r in hits]
+        names = sorted({r["Kernel_Name"] for r in hits})
+        if len(names) != 1:
+            raise SystemExit(f"--kernel {args.kernel!r} matches {len(names)} kernels in the {counter} pass: {names}")
+        summary["kernel_name"] = names[0]  # exactly as the counter CSV has it
         summary[counter + "_raw_kib_per_launch"] = sum(vals) / len(vals) if vals else None
         summary[counter + "_launches"] = len(vals)
     f, w = summary.get("FETCH_SIZE_raw_kib_per_launch"), summary.get("WRITE_SIZE_raw_kib_per_launch")
@@ -56,8 +61,12 @@ def main():
         summary["hbm_read_bytes_per_launch"] = 2.0 * f * 1024.0
         summary["hbm_write_bytes_per_launch"] = w * 1024.0
         summary["hbm_bytes_per_launch"] = summary["hbm_read_bytes_per_launch"] + summary["hbm_write_bytes_per_launch"]
+    summary["git_head"] = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or "unknown"
     if bench_line:
         rl = bench_line["roofline"]
+        summary["kernel_source_id"] = rl.get("kernel_source_id")
+        if rl.get("kernel") not in summary.get("kernel_name", ""):
+            raise SystemExit(f"bench.py timed {rl.get('kernel')!r}, the counters are of {summary.get('kernel_name')!r}")
         summary["algorithmic_bytes_per_launch"] = rl["algorithmic_bytes_per_launch"]
         summary["points_per_launch"] = int(round(rl["algorithmic_bytes_per_launch"] / 12))
         if summary.get("hbm_bytes_per_launch"):
