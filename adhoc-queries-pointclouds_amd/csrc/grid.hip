@@ -740,18 +740,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
     // and the first chunk of the current partition's tuples
     uint32_t cur_lo = 0, cur_cnt = 0, nxt_lo = 0, nxt_cnt = 0;
     uint64_t cur_out = 0, nxt_out = 0;
-    GridTuple first[FOLD_K];
+    GridTuple first[XPART ? FOLD_K : 1];
+    bool have_first = false;  // first[] holds the first chunk of the current partition (prefetched by the direct path)
     uint32_t p = blockIdx.x;
-    if (p < nparts) {
-        cur_lo = sg0.off[p], cur_cnt = sg0.off[p + 1] - cur_lo, cur_out = P.wbase[p];
-        if (XPART) {
-#pragma unroll
-            for (int k = 0; k < FOLD_K; k++) {
-                const uint32_t i = k * NT + threadIdx.x;
-                first[k] = ld_tuple(sg0.tuples + cur_lo + (i < cur_cnt ? i : (cur_cnt ? cur_cnt - 1 : 0)));
-            }
-        }
-    }
+    if (p < nparts) cur_lo = sg0.off[p], cur_cnt = sg0.off[p + 1] - cur_lo, cur_out = P.wbase[p];
     for (; p < nparts; p += gridDim.x) {
         const uint32_t pn = p + gridDim.x;
         if (pn < nparts) nxt_lo = sg0.off[pn], nxt_cnt = sg0.off[pn + 1] - nxt_lo, nxt_out = P.wbase[pn];
@@ -789,16 +781,117 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
         }
         if (n_old) __syncthreads();
 
-        for (int r = 0; r < P.nsegs; r++) {
-            const GridSeg sg = r == 0 ? sg0 : P.segs[r];
-            const uint32_t lo = r == 0 ? cur_lo : sg.off[p], cnt = r == 0 ? cur_cnt : sg.off[p + 1] - lo;
-            if (cnt == 0) continue;
-            for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
-                GridTuple tu[FOLD_K];
-                uint64_t dbits[FOLD_K];
-                int slot[FOLD_K];
-                if (XPART) {
-                    if (r == 0 && c0 == 0) {
+        // The common partition of a dense grid: one segment, at most one chunk of tuples, no earlier winners.  Every thread
+        // still holds its tuples when the winners are known, so the winner of a cell writes its record straight from
+        // registers — no payload parked in LDS, no sweep over the table's slots.
+        if (XPART && P.nsegs == 1 && n_old == 0 && cur_cnt <= CHUNK) {
+            const uint32_t cnt = cur_cnt;
+            GridTuple tu[FOLD_K];
+            uint64_t dbits[FOLD_K];
+            int slot[FOLD_K];
+            if (have_first) {
+#pragma unroll
+                for (int k = 0; k < FOLD_K; k++) tu[k] = first[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < FOLD_K; k++) {
+                    const uint32_t i = k * NT + threadIdx.x;
+                    tu[k] = ld_tuple(sg0.tuples + cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0)));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) {  // phase 1: cells and their minimum distance
+                const uint32_t i = k * NT + threadIdx.x;
+                slot[k] = -1;
+                if (i >= cnt) continue;
+                const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
+                dbits[k] = ev.dbits;
+                const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, hash64(ev.key), &s_ncell);
+                if (s < 0) {
+                    s_over = 1;
+                    continue;
+                }
+                slot[k] = s;
+                if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
+                if (ev.dbits < __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
+            }
+            have_first = pn < nparts;
+            if (have_first) {  // the next partition's tuples are on their way while this one is finished
+#pragma unroll
+                for (int k = 0; k < FOLD_K; k++) {
+                    const uint32_t i = k * NT + threadIdx.x;
+                    first[k] = ld_tuple(sg0.tuples + nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0)));
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++)  // phase 2: among the tuples at the minimum, the earliest in file order
+                if (slot[k] >= 0 && dbits[k] == s_dist[slot[k]]) atomicMin((unsigned long long *)&s_ord[slot[k]], (unsigned long long)ord_of(tu[k]));
+            __syncthreads();
+            if (s_over) {
+                if (threadIdx.x == 0) {
+                    P.wcount[p] = 0;
+                    atomicAdd(&P.stats[1], 1ull);
+                }
+            } else {
+                // every occupied slot has exactly one tuple at (minimum distance, earliest order): its thread writes the cell
+                bool win[FOLD_K];
+                uint32_t mine = 0;
+#pragma unroll
+                for (int k = 0; k < FOLD_K; k++) {
+                    win[k] = slot[k] >= 0 && dbits[k] == s_dist[slot[k]] && s_ord[slot[k]] == ord_of(tu[k]);
+                    mine += win[k] ? 1 : 0;
+                }
+                uint32_t incl = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t up = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += up;
+                }
+                if (lane == 63) s_wsum[wave] = incl;
+                __syncthreads();
+                uint32_t before = incl - mine, total = 0;
+                for (int w = 0; w < NT / 64; w++) {
+                    before += w < wave ? s_wsum[w] : 0;
+                    total += s_wsum[w];
+                }
+                bool any_alias = false;
+                uint64_t o = out_base + before;
+#pragma unroll
+                for (int k = 0; k < FOLD_K; k++) {
+                    if (!win[k]) continue;
+                    const int sl = slot[k];
+                    P.wkeys[o] = s_key[sl];
+                    uint8_t *dst = P.wrecs + o * 32;
+                    if ((s_aliasbits[sl >> 5] >> (sl & 31)) & 1) {  // left to the exact replay: no point yet, the flag
+                        any_alias = true;
+                        reinterpret_cast<uint4 *>(dst)[0] = make_uint4(0, 0, 0, 0);
+                        reinterpret_cast<uint4 *>(dst)[1] = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
+                    } else {
+                        st_record(dst, P.entries.get((tu[k].w0 >> 8) & 0xff), tu[k].x, tu[k].y, tu[k].z, tu[k].w0, tu[k].w1, R_HAS);
+                    }
+                    o++;
+                }
+                if (__syncthreads_or(any_alias) && threadIdx.x == 0) {
+                    P.palias[p] = 1;
+                    atomicAdd(&P.stats[2], 1ull);
+                }
+                if (threadIdx.x == 0) {
+                    P.wcount[p] = total;
+                    if (total) atomicAdd(&P.stats[0], (unsigned long long)total);
+                }
+            }
+        } else {
+            for (int r = 0; r < P.nsegs; r++) {
+                const GridSeg sg = r == 0 ? sg0 : P.segs[r];
+                const uint32_t lo = r == 0 ? cur_lo : sg.off[p], cnt = r == 0 ? cur_cnt : sg.off[p + 1] - lo;
+                if (cnt == 0) continue;
+                for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
+                    GridTuple tu[FOLD_K];
+                    uint64_t dbits[FOLD_K];
+                    int slot[FOLD_K];
+                    if (r == 0 && c0 == 0 && have_first) {
 #pragma unroll
                         for (int k = 0; k < FOLD_K; k++) tu[k] = first[k];
                     } else {
@@ -808,142 +901,123 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                             tu[k] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
                         }
                     }
-                    if (r == 0 && c0 + CHUNK >= cnt && pn < nparts) {  // the next partition's first chunk is on its way while this one is folded
-#pragma unroll
-                        for (int k = 0; k < FOLD_K; k++) {
-                            const uint32_t i = k * NT + threadIdx.x;
-                            first[k] = ld_tuple(sg0.tuples + nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0)));
-                        }
-                    }
-                } else {
+                    // phase 1: cells and their minimum distance
 #pragma unroll
                     for (int k = 0; k < FOLD_K; k++) {
                         const uint32_t i = c0 + k * NT + threadIdx.x;
-                        tu[k] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
-                    }
-                }
-                // phase 1: cells and their minimum distance
-#pragma unroll
-                for (int k = 0; k < FOLD_K; k++) {
-                    const uint32_t i = c0 + k * NT + threadIdx.x;
-                    slot[k] = -1;
-                    if (i >= cnt) continue;
-                    const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
-                    dbits[k] = ev.dbits;
-                    const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, hash64(ev.key), &s_ncell);
-                    if (s < 0) {
-                        s_over = 1;
-                        continue;
-                    }
-                    slot[k] = s;
-                    if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
-                    // most tuples of a coarse grid cannot lower the minimum: a plain read first (a stale value is only too large)
-                    if (ev.dbits < __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                        const uint64_t old = atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
-                        if (ev.dbits < old) s_ord[s] = ~0ull;  // a new minimum: whoever held the cell is out (racing writers store the same value)
-                    }
-                }
-                __syncthreads();
-                // phase 2: among the tuples at the minimum, the earliest in file order
-#pragma unroll
-                for (int k = 0; k < FOLD_K; k++) {
-                    if (slot[k] < 0) continue;
-                    if (dbits[k] == s_dist[slot[k]]) atomicMin((unsigned long long *)&s_ord[slot[k]], (unsigned long long)ord_of(tu[k]));
-                }
-                __syncthreads();
-                // phase 3: a winner from this chunk parks its payload
-#pragma unroll
-                for (int k = 0; k < FOLD_K; k++) {
-                    const int s = slot[k];
-                    if (s < 0) continue;
-                    if (dbits[k] == s_dist[s] && s_ord[s] == ord_of(tu[k])) {
-                        pay[s * 5] = (uint32_t)tu[k].x, pay[s * 5 + 1] = (uint32_t)tu[k].y, pay[s * 5 + 2] = (uint32_t)tu[k].z;
-                        pay[s * 5 + 3] = tu[k].w0, pay[s * 5 + 4] = tu[k].w1;
-                        atomicAnd(&s_oldbits[s >> 5], ~(1u << (s & 31)));
-                    }
-                }
-                // no barrier here: the next chunk's phase 1 can only make this test fail for a slot whose winner is
-                // about to be replaced, and every thread passes the barrier behind it before anyone parks again
-            }
-        }
-        if (XPART && cur_cnt == 0 && pn < nparts) {  // an empty first segment never reached the prefetch above
-#pragma unroll
-            for (int k = 0; k < FOLD_K; k++) {
-                const uint32_t i = k * NT + threadIdx.x;
-                first[k] = ld_tuple(sg0.tuples + nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0)));
-            }
-        }
-        if (!PAY_LDS) __threadfence();  // the parked payloads are read back by other threads of the workgroup
-        __syncthreads();
-        if (s_over) {  // more cells than the table holds: the host repeats the fold with more partitions
-            if (threadIdx.x == 0) {
-                P.wcount[p] = 0;
-                atomicAdd(&P.stats[1], 1ull);
-            }
-        } else {
-            // compaction: thread t owns slots [t * SPT, ...): winners leave in slot order
-            uint32_t mine = 0;
-            const int s0 = threadIdx.x * SPT;
-#pragma unroll
-            for (int j = 0; j < SPT; j++) mine += (s0 + j < NSLOT && s_key[s0 + j] != PCQ_EMPTY_KEY) ? 1 : 0;
-            uint32_t incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t up = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += up;
-            }
-            if (lane == 63) s_wsum[wave] = incl;
-            __syncthreads();
-            uint32_t before = incl - mine, total = 0;
-            for (int w = 0; w < NT / 64; w++) {
-                before += w < wave ? s_wsum[w] : 0;
-                total += s_wsum[w];
-            }
-            bool any_alias = false;
-            uint64_t o = out_base + before;
-#pragma unroll
-            for (int j = 0; j < SPT; j++) {
-                const int s = s0 + j;
-                if (s >= NSLOT || s_key[s] == PCQ_EMPTY_KEY) continue;
-                const uint64_t key = s_key[s];
-                P.wkeys[o] = key;
-                uint8_t *dst = P.wrecs + o * 32;
-                const bool alias = (s_aliasbits[s >> 5] >> (s & 31)) & 1, old = (s_oldbits[s >> 5] >> (s & 31)) & 1;
-                if (alias) {  // left to the exact replay: the state before this fold (the earlier winner, if there is one) + the flag
-                    any_alias = true;
-                    uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
-                    for (uint32_t i = 0; i < n_old; i++)
-                        if (P.okeys[old_base + i] == key) {
-                            const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + (old_base + i) * 32);
-                            a = sp[0], b = sp[1];
-                            b.w |= (uint32_t)R_ALIAS << 24;
-                            break;
+                        slot[k] = -1;
+                        if (i >= cnt) continue;
+                        const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
+                        dbits[k] = ev.dbits;
+                        const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, hash64(ev.key), &s_ncell);
+                        if (s < 0) {
+                            s_over = 1;
+                            continue;
                         }
-                    reinterpret_cast<uint4 *>(dst)[0] = a;
-                    reinterpret_cast<uint4 *>(dst)[1] = b;
-                } else {
-                    uint32_t w[5];
-#pragma unroll
-                    for (int q = 0; q < 5; q++)
-                        w[q] = PAY_LDS ? pay[s * 5 + q] : __hip_atomic_load(&pay[s * 5 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (old) {
-                        const uint64_t oi = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
-                        const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + oi * 32);
-                        reinterpret_cast<uint4 *>(dst)[0] = sp[0];
-                        reinterpret_cast<uint4 *>(dst)[1] = sp[1];
-                    } else {
-                        st_record(dst, P.entries.get((w[3] >> 8) & 0xff), (int32_t)w[0], (int32_t)w[1], (int32_t)w[2], w[3], w[4], R_HAS);
+                        slot[k] = s;
+                        if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
+                        // most tuples of a coarse grid cannot lower the minimum: a plain read first (a stale value is only too large)
+                        if (ev.dbits < __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                            const uint64_t old = atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
+                            if (ev.dbits < old) s_ord[s] = ~0ull;  // a new minimum: whoever held the cell is out (racing writers store the same value)
+                        }
                     }
+                    __syncthreads();
+                    // phase 2: among the tuples at the minimum, the earliest in file order
+#pragma unroll
+                    for (int k = 0; k < FOLD_K; k++) {
+                        if (slot[k] < 0) continue;
+                        if (dbits[k] == s_dist[slot[k]]) atomicMin((unsigned long long *)&s_ord[slot[k]], (unsigned long long)ord_of(tu[k]));
+                    }
+                    __syncthreads();
+                    // phase 3: a winner from this chunk parks its payload
+#pragma unroll
+                    for (int k = 0; k < FOLD_K; k++) {
+                        const int s = slot[k];
+                        if (s < 0) continue;
+                        if (dbits[k] == s_dist[s] && s_ord[s] == ord_of(tu[k])) {
+                            pay[s * 5] = (uint32_t)tu[k].x, pay[s * 5 + 1] = (uint32_t)tu[k].y, pay[s * 5 + 2] = (uint32_t)tu[k].z;
+                            pay[s * 5 + 3] = tu[k].w0, pay[s * 5 + 4] = tu[k].w1;
+                            atomicAnd(&s_oldbits[s >> 5], ~(1u << (s & 31)));
+                        }
+                    }
+                    // no barrier here: the next chunk's phase 1 can only make this test fail for a slot whose winner is
+                    // about to be replaced, and every thread passes the barrier behind it before anyone parks again
                 }
-                o++;
             }
-            if (__syncthreads_or(any_alias) && threadIdx.x == 0) {
-                P.palias[p] = 1;
-                atomicAdd(&P.stats[2], 1ull);
-            }
-            if (threadIdx.x == 0) {
-                P.wcount[p] = total;
-                if (total) atomicAdd(&P.stats[0], (unsigned long long)total);
+            have_first = false;  // the generic path does not prefetch
+            if (!PAY_LDS) __threadfence();  // the parked payloads are read back by other threads of the workgroup
+            __syncthreads();
+            if (s_over) {  // more cells than the table holds: the host repeats the fold with more partitions
+                if (threadIdx.x == 0) {
+                    P.wcount[p] = 0;
+                    atomicAdd(&P.stats[1], 1ull);
+                }
+            } else {
+                // compaction: thread t owns slots [t * SPT, ...): winners leave in slot order
+                uint32_t mine = 0;
+                const int s0 = threadIdx.x * SPT;
+#pragma unroll
+                for (int j = 0; j < SPT; j++) mine += (s0 + j < NSLOT && s_key[s0 + j] != PCQ_EMPTY_KEY) ? 1 : 0;
+                uint32_t incl = mine;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t up = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += up;
+                }
+                if (lane == 63) s_wsum[wave] = incl;
+                __syncthreads();
+                uint32_t before = incl - mine, total = 0;
+                for (int w = 0; w < NT / 64; w++) {
+                    before += w < wave ? s_wsum[w] : 0;
+                    total += s_wsum[w];
+                }
+                bool any_alias = false;
+                uint64_t o = out_base + before;
+#pragma unroll
+                for (int j = 0; j < SPT; j++) {
+                    const int s = s0 + j;
+                    if (s >= NSLOT || s_key[s] == PCQ_EMPTY_KEY) continue;
+                    const uint64_t key = s_key[s];
+                    P.wkeys[o] = key;
+                    uint8_t *dst = P.wrecs + o * 32;
+                    const bool alias = (s_aliasbits[s >> 5] >> (s & 31)) & 1, old = (s_oldbits[s >> 5] >> (s & 31)) & 1;
+                    if (alias) {  // left to the exact replay: the state before this fold (the earlier winner, if there is one) + the flag
+                        any_alias = true;
+                        uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
+                        for (uint32_t i = 0; i < n_old; i++)
+                            if (P.okeys[old_base + i] == key) {
+                                const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + (old_base + i) * 32);
+                                a = sp[0], b = sp[1];
+                                b.w |= (uint32_t)R_ALIAS << 24;
+                                break;
+                            }
+                        reinterpret_cast<uint4 *>(dst)[0] = a;
+                        reinterpret_cast<uint4 *>(dst)[1] = b;
+                    } else {
+                        uint32_t w[5];
+#pragma unroll
+                        for (int q = 0; q < 5; q++)
+                            w[q] = PAY_LDS ? pay[s * 5 + q] : __hip_atomic_load(&pay[s * 5 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (old) {
+                            const uint64_t oi = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
+                            const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + oi * 32);
+                            reinterpret_cast<uint4 *>(dst)[0] = sp[0];
+                            reinterpret_cast<uint4 *>(dst)[1] = sp[1];
+                        } else {
+                            st_record(dst, P.entries.get((w[3] >> 8) & 0xff), (int32_t)w[0], (int32_t)w[1], (int32_t)w[2], w[3], w[4], R_HAS);
+                        }
+                    }
+                    o++;
+                }
+                if (__syncthreads_or(any_alias) && threadIdx.x == 0) {
+                    P.palias[p] = 1;
+                    atomicAdd(&P.stats[2], 1ull);
+                }
+                if (threadIdx.x == 0) {
+                    P.wcount[p] = total;
+                    if (total) atomicAdd(&P.stats[0], (unsigned long long)total);
+                }
             }
         }
         cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;

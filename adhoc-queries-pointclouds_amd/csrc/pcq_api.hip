@@ -593,8 +593,9 @@ extern "C" int pcq_collector_reset(pcq_collector *c) {
     c->next_index = 0;
     if (c->kind == COLL_COUNT) PCQ_HIP(hipMemsetAsync(c->d_count, 0, 8, s));
     if (c->kind == COLL_BUFFER) {
-        PCQ_HIP(hipMemsetAsync(c->d_count, 0, 8, s));
+        PCQ_HIP(hipMemsetAsync(c->d_count, 0, 16, s));
         c->n_upper = 0;
+        c->count_slot = 0;
     }
     if (c->kind == COLL_GRID) {
         PCQ_HIP(hipStreamSynchronize(s));
@@ -618,7 +619,7 @@ extern "C" int pcq_collector_point_count(pcq_collector *c, uint64_t *out) {
         *out = ctx->h_scalars[0];
         return PCQ_OK;
     case COLL_BUFFER:
-        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->d_count + c->count_slot, 8, hipMemcpyDeviceToHost, ctx->stream));
         PCQ_HIP(hipStreamSynchronize(ctx->stream));
         *out = ctx->h_scalars[0];
         c->n_upper = ctx->h_scalars[0];
@@ -636,7 +637,7 @@ extern "C" int pcq_collector_points(pcq_collector *c, pcq_point *out, uint64_t c
     if (c->kind == COLL_COUNT) return PCQ_OK;  // points() is None (collect_points.rs:87-93)
     if (c->last_stream && c->last_stream != ctx->stream) PCQ_HIP(hipStreamSynchronize(c->last_stream));
     if (c->kind == COLL_BUFFER) {
-        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->d_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->d_count + c->count_slot, 8, hipMemcpyDeviceToHost, ctx->stream));
         PCQ_HIP(hipStreamSynchronize(ctx->stream));
         const uint64_t n_points = ctx->h_scalars[0];
         c->n_upper = n_points;
@@ -732,7 +733,7 @@ static int buffer_reserve(pcq_collector *c, uint64_t incoming, hipStream_t s) {
     if (c->n_upper + incoming <= c->cap_points) return PCQ_OK;
     pcq_ctx *ctx = c->ctx;
     if (c->last_stream && c->last_stream != s) PCQ_HIP(hipStreamSynchronize(c->last_stream));
-    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->d_count, 8, hipMemcpyDeviceToHost, s));
+    PCQ_HIP(hipMemcpyAsync(ctx->h_scalars, c->d_count + c->count_slot, 8, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipStreamSynchronize(s));
     const uint64_t have = ctx->h_scalars[0];
     c->n_upper = have;
@@ -767,8 +768,9 @@ static int scan_dev_impl(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predic
         if (dp.kind == PCQ_PRED_BOUNDS && dp.empty) return PCQ_OK;
         rc = buffer_reserve(c, dc.n, s);
         if (rc) return rc;
-        rc = pcq_launch_emit_points(ctx, dc, dp, c->d_points, c->d_count, s);  // asynchronous: one pass, no count first
+        rc = pcq_launch_emit_points(ctx, dc, dp, c->d_points, c->d_count + c->count_slot, c->d_count + (c->count_slot ^ 1), s);  // asynchronous: one pass, no count first
         if (rc) return rc;
+        c->count_slot ^= 1;
         c->n_upper += dc.n;
         return PCQ_OK;
     }

@@ -193,6 +193,7 @@ struct pcq_collector {
     // scanned point) and asks the device for the truth when that bound outgrows the buffer.
     uint8_t *d_points = nullptr;
     uint64_t n_upper = 0, cap_points = 0;
+    int count_slot = 0;                 // which of the two words of d_count holds the current count (a scan reads one, writes the other)
     // grid
     double bmin[3], bmax[3], cell_size = 0;
     uint64_t dims[3], bits[3];
@@ -216,7 +217,8 @@ int pcq_launch_class_count_u8(pcq_ctx *ctx, const void *d_cls, uint64_t n, uint8
 // scan_generic.hip
 int pcq_launch_generic_count(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred,
                              uint64_t *d_count, hipStream_t s);
-int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint8_t *d_out31, uint64_t *d_npoints, hipStream_t s);
+int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint8_t *d_out31, const uint64_t *d_npoints_in,
+                           uint64_t *d_npoints_out, hipStream_t s);
 // grid.hip
 int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const DevPred &pred, hipStream_t s);
 void pcq_grid_release(pcq_collector *c);

@@ -7,12 +7,15 @@
 //   * order-preserving emit    — BufferCollector semantics (collect_points.rs:29-31): matches are
 //                                appended in file order, as 31-byte Point records built like
 //                                last.rs:137-163.
-// The emit is a SINGLE-pass stable stream compaction (decoupled look-back): a workgroup takes the next tile of 2048
-// points, evaluates the predicate once, publishes the tile's match count, finds its output offset by looking back
-// over the tiles in front of it (their counts, or the running prefix the nearest finished one published), and
-// writes each match at offset + rank-in-tile — the rank from a wave64 ballot prefix (popcount(mask & lanes_below))
-// plus an LDS prefix over the block's four waves.  The collector's point count lives on the device: the scan
-// reads it as its base and the last tile moves it on, so nothing comes back to the host between scans.
+// The emit is a stable stream compaction in three launches on one stream, with nothing coming back to the host:
+// (1) k_tile_counts: matches per tile of 2048 points, (2) a three-step exclusive scan of the tile counts on the device,
+// (3) k_emit_points: the predicate again, each match written at collector count + tile offset + rank-in-tile — the rank
+// from wave64 ballot prefixes (popcount(mask & lanes_below)) and the per-(row, wave) counts in LDS.  The collector's
+// point count lives on the device: the emit reads it as its base and stores the new count.
+// A single-pass form (decoupled look-back over the tiles, one read of the positions) was built and measured first: on
+// this chip a look-back round is a cross-XCD round trip of several microseconds and the kernel took 2.8 ms for a
+// 163 M-point file against 1.05 ms for the same kernel with the look-back cut out — the second read of the positions
+// (0.3 ms at the streaming rate) is much cheaper than the dependency chain (profiles/r02_emit_lookback.txt).
 #include "dev_common.h"
 
 using namespace pcqdev;
@@ -61,131 +64,248 @@ __global__ __launch_bounds__(BLOCK) void k_sum_partials(const uint64_t *__restri
     if (threadIdx.x == 0) atomicAdd((unsigned long long *)d_count, (unsigned long long)s[0]);
 }
 
-// Tile states of the look-back: the top two bits say what the low 62 hold.
-constexpr uint64_t ST_AGG = 1ull << 62;     // the tile's own match count
-constexpr uint64_t ST_PREFIX = 2ull << 62;  // matches of this tile and of every tile in front of it
-constexpr uint64_t ST_VALUE = (1ull << 62) - 1;
-
 // 31-byte records at a 31-byte pitch are hostile to per-lane stores (31 byte-stores per match, 16
 // cache lines touched per wave-instruction).  The block instead assembles the records of 1024 input
 // points in LDS, laid out congruent (mod 16) to their final global position, and then streams the
 // contiguous byte range out with 16-byte stores; only the two ragged ends use byte stores, so
 // neighbouring blocks never write the same 16-byte chunk.
+constexpr int EMIT_ITEMS = 8;                                   // points per thread and tile: 2048-point tiles
+constexpr int EMIT_TILE = BLOCK * EMIT_ITEMS;
 constexpr int FLUSH_ITEMS = 4;                                  // input rows of 256 points per LDS flush
 constexpr int STAGE_BYTES = FLUSH_ITEMS * BLOCK * 31 + 16;      // 31,760 B: five blocks per CU fit in LDS
+constexpr int STAGE_WORDS = (STAGE_BYTES + 3) / 4 + 9;          // + the dwords a record's last OR may touch
 
-template <int KIND>
-__global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, uint64_t *__restrict__ tile_state, uint32_t *__restrict__ ticket,
-                                                       uint64_t *__restrict__ d_npoints, uint8_t *__restrict__ out31, uint32_t ntiles) {
-    __shared__ uint32_t s_w[WAVES];
-    __shared__ uint32_t s_tile;
-    __shared__ uint64_t s_before, s_base;
-    __shared__ __attribute__((aligned(16))) uint8_t s_stage[STAGE_BYTES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // tiles are handed out in launch order, so every tile a workgroup looks back at belongs to a workgroup that is
-    // already running (or done): the wait below always ends
-    if (threadIdx.x == 0) {
-        s_tile = atomicAdd(ticket, 1u);
-        s_base = *d_npoints;  // points in the collector before this scan; read before this tile publishes anything
-    }
-    __syncthreads();
-    const uint32_t tile = s_tile;
-    const uint64_t base = (uint64_t)tile * TILE;
-
-    // the predicate, once: all ITEMS loads of a thread are issued before the first compare
-    RawPoint rps[ITEMS];
-    bool passes[ITEMS];
+// A 31-byte record lands at an arbitrary byte offset of the LDS image, and neighbouring records share dwords.  Byte
+// stores cost 31 LDS instructions per record (the LDS pipe, not HBM, then bounds the emit); instead the record is
+// shifted into place as nine dwords and OR-ed into an image that starts out zero — nine LDS operations, no read.
+__device__ __forceinline__ void or_point31(uint32_t *image, uint32_t byte_offset, const pcq_point &p) {
+    const uint64_t bx = (uint64_t)__double_as_longlong(p.x), by = (uint64_t)__double_as_longlong(p.y), bz = (uint64_t)__double_as_longlong(p.z);
+    const uint32_t src[8] = {(uint32_t)bx, (uint32_t)(bx >> 32), (uint32_t)by, (uint32_t)(by >> 32), (uint32_t)bz, (uint32_t)(bz >> 32),
+                             (uint32_t)p.r | ((uint32_t)p.g << 16), (uint32_t)p.b | ((uint32_t)p.classification << 16)};  // byte 31 = 0
+    const uint32_t d0 = byte_offset >> 2, back = 32u - 8u * (byte_offset & 3u);  // 32, 24, 16 or 8
+    uint32_t prev = 0;
 #pragma unroll
-    for (int j = 0; j < ITEMS; j++) {
-        const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
-        passes[j] = eval_pred_kind<KIND>(c, pr, i < c.n ? i : c.n - 1, rps[j]) & (i < c.n);
+    for (int d = 0; d < 9; d++) {
+        const uint32_t cur = d < 8 ? src[d] : 0u;
+        const uint32_t v = (uint32_t)((((uint64_t)cur << 32) | prev) >> back);
+        if (v) atomicOr(&image[d0 + d], v);
+        prev = cur;
     }
+}
+
+// What a tile's threads need from HBM: the predicate's inputs and — for the emit — the attributes a match's record carries.
+template <int KIND, bool ATTRS>
+struct TileIn {
+    RawPoint rps[EMIT_ITEMS];
+    bool passes[EMIT_ITEMS];
+    uint32_t attr_cls[EMIT_ITEMS], attr_rg[EMIT_ITEMS], attr_b[EMIT_ITEMS];
+};
+// Everything is requested together, before the first compare.  (Loading the attributes where the record is built — behind
+// the ranks, one dependent round trip per row of 256 points — left the waves waiting 80 % of the time.)
+template <int KIND, bool ATTRS>
+__device__ __forceinline__ void tile_load_and_test(const DevCols &c, const DevPred &pr, uint64_t base, TileIn<KIND, ATTRS> &T) {
+#pragma unroll
+    for (int j = 0; j < EMIT_ITEMS; j++) {
+        const uint64_t i0 = base + (uint64_t)j * BLOCK + threadIdx.x, i = i0 < c.n ? i0 : c.n - 1;
+        T.attr_cls[j] = (ATTRS || KIND == PCQ_PRED_CLASS) && c.cls ? c.cls[i * c.cls_stride] : 0;  // last.rs:138-142
+        T.attr_rg[j] = T.attr_b[j] = 0;
+        if (ATTRS && c.rgb) {  // last.rs:145-153
+            const uint8_t *q = c.rgb + i * c.rgb_stride;
+            T.attr_rg[j] = (uint32_t)ld_u16(q) | ((uint32_t)ld_u16(q + 2) << 16);
+            T.attr_b[j] = ld_u16(q + 4);
+        }
+        if (KIND != PCQ_PRED_CLASS) T.rps[j] = ld_xyz(c, i);
+    }
+#pragma unroll
+    for (int j = 0; j < EMIT_ITEMS; j++) {
+        const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
+        bool pass;
+        if (KIND == PCQ_PRED_CLASS) pass = T.attr_cls[j] == pr.cls;
+        else if (KIND == PCQ_PRED_BOUNDS)
+            pass = (pr.empty == 0) & ((uint32_t)(T.rps[j].x - pr.lo[0]) <= pr.width[0]) & ((uint32_t)(T.rps[j].y - pr.lo[1]) <= pr.width[1]) &
+                   ((uint32_t)(T.rps[j].z - pr.lo[2]) <= pr.width[2]);
+        else {
+            const double wx = c.offset[0] + c.scale[0] * (double)T.rps[j].x, wy = c.offset[1] + c.scale[1] * (double)T.rps[j].y,
+                         wz = c.offset[2] + c.scale[2] * (double)T.rps[j].z;
+            pass = !((wx < pr.wmin[0]) | (wy < pr.wmin[1]) | (wz < pr.wmin[2]) | (wx > pr.wmax[0]) | (wy > pr.wmax[1]) | (wz > pr.wmax[2]));
+        }
+        T.passes[j] = pass & (i < c.n);
+    }
+}
+
+// Launch 1: counts[tile] = matches among the tile's 2048 points.
+template <int KIND>
+__global__ __launch_bounds__(BLOCK) void k_tile_counts(DevCols c, DevPred pr, uint64_t *__restrict__ counts) {
+    __shared__ uint32_t s_w[WAVES];
+    TileIn<KIND, false> T;
+    tile_load_and_test<KIND, false>(c, pr, (uint64_t)blockIdx.x * EMIT_TILE, T);
     uint32_t cnt = 0;
 #pragma unroll
-    for (int j = 0; j < ITEMS; j++) cnt += (uint32_t)__popcll(__ballot(passes[j]));  // wave-uniform
-    if (lane == 0) s_w[wave] = cnt;
+    for (int j = 0; j < EMIT_ITEMS; j++) cnt += (uint32_t)__popcll(__ballot(T.passes[j]));  // wave-uniform
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
     __syncthreads();
-    uint32_t total = 0;
-#pragma unroll
-    for (int w = 0; w < WAVES; w++) total += s_w[w];
-
-    if (wave == 0) {  // publish, then look back: 64 predecessors at a time, nearest first
-        if (lane == 0)
-            __hip_atomic_store(&tile_state[tile], (tile == 0 ? ST_PREFIX : ST_AGG) | (uint64_t)total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        uint64_t before = 0;
-        int64_t look = (int64_t)tile - 1;
-        while (look >= 0) {
-            const int64_t t = look - lane;
-            uint64_t v = ST_PREFIX;  // lanes in front of tile 0 read as "prefix 0"
-            if (t >= 0) {
-                do {
-                    v = __hip_atomic_load(&tile_state[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                    if (!(v >> 62)) __builtin_amdgcn_s_sleep(1);
-                } while (!(v >> 62));
-            }
-            const uint64_t has_prefix = __ballot((v & ST_PREFIX) != 0);
-            const int stop = has_prefix ? __builtin_ctzll(has_prefix) : 63;  // the nearest tile that knows everything in front of it
-            uint64_t part = lane <= stop ? (v & ST_VALUE) : 0;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) part += __shfl_down((unsigned long long)part, off, 64);
-            before += __shfl((unsigned long long)part, 0, 64);
-            if (has_prefix) break;
-            look -= 64;
-        }
-        if (lane == 0) {
-            if (tile > 0)
-                __hip_atomic_store(&tile_state[tile], ST_PREFIX | (before + total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-            s_before = before;
-            if (tile == ntiles - 1) *d_npoints = s_base + before + total;  // every tile has read the old value: they all published before this one got here
-        }
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < WAVES; w++) t += s_w[w];
+        counts[blockIdx.x] = t;
     }
-    __syncthreads();
-    uint64_t run = s_base + s_before;  // record index of the block's next match
-#pragma unroll 1
-    for (int h = 0; h < ITEMS / FLUSH_ITEMS; h++) {
-        const uint64_t gbyte0 = run * 31ull;
-        const uint32_t pad = (uint32_t)(gbyte0 & 15);
-        uint32_t seg = 0;  // matches staged so far (block-uniform)
+}
+
+// Launch 2 (three small kernels): exclusive prefix of the tile counts; out[n] = the total.
+constexpr int SCAN_PIECE = 4096;
+__global__ __launch_bounds__(1024) void k_scan_piece_sums(const uint64_t *__restrict__ in, uint32_t n, uint64_t *__restrict__ sums) {
+    __shared__ uint64_t s_wave[16];
+    const uint32_t base = blockIdx.x * SCAN_PIECE;
+    uint64_t v = 0;
+    for (int k = 0; k < SCAN_PIECE / 1024; k++) {
+        const uint32_t i = base + k * 1024 + threadIdx.x;
+        v += i < n ? in[i] : 0;
+    }
 #pragma unroll
-        for (int jj = 0; jj < FLUSH_ITEMS; jj++) {
-            const int j = h * FLUSH_ITEMS + jj;
-            const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
-            RawPoint rp = rps[j];
-            const bool have = KIND != PCQ_PRED_CLASS;
-            const bool pass = passes[j];
-            const uint64_t mask = __ballot(pass);
-            if (lane == 0) s_w[wave] = (uint32_t)__popcll(mask);
-            __syncthreads();
-            uint32_t before = 0, all = 0;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down((unsigned long long)v, off, 64);
+    if ((threadIdx.x & 63) == 0) s_wave[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t t = 0;
+        for (int w = 0; w < 16; w++) t += s_wave[w];
+        sums[blockIdx.x] = t;
+    }
+}
+// in place over up to 1024 piece sums: sums[i] = sum of the pieces in front of i
+__global__ __launch_bounds__(1024) void k_scan_sums(uint64_t *__restrict__ sums, uint32_t n) {
+    __shared__ uint64_t s_wave[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t v = threadIdx.x < n ? sums[threadIdx.x] : 0;
+    uint64_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t up = __shfl_up((unsigned long long)incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t run = incl - v;
+    for (int w = 0; w < wave; w++) run += s_wave[w];
+    if (threadIdx.x < n) sums[threadIdx.x] = run;
+}
+// out[i] = piece_prefix[piece] + exclusive prefix inside the piece (thread t owns 4 consecutive elements); out[n] = total
+__global__ __launch_bounds__(1024) void k_scan_pieces(const uint64_t *__restrict__ in, uint32_t n, const uint64_t *__restrict__ piece_prefix,
+                                                      uint64_t *__restrict__ out) {
+    __shared__ uint64_t s_wave[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t i0 = blockIdx.x * SCAN_PIECE + threadIdx.x * 4;
+    uint64_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        v[k] = i0 + k < n ? in[i0 + k] : 0;
+        sum += v[k];
+    }
+    uint64_t incl = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint64_t up = __shfl_up((unsigned long long)incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint64_t run = piece_prefix[blockIdx.x] + incl - sum;
+    for (int w = 0; w < wave; w++) run += s_wave[w];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (i0 + k < n) out[i0 + k] = run;
+        run += v[k];
+        if (i0 + k + 1 == n) out[n] = run;
+    }
+}
+
+// Launch 3: tile t's matches go to records [*d_npoints_in + offsets[t], ...), in file order; tile 0 stores the new count.
+template <int KIND>
+__global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, const uint64_t *__restrict__ offsets,
+                                                       const uint64_t *__restrict__ d_npoints_in, uint64_t *__restrict__ d_npoints_out,
+                                                       uint8_t *__restrict__ out31, uint32_t ntiles) {
+    __shared__ uint32_t s_rw[EMIT_ITEMS][WAVES];
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[STAGE_WORDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x;
+    const uint64_t base_count = *d_npoints_in, before = offsets[tile];
+    if (tile == 0 && threadIdx.x == 0) *d_npoints_out = base_count + offsets[ntiles];
+    for (int t = threadIdx.x; t < STAGE_WORDS; t += BLOCK) s_stage[t] = 0;
+    {
+        const uint64_t base = (uint64_t)tile * EMIT_TILE;
+        TileIn<KIND, true> T;
+        tile_load_and_test<KIND, true>(c, pr, base, T);
+        RawPoint (&rps)[EMIT_ITEMS] = T.rps;
+        bool (&passes)[EMIT_ITEMS] = T.passes;
+        uint32_t (&attr_cls)[EMIT_ITEMS] = T.attr_cls, (&attr_rg)[EMIT_ITEMS] = T.attr_rg, (&attr_b)[EMIT_ITEMS] = T.attr_b;
+        if (KIND == PCQ_PRED_CLASS) {  // positions only of the matches (last.rs:265-269), all requested together
+#pragma unroll
+            for (int j = 0; j < EMIT_ITEMS; j++)
+                if (passes[j]) rps[j] = ld_xyz(c, base + (uint64_t)j * BLOCK + threadIdx.x);
+        }
+        // ranks: the matches of row j in wave w sit behind those of the rows in front and of the waves in front in row j
+        uint64_t masks[EMIT_ITEMS];
+#pragma unroll
+        for (int j = 0; j < EMIT_ITEMS; j++) {
+            masks[j] = __ballot(passes[j]);
+            if (lane == 0) s_rw[j][wave] = (uint32_t)__popcll(masks[j]);
+        }
+        __syncthreads();
+        uint32_t row_front[EMIT_ITEMS] = {};  // matches of the tile in front of this thread's wave in row j
+        uint32_t total = 0;
+#pragma unroll
+        for (int j = 0; j < EMIT_ITEMS; j++) {
+            uint32_t in_row = 0;
 #pragma unroll
             for (int w = 0; w < WAVES; w++) {
-                const uint32_t v = s_w[w];
-                before += w < wave ? v : 0;
-                all += v;
+                const uint32_t v = s_rw[j][w];
+                row_front[j] = w == wave ? total + in_row : row_front[j];
+                in_row += v;
             }
-            if (pass) {
-                const uint32_t rank = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                if (!have) rp = ld_xyz(c, i);
+            total += in_row;
+        }
+        uint64_t run = base_count + before;  // record index of the block's next match
+        uint32_t flushed = 0;                // matches of the tile already written
+#pragma unroll  // rps[] / passes[] must be indexed statically to stay in registers
+        for (int h = 0; h < EMIT_ITEMS / FLUSH_ITEMS; h++) {
+            const uint64_t gbyte0 = run * 31ull;
+            const uint32_t pad = (uint32_t)(gbyte0 & 15);
+            uint32_t seg = 0;  // matches of this flush (block-uniform)
+#pragma unroll
+            for (int jj = 0; jj < FLUSH_ITEMS; jj++) {
+                const int j = h * FLUSH_ITEMS + jj;
+                uint32_t in_row = 0;
+#pragma unroll
+                for (int w = 0; w < WAVES; w++) in_row += s_rw[j][w];
+                seg += in_row;
+                if (!passes[j]) continue;
+                const RawPoint rp = rps[j];
+                const uint32_t rank = row_front[j] - flushed + (uint32_t)__popcll(masks[j] & ((1ull << lane) - 1ull));
                 pcq_point pt;
-                make_point(c, i, rp, pt);
-                store_point31(s_stage + pad + 31u * (seg + before + rank), pt);
+                pt.x = world(rp.x, c.scale[0], c.offset[0]);  // last.rs:156-160
+                pt.y = world(rp.y, c.scale[1], c.offset[1]);
+                pt.z = world(rp.z, c.scale[2], c.offset[2]);
+                pt.r = (uint16_t)attr_rg[j], pt.g = (uint16_t)(attr_rg[j] >> 16), pt.b = (uint16_t)attr_b[j];
+                pt.classification = (uint8_t)attr_cls[j];
+                or_point31(s_stage, pad + 31u * rank, pt);
             }
-            seg += all;
             __syncthreads();
-        }
-        const uint32_t total_b = pad + seg * 31u;  // staged image is [pad, total_b)
-        uint8_t *gdst = out31 + (gbyte0 - pad);     // 16-byte aligned (out31 comes from hipMalloc)
-        for (uint32_t b0 = threadIdx.x * 16u; b0 < total_b; b0 += BLOCK * 16u) {
-            const uint32_t b1 = b0 + 16u;
-            if (b0 >= pad && b1 <= total_b) {
-                *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(s_stage + b0);
-            } else {
-                const uint32_t lo = b0 > pad ? b0 : pad, hi = b1 < total_b ? b1 : total_b;
-                for (uint32_t k = lo; k < hi; k++) gdst[k] = s_stage[k];
+            const uint32_t total_b = pad + seg * 31u;  // staged image is [pad, total_b)
+            uint8_t *gdst = out31 + (gbyte0 - pad);     // 16-byte aligned (out31 comes from the pool)
+            const uint8_t *stage8 = reinterpret_cast<const uint8_t *>(s_stage);
+            for (uint32_t b0 = threadIdx.x * 16u; b0 < total_b; b0 += BLOCK * 16u) {
+                const uint32_t b1 = b0 + 16u;
+                if (b0 >= pad && b1 <= total_b) {
+                    *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(stage8 + b0);
+                } else {
+                    const uint32_t lo = b0 > pad ? b0 : pad, hi = b1 < total_b ? b1 : total_b;
+                    for (uint32_t k = lo; k < hi; k++) gdst[k] = stage8[k];
+                }
+                *reinterpret_cast<uint4 *>(s_stage + b0 / 4) = make_uint4(0, 0, 0, 0);  // the image is zero again for the next flush
             }
+            run += seg;
+            flushed += seg;
+            __syncthreads();  // the stage is reused by the next flush
         }
-        run += seg;
-        __syncthreads();  // the stage is reused by the next half
     }
 }
 
@@ -208,21 +328,27 @@ int pcq_launch_generic_count(pcq_ctx *ctx, const DevCols &cols, const DevPred &p
     return PCQ_OK;
 }
 
-// Appends the matches of `cols` to the packed records at d_out31, in file order.  *d_npoints (device) is the number of
-// records in front of them and is moved on by the kernel.  Asynchronous.
-int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint8_t *d_out31, uint64_t *d_npoints, hipStream_t s) {
+// Appends the matches of `cols` to the packed records at d_out31, in file order.  *d_npoints_in (device) is the number
+// of records in front of them; the emit stores the new count in *d_npoints_out.  Asynchronous: five launches, no copy.
+int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint8_t *d_out31, const uint64_t *d_npoints_in,
+                           uint64_t *d_npoints_out, hipStream_t s) {
     if (cols.n == 0) return PCQ_OK;
-    const uint64_t ntiles = (cols.n + TILE - 1) / TILE;
-    if (ntiles > 0x7fffffffull) return pcq_fail(PCQ_ERR_ARG, "scan chunk too large (%llu points)", (unsigned long long)cols.n);
-    int rc = pcq_ensure_partials(ctx, (size_t)ntiles + 2);  // tile states + the ticket
+    const uint64_t ntiles = (cols.n + EMIT_TILE - 1) / EMIT_TILE;
+    const uint64_t npieces = (ntiles + SCAN_PIECE - 1) / SCAN_PIECE;
+    if (npieces > 1024) return pcq_fail(PCQ_ERR_ARG, "scan chunk too large (%llu points)", (unsigned long long)cols.n);
+    int rc = pcq_ensure_partials(ctx, (size_t)(2 * ntiles + npieces + 2));  // counts | offsets (+ total) | piece sums
     if (rc) return rc;
-    PCQ_HIP(hipMemsetAsync(ctx->d_partials, 0, ((size_t)ntiles + 2) * sizeof(uint64_t), s));
-    uint64_t *state = ctx->d_partials;
-    uint32_t *ticket = reinterpret_cast<uint32_t *>(ctx->d_partials + ntiles);
+    uint64_t *counts = ctx->d_partials, *offsets = counts + ntiles, *pieces = offsets + ntiles + 1;
     const dim3 g((unsigned)ntiles), b(BLOCK);
-    if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_emit_points<PCQ_PRED_BOUNDS>, g, b, 0, s, cols, pred, state, ticket, d_npoints, d_out31, (uint32_t)ntiles);
-    else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_emit_points<PCQ_PRED_CLASS>, g, b, 0, s, cols, pred, state, ticket, d_npoints, d_out31, (uint32_t)ntiles);
-    else hipLaunchKernelGGL(k_emit_points<PCQ_PRED_BOUNDS_F64>, g, b, 0, s, cols, pred, state, ticket, d_npoints, d_out31, (uint32_t)ntiles);
+    if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_BOUNDS>, g, b, 0, s, cols, pred, counts);
+    else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_CLASS>, g, b, 0, s, cols, pred, counts);
+    else hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_BOUNDS_F64>, g, b, 0, s, cols, pred, counts);
+    hipLaunchKernelGGL(k_scan_piece_sums, dim3((unsigned)npieces), dim3(1024), 0, s, counts, (uint32_t)ntiles, pieces);
+    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, pieces, (uint32_t)npieces);
+    hipLaunchKernelGGL(k_scan_pieces, dim3((unsigned)npieces), dim3(1024), 0, s, counts, (uint32_t)ntiles, pieces, offsets);
+    if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_emit_points<PCQ_PRED_BOUNDS>, g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles);
+    else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_emit_points<PCQ_PRED_CLASS>, g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles);
+    else hipLaunchKernelGGL(k_emit_points<PCQ_PRED_BOUNDS_F64>, g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles);
     PCQ_HIP(hipGetLastError());
     return PCQ_OK;
 }
