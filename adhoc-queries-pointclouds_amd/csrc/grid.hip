@@ -50,11 +50,12 @@ constexpr int P0_TILE = P0_NT * P0_ITEMS;  // 2560 points: their tuples (60 KB) 
 constexpr int P0_MAX_BLOCKS = 1024;    // pass 0: at most this many workgroups (rows of the count table)
 // The fold comes in two shapes.  BIG: one 1024-thread workgroup owns a CU's whole LDS — 6400 slots of {key, distance,
 // file order}, the winner's payload parked in HBM scratch — and folds a level-1 bin directly (coarse grids: few cells,
-// many tuples per cell).  SMALL: 1024 slots with the payload in LDS, three 256-thread workgroups per CU, for the
-// partitions a second level cuts out of a dense grid (about one tuple per cell: many small partitions, latency-bound).
+// many tuples per cell).  SMALL: 2048 slots, three 256-thread workgroups per CU, seven tuples per thread — a whole
+// partition of the second level (about 1100 cells, 1500 tuples) in registers, so that the winner of a cell writes its
+// record straight from there (dense grids: about one tuple per cell, many small partitions).
 constexpr int BIG_SLOTS = 6400, BIG_NT = 1024, BIG_LIMIT = 5440, BIG_DIRECT = 4700;
-constexpr int SMALL_SLOTS = 1024, SMALL_NT = 256, SMALL_LIMIT = 870, SMALL_TARGET = 600;
-constexpr int FOLD_K = 4;              // fold: tuples per thread and chunk
+constexpr int SMALL_SLOTS = 2048, SMALL_NT = 256, SMALL_K = 6, SMALL_LIMIT = 1740, SMALL_TARGET = 1000;
+constexpr int BIG_K = 4;               // fold: tuples per thread and chunk
 constexpr int L2_NT = 512;             // second level: threads per workgroup (one workgroup per level-1 bin)
 constexpr int L2_UNROLL = 4;
 constexpr int PROBE_BINS = 2;          // bins whose distinct cells are counted to estimate the grid's density
@@ -723,7 +724,7 @@ __device__ __forceinline__ int lds_find_or_insert(uint64_t *s_key, uint64_t key,
 // SMALL (XPART) keeps the next PARTITION's first chunk in flight and loads further chunks of a partition (rare: a partition
 // is about one chunk) on demand.  BIG loads chunk by chunk: with 16 waves on the CU a register prefetch of the next chunk
 // measured no faster and spilled.
-template <int NSLOT, int NT, int LIMIT, bool PAY_LDS, bool XPART, int MIN_WAVES>
+template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool PAY_LDS, bool XPART, bool DIRECT, int MIN_WAVES>
 __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t nparts) {
     constexpr int SPT = (NSLOT + NT - 1) / NT;   // slots per thread in the compaction
     constexpr int CHUNK = NT * FOLD_K;
@@ -747,7 +748,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
     for (; p < nparts; p += gridDim.x) {
         const uint32_t pn = p + gridDim.x;
         if (pn < nparts) nxt_lo = sg0.off[pn], nxt_cnt = sg0.off[pn + 1] - nxt_lo, nxt_out = P.wbase[pn];
-        uint32_t *pay = PAY_LDS ? s_pay_lds : P.pay_scratch + (size_t)p * NSLOT * 5;
+        uint32_t *pay = PAY_LDS ? s_pay_lds : P.pay_scratch + (size_t)blockIdx.x * NSLOT * 5;  // HBM scratch of this workgroup
         const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
         const uint64_t old_base = P.okeys ? P.obase[p] : 0;
         const uint64_t out_base = cur_out;
@@ -784,14 +785,14 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
         // The common partition of a dense grid: one segment, at most one chunk of tuples, no earlier winners.  Every thread
         // still holds its tuples when the winners are known, so the winner of a cell writes its record straight from
         // registers — no payload parked in LDS, no sweep over the table's slots.
-        if (XPART && P.nsegs == 1 && n_old == 0 && cur_cnt <= CHUNK) {
+        if (DIRECT && P.nsegs == 1 && n_old == 0 && cur_cnt <= CHUNK) {
             const uint32_t cnt = cur_cnt;
             GridTuple tu[FOLD_K];
             uint64_t dbits[FOLD_K];
             int slot[FOLD_K];
-            if (have_first) {
+            if (XPART && have_first) {
 #pragma unroll
-                for (int k = 0; k < FOLD_K; k++) tu[k] = first[k];
+                for (int k = 0; k < FOLD_K; k++) tu[k] = first[XPART ? k : 0];
             } else {
 #pragma unroll
                 for (int k = 0; k < FOLD_K; k++) {
@@ -816,12 +817,12 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                 if (ev.dbits < __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
                     atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
             }
-            have_first = pn < nparts;
+            have_first = XPART && pn < nparts;
             if (have_first) {  // the next partition's tuples are on their way while this one is finished
 #pragma unroll
                 for (int k = 0; k < FOLD_K; k++) {
                     const uint32_t i = k * NT + threadIdx.x;
-                    first[k] = ld_tuple(sg0.tuples + nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0)));
+                    first[XPART ? k : 0] = ld_tuple(sg0.tuples + nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0)));
                 }
             }
             __syncthreads();
@@ -891,9 +892,9 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                     GridTuple tu[FOLD_K];
                     uint64_t dbits[FOLD_K];
                     int slot[FOLD_K];
-                    if (r == 0 && c0 == 0 && have_first) {
+                    if (XPART && r == 0 && c0 == 0 && have_first) {
 #pragma unroll
-                        for (int k = 0; k < FOLD_K; k++) tu[k] = first[k];
+                        for (int k = 0; k < FOLD_K; k++) tu[k] = first[XPART ? k : 0];
                     } else {
 #pragma unroll
                         for (int k = 0; k < FOLD_K; k++) {
@@ -1494,7 +1495,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         if (!rc) rc = att.get(nparts, &d_palias);
         if (!rc) rc = att.get(npieces, &d_pieces);
         if (!rc) rc = att.get((size_t)npieces + 1, &d_piece_pre);
-        if (!rc && big) rc = att.get((size_t)nparts * BIG_SLOTS * 5, &d_pay);
+        const uint32_t resident_wgs = (uint32_t)ctx->num_cus * (big ? 1u : 3u);  // what fits the LDS: the rest of the partitions is looped over
+        if (!rc) rc = att.get((size_t)resident_wgs * (big ? BIG_SLOTS : SMALL_SLOTS) * 5, &d_pay);  // parked payloads, per resident workgroup
         if (rc) return rc;
         hipLaunchKernelGGL(k_winner_room, dim3((nparts + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_tot, w_old ? ocount : nullptr, nparts, limit, d_room);
         hipLaunchKernelGGL(k_scan_piece_sums, dim3(npieces), dim3(1024), 0, s, d_room, nparts, d_pieces);
@@ -1507,10 +1509,10 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         if (w_old) F.okeys = okeys, F.orecs = orecs, F.obase = obase, F.ocount = ocount;
         F.wkeys = n_wkeys, F.wrecs = n_wrecs, F.wbase = n_wbase, F.wcount = n_wcount, F.palias = d_palias, F.pay_scratch = d_pay, F.stats = d_stats;
         {
-            uint32_t resident = (uint32_t)ctx->num_cus * (big ? 1u : 3u);  // what fits the LDS: the rest of the partitions is looped over
+            uint32_t resident = resident_wgs;
             if (resident > nparts) resident = nparts;
-            if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_LIMIT, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
-            else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_LIMIT, true, true, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
+            if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
+            else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, false, true, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
         }
         PCQ_HIP(hipGetLastError());
         unsigned long long st[4] = {0, 0, 0, 0};

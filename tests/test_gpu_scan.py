@@ -294,7 +294,7 @@ def test_grid_fold_levels_refold_and_forced_fanout(oracle):
 
             assert run(1.0) == (1, 0, 0, 1)
             assert run(0.72) == (1, 0, 0, 1)
-            assert run(0.25) == (1, 1, 0, 9)       # ~5270 cells per bin / 600 per partition
+            assert run(0.25) == (1, 1, 0, 6)       # ~5270 cells per bin / 1000 per partition
             ctx.set_option("grid_f2", 1)           # forced direct fold: the bins overflow the table, the fold is repeated
             folds, level2, refolds, f2 = run(0.2)
             assert folds == 1 and level2 >= 1 and refolds >= 1 and f2 > 1
