@@ -312,6 +312,8 @@ extern "C" int pcq_scan_dev_indexed(pcq_ctx *ctx, const pcq_columns *cols, const
     DevPred dp;
     int rc = pcq_make_dev_pred(pred, &dp);
     if (rc) return rc;
+    rc = pcq_scratch_stream(ctx, s);
+    if (rc) return rc;
     const int max_blocks = ctx->num_cus * 8;
     if (pred->kind == PCQ_PRED_BOUNDS) {
         if (cols->xyz_stride != 12 || ((uintptr_t)cols->xyz & 15) != 0 || cols->n < CHUNK_POINTS)

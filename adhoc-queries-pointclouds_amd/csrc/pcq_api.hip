@@ -752,10 +752,21 @@ static int buffer_reserve(pcq_collector *c, uint64_t incoming, hipStream_t s) {
     return PCQ_OK;
 }
 
+// The per-context scratch (partial counts, tile offsets, the grid's count table, the segment table) is shared by all
+// scans of the context and ordered only by the stream they run on: when a scan arrives on a different stream than the
+// previous one, the previous stream is drained first (one stream in flight per context).
+int pcq_scratch_stream(pcq_ctx *ctx, hipStream_t s) {
+    if (ctx->scratch_stream && ctx->scratch_stream != s) PCQ_HIP(hipStreamSynchronize(ctx->scratch_stream));
+    ctx->scratch_stream = s;
+    return PCQ_OK;
+}
+
 static int scan_dev_impl(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c, hipStream_t s) {
     int rc = validate_scan(cols, pred, c);
     if (rc) return rc;
     if (cols->n == 0) return PCQ_OK;
+    rc = pcq_scratch_stream(ctx, s);
+    if (rc) return rc;
     DevPred dp;
     rc = pcq_make_dev_pred(pred, &dp);
     if (rc) return rc;
@@ -979,6 +990,13 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
 
     // on any failure the copies and kernels already queued must drain before the staging buffers (or the
     // caller's memory) can be touched again
+    // every error exit below goes through fail(): queued copies and kernels drain before the staging buffers (or the caller's
+    // memory) can be touched again, and no staging pair stays marked busy
+#define PCQ_HIP_OR_FAIL(expr)                                                                                             \
+    do {                                                                                                                  \
+        hipError_t _e = (expr);                                                                                           \
+        if (_e != hipSuccess) return fail(pcq_fail(PCQ_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__)); \
+    } while (0)
     auto fail = [&](int code) {
         (void)hipStreamSynchronize(cs);
         (void)hipStreamSynchronize(s);
@@ -995,7 +1013,7 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
         }
         const uint64_t first = k * chunk;
         const uint64_t cnt = cols->n - first < chunk ? cols->n - first : chunk;
-        PCQ_HIP(hipStreamWaitEvent(s, ctx->copied[b], 0));
+        PCQ_HIP_OR_FAIL(hipStreamWaitEvent(s, ctx->copied[b], 0));
         pcq_columns dcols = *cols;
         const uint8_t *d = ctx->d_stage[b];
         if (pl.aos) {
@@ -1011,14 +1029,15 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
         dcols.first_index = cols->first_index + first;
         rc = scan_dev_impl(ctx, &dcols, pred, c, s);
         if (rc) return fail(rc);
-        PCQ_HIP(hipEventRecord(ctx->consumed[b], s));
+        PCQ_HIP_OR_FAIL(hipEventRecord(ctx->consumed[b], s));
         ctx->stage_busy[b] = true;
     }
     if (wait) {
-        PCQ_HIP(hipStreamSynchronize(s));
+        PCQ_HIP_OR_FAIL(hipStreamSynchronize(s));
         ctx->stage_busy[0] = ctx->stage_busy[1] = false;
     }
     return PCQ_OK;
+#undef PCQ_HIP_OR_FAIL
 }
 
 extern "C" int pcq_scan_host(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {

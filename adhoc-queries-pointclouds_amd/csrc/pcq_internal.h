@@ -122,6 +122,7 @@ struct pcq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;       // compute stream
     hipStream_t copy_stream = nullptr;  // H2D stream
+    hipStream_t scratch_stream = nullptr;  // the stream whose kernels may still be using the context's scratch (pcq_scratch_stream)
     hipEvent_t copied[2] = {nullptr, nullptr};
     hipEvent_t consumed[2] = {nullptr, nullptr};
     int num_cus = 0;
@@ -207,6 +208,7 @@ struct pcq_collector {
 // internal entry points (defined across the .hip files)
 // ---------------------------------------------------------------------------------------------
 int pcq_make_dev_pred(const pcq_predicate *p, DevPred *out);
+int pcq_scratch_stream(pcq_ctx *ctx, hipStream_t s);
 int pcq_ensure_partials(pcq_ctx *ctx, size_t n);
 
 // scan_count.hip

@@ -480,6 +480,10 @@ extern "C" int pcq_scan_dev_count_batch(pcq_ctx *ctx, const pcq_columns *cols, c
         return pcq_fail(PCQ_ERR_ARG, "pcq_scan_dev_count_batch: null argument");
     if (nsegments == 0) return PCQ_OK;
     hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    {
+        const int src = pcq_scratch_stream(ctx, s);
+        if (src) return src;
+    }
     if (nsegments > ctx->segments_cap) {
         if (ctx->d_segments) (void)hipFree(ctx->d_segments);
         if (ctx->h_segments) (void)hipHostFree(ctx->h_segments);

@@ -56,7 +56,7 @@ def test_product_library_ships_no_lab_code():
     inflater measured in round 1 are not in it (csrc/lab/ -> libpcq_lab.so, loaded only by tools/ with PCQ_LAB=1)."""
     syms = subprocess.run(["nm", "-D", "--defined-only", pkg.lib_path()], capture_output=True, text=True).stdout
     assert "pcq_scan_dev" in syms
-    for name in ("membench", "lz4_inflate", "pcq_read_fd_to_device"):
+    for name in ("membench", "lz4_inflate"):
         assert name not in syms, name
     all_syms = subprocess.run(["nm", "-C", pkg.lib_path()], capture_output=True, text=True).stdout
     for kernel in ("k_bounds_count_xyz12", "k_bounds_count_w1<", "k_bounds_count_batch_w1", "k_class_count_batch_w1", "k_class_count_u8"):
