@@ -24,6 +24,9 @@ def _check(line, n_gpus):
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert abs(d["value"] - d["config"]["points"] * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"]) / 1e6) / d["value"] < 1e-9
     assert d["matches"] == d["config"]["points"]  # XL contains every generated point
+    assert "traffic_source" in r and r["kernel"] == "k_bounds_count_batch_pipe<2>" and len(r["kernel_source_id"]) == 16
+    assert (r["traffic"] is None) == (r["traffic_source"] is None or "not reported" in r["traffic_source"])
+    assert len(d["scanned_per_rank"]) == n_gpus == len(d["rank_devices"]) and sum(d["scanned_per_rank"]) == d["config"]["points"]
     return d
 
 
@@ -36,6 +39,9 @@ def test_bench_json_contract_single_process():
     d = _check(lines[0], 1)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["unit"] == "Mpoints/s" and c["cores"] >= 1 and c["parity_on_sample"] is True
+    pb = d["parity_batched_on_sample"]  # the TIMED kernel on a selective box (ca13_L) against the oracle
+    assert pb["equal"] is True and pb["gpu"] == pb["oracle"] and pb["kernel"] == d["roofline"]["kernel"] and pb["query"] == "ca13_L"
+    assert d["rccl_ranks"] == 0
 
 
 def test_bench_under_torch_distributed_run_exercises_rccl():
@@ -47,7 +53,7 @@ def test_bench_under_torch_distributed_run_exercises_rccl():
     lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1
     d = _check(lines[0], 1)
-    assert d["cpu_baseline"] is None
+    assert d["cpu_baseline"] is None and d["rccl_ranks"] == 1
 
 
 def test_bench_two_rank_rehearsal_shards_files_and_sums_counts():
@@ -63,6 +69,7 @@ def test_bench_two_rank_rehearsal_shards_files_and_sums_counts():
     assert len(lines) == 1  # rank 0 only
     d = _check(lines[0], 2)
     assert d["config"]["points"] == 5 * 300007 and d["scaling"] == "strong"
+    assert sorted(d["scanned_per_rank"]) == [2 * 300007, 3 * 300007]  # file i -> rank i % 2
 
 
 def test_smoke_entry_point():

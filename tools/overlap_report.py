@@ -30,3 +30,24 @@ print("kernel time by name (ms):", {k: round(v / 1e6, 2) for k, v in sorted(name
 if big:
     span = big[-1][1] - big[0][0]
     print(f"span first copy start -> last copy end: {span / 1e6:.2f} ms; copy engine busy {100 * tot / span:.0f} % of it")
+
+# timeline of each scan (copies separated by less than 3 ms belong to one scan): when the copy engine and the kernels ran
+groups, cur = [], []
+for c in big:
+    if cur and c[0] - cur[-1][1] > 3_000_000:
+        groups.append(cur); cur = []
+    cur.append(c)
+if cur: groups.append(cur)
+for gi, g in enumerate(groups):
+    a, b = g[0][0], g[-1][1]
+    ks = [(s, e, n) for s, e, n in kern if e > a and s < b + 3_000_000]
+    inside = sum(min(e, b) - max(s, a) for s, e, n in ks if s < b and e > a)
+    after = sum(e - max(s, b) for s, e, n in ks if e > b)
+    print(f"scan {gi}: {len(g)} chunk copies over {(b - a) / 1e6:.2f} ms (engine busy {sum(e - s for s, e, _ in g) / 1e6:.2f} ms); "
+          f"{len(ks)} kernels, {inside / 1e6:.2f} ms of kernel time under the copies, {after / 1e6:.2f} ms after the last copy ended")
+if "--timeline" in sys.argv and groups:
+    g = groups[int(sys.argv[sys.argv.index("--timeline") + 1])]
+    a, b = g[0][0], g[-1][1]
+    ev = [(s, e, "H2D chunk") for s, e, _ in g] + [(s, e, n.replace("(anonymous namespace)::", "").split("(")[0]) for s, e, n in kern if e > a and s < b + 3_000_000]
+    for s, e, n in sorted(ev):
+        print(f"  {(s - a) / 1e3:9.1f} us  +{(e - s) / 1e3:7.1f} us  {n}")
