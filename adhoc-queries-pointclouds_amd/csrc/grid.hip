@@ -46,7 +46,7 @@ constexpr int F1 = 1 << F1_BITS;       // level-1 bins: the top F1_BITS bits of 
 constexpr int F2_MAX = 4096;           // largest second-level fan-out
 constexpr int P0_NT = 512;             // pass 0: threads per workgroup
 constexpr int P0_ITEMS = 5;            // pass 0: points per thread and tile
-constexpr int P0_TILE = P0_NT * P0_ITEMS;  // 2560 points: their tuples (60 KB) are staged in LDS, two workgroups per CU
+constexpr int P0_TILE = P0_NT * P0_ITEMS;  // 2560 points: their tuples (60 KB) and bin / selector words (10 KB) are staged in LDS, two workgroups per CU
 constexpr int P0_MAX_BLOCKS = 1024;    // pass 0: at most this many workgroups (rows of the count table)
 // The fold comes in two shapes.  BIG: one 1024-thread workgroup owns a CU's whole LDS — 6400 slots of {key, distance,
 // file order}, the winner's payload parked in HBM scratch — and folds a level-1 bin directly (coarse grids: few cells,
@@ -58,6 +58,9 @@ constexpr int SMALL_SLOTS = 2048, SMALL_NT = 256, SMALL_K = 6, SMALL_LIMIT = 174
 constexpr int BIG_K = 4;               // fold: tuples per thread and chunk
 constexpr int L2_NT = 512;             // second level: threads per workgroup (one workgroup per level-1 bin)
 constexpr int L2_UNROLL = 4;
+constexpr int L2_ITEMS = 3;            // second level, staged form: tuples per thread and tile (1536 tuples = 36 KB of LDS)
+constexpr int L2_TILE = L2_NT * L2_ITEMS;
+constexpr int L2_STAGED_F2 = 1024;     // largest fan-out of the staged form (its per-tile tables live in LDS)
 constexpr int PROBE_BINS = 2;          // bins whose distinct cells are counted to estimate the grid's density
 constexpr uint64_t ALIAS_QUADRATIC = 8192;  // aliased tuples up to which the replay order comes from the quadratic rank kernel
 constexpr int MAX_RUNS = 1024;         // pending pass-0 runs per collector before a fold is forced
@@ -85,6 +88,7 @@ struct GridEntryDev {
 struct GridSeg {
     const GridTuple *tuples;
     const uint32_t *off;
+    const uint16_t *sub16;  // per tuple: the 16 hash bits the second level partitions by (nullptr behind the second level)
 };
 
 struct AliasItem {  // a tuple of an aliased key, for the exact replay (key at +0, order at +8: alias_sort.hip)
@@ -140,11 +144,74 @@ __device__ __forceinline__ double centre_dist(const DevGrid &g, const uint64_t (
     return (a + b) + c;
 }
 
-// hash(key) picks the level-1 bin (bits 63..53), the second-level partition (bits 52..21) and the first LDS slot (bits 20..0)
+// The same cell, the short way.  Every pass over the matches is bound by its vector instructions (a point costs ~125 of
+// them through cell_of + the 64-bit hash), so the common case is cut down to what it needs:
+//   q = (p - bmin) * k, k = RN(dims / extent) computed once on the host — one multiply instead of two.  q is within
+//   (1 + 2^-53)^3 of the exact quotient num / extent the reference rounds (num = RN((p - bmin) * dims)), and RN of that is
+//   another half ulp away: |q - RN(num / extent)| < 4.01 * 2^-53 * q.  With q < qmax <= 2^31 and both q - floor(q) and
+//   1 - (q - floor(q)) above guard = qmax * 2^-50 (= 8 * 2^-53 * qmax) no integer lies between the two, so
+//   floor(q) IS trunc(RN(num / extent)).  A negative q (the reference's `as u64` saturates to 0) gives 0 as well: the
+//   conversion saturates, and the quotient has the sign of p - bmin either way.
+//   The cell fits 32 bits then: one conversion instruction each way instead of the emulated 64-bit ones.
+// Anything else — within the guard of a cell boundary, beyond qmax, NaN, a grid with a zero extent — reports !ok and the
+// caller takes cell_of().
+struct CellFast {
+    uint32_t c[3];
+    double f[3];  // c as f64
+    bool ok;
+};
+__device__ __forceinline__ CellFast cell_fast(const DevGrid &g, double px, double py, double pz) {
+    const double p[3] = {px, py, pz};
+    CellFast r;
+    r.ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const double q = (p[a] - g.bmin[a]) * g.qk[a];
+        const double fl = floor(q);
+        const double frac = q - fl;
+        r.ok &= (frac > g.guard[a]) & (1.0 - frac > g.guard[a]) & (q < g.qmax[a]);
+        r.f[a] = fl > 0.0 ? fl : 0.0;
+        r.c[a] = (uint32_t)r.f[a];
+    }
+    return r;
+}
+__device__ __forceinline__ uint64_t key_fast(const DevGrid &g, const CellFast &cf, bool *alias) {
+    uint64_t key = 0;
+    uint32_t beyond = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const uint32_t m = (uint32_t)g.mask[a];  // 32 or more bits: all ones, like the cell's zero upper half
+        beyond |= cf.c[a] & ~m;
+        key |= (uint64_t)(cf.c[a] & m) << g.shift[a];
+    }
+    *alias = beyond != 0;
+    return key;
+}
+__device__ __forceinline__ double centre_dist_fast(const DevGrid &g, const CellFast &cf, double px, double py, double pz) {
+    const double cx = (cf.f[0] + 0.5) * g.cell_size + g.bmin[0];
+    const double cy = (cf.f[1] + 0.5) * g.cell_size + g.bmin[1];
+    const double cz = (cf.f[2] + 0.5) * g.cell_size + g.bmin[2];
+    const double dx = px - cx, dy = py - cy, dz = pz - cz;
+    const double a = dx * dx, b = dy * dy, c = dz * dz;
+    return (a + b) + c;
+}
+
+// The partition hash of a cell key: one 64-bit multiply (Fibonacci hashing; the murmur finaliser costs two and three
+// shifts, a third of what is left of a point's instructions).  Bits 63..55 pick the level-1 bin, bits 52..37 the
+// second-level partition, bits 36..16 the first LDS slot; the fold of the upper half in front makes every key bit count
+// in the slot bits too.
+__device__ __forceinline__ uint64_t cell_hash(uint64_t k) {
+    k ^= k >> 32;
+    return k * 0x9e3779b97f4a7c15ull;
+}
 __device__ __forceinline__ uint32_t bin_of(uint64_t h) { return (uint32_t)(h >> (64 - F1_BITS)); }
-__device__ __forceinline__ uint32_t sub_of(uint64_t h, uint32_t f2) { return (uint32_t)((((h >> 21) & 0xffffffffull) * f2) >> 32); }
+// the second-level partition comes from the 16 bits under the bin bits: pass 0 stores them next to every tuple (sub16), so
+// that the second level never recomputes a cell
+__device__ __forceinline__ uint32_t sel16_of(uint64_t h) { return (uint32_t)(h >> 37) & 0xffffu; }
+__device__ __forceinline__ uint32_t sub_from_sel16(uint32_t sel16, uint32_t f2) { return (sel16 * f2) >> 16; }
+__device__ __forceinline__ uint32_t sub_of(uint64_t h, uint32_t f2) { return sub_from_sel16(sel16_of(h), f2); }
 template <int NSLOT>
-__device__ __forceinline__ uint32_t slot_of(uint64_t h) { return (uint32_t)(((h & 0x1fffffull) * NSLOT) >> 21); }
+__device__ __forceinline__ uint32_t slot_of(uint64_t h) { return (uint32_t)((((h >> 16) & 0x1fffffull) * NSLOT) >> 21); }
 
 __device__ __forceinline__ GridTuple ld_tuple(const GridTuple *p) {
     const uint2 *q = reinterpret_cast<const uint2 *>(p);
@@ -175,14 +242,22 @@ struct TupleEval {
     uint64_t key, dbits;
     bool alias;
 };
-__device__ __forceinline__ TupleEval eval_tuple(const DevGrid &g, const EntryRef &entries, const GridTuple &t) {
-    const GridEntryDev e = entries.get((t.w0 >> 8) & 0xff);
-    const double px = world(t.x, e.scale[0], e.offset[0]), py = world(t.y, e.scale[1], e.offset[1]), pz = world(t.z, e.scale[2], e.offset[2]);
+__device__ __forceinline__ TupleEval eval_exact(const DevGrid &g, double px, double py, double pz) {
     const CellInfo ci = cell_of(g, px, py, pz);
     TupleEval r;
     r.key = ci.key;
     r.alias = ci.alias;
     r.dbits = (uint64_t)__double_as_longlong(centre_dist(g, ci.cell, px, py, pz));
+    return r;
+}
+__device__ __forceinline__ TupleEval eval_tuple(const DevGrid &g, const EntryRef &entries, const GridTuple &t) {
+    const GridEntryDev e = entries.get((t.w0 >> 8) & 0xff);
+    const double px = world(t.x, e.scale[0], e.offset[0]), py = world(t.y, e.scale[1], e.offset[1]), pz = world(t.z, e.scale[2], e.offset[2]);
+    const CellFast cf = cell_fast(g, px, py, pz);
+    if (!cf.ok) return eval_exact(g, px, py, pz);
+    TupleEval r;
+    r.key = key_fast(g, cf, &r.alias);
+    r.dbits = (uint64_t)__double_as_longlong(centre_dist_fast(g, cf, px, py, pz));
     return r;
 }
 // file order among tuples: entries are numbered in scan order; 0 is reserved for an earlier fold's winner
@@ -207,10 +282,14 @@ __device__ __forceinline__ void st_record(uint8_t *dst32, const GridEntryDev &e,
 // ---------------------------------------------------------------------------------------------------------------
 // pass 0: counting-sort partition of the matched points of one scan
 // ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t key_exact(const DevGrid &g, double px, double py, double pz) { return cell_of(g, px, py, pz).key; }
 template <int KIND>
 __device__ __forceinline__ uint64_t point_hash(const DevCols &c, const DevGrid &g, const RawPoint &rp) {
     const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]), pz = world(rp.z, c.scale[2], c.offset[2]);
-    return hash64(cell_of(g, px, py, pz).key);
+    const CellFast cf = cell_fast(g, px, py, pz);
+    if (!cf.ok) return cell_hash(key_exact(g, px, py, pz));
+    bool alias;
+    return cell_hash(key_fast(g, cf, &alias));
 }
 
 // What the predicate reads of a point: its position (bounds kinds) or its class byte.
@@ -358,15 +437,19 @@ __global__ __launch_bounds__(1024) void k_excl_scan_u64(const uint64_t *__restri
 // The second reading of the scan: every match becomes a tuple at binoff[bin] + (workgroup's offset in the bin) + rank.
 // Per tile of 2560 points: the matches take a rank in their bin (LDS atomics), the tile's tuples are laid out in LDS
 // sorted by bin, and the sorted image is copied out one tuple per lane — consecutive lanes write consecutive tuples of
-// a bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.
+// a bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.  A tuple is staged (and stored) as
+// 16 + 8 bytes; next to it one word holds its bin and its second-level selector: the bin gives the tuple's place in the
+// run (the tile's first place in the bin + the tuple's place in the sorted image), the selector goes to sub16.
+typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 template <int KIND>
-__global__ __launch_bounds__(P0_NT) void k_p0_scatter(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
-                                                      const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out, uint32_t entry,
-                                                      uint64_t idx_base) {
+__global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
+                                                      const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out,
+                                                      uint16_t *__restrict__ out_sub16, uint32_t entry, uint64_t idx_base) {
     static_assert(F1 == P0_NT, "one thread per bin in the per-tile scan");
-    __shared__ uint2 s_stage[P0_TILE * 3];   // the tile's tuples, sorted by bin (three 8-byte words each)
-    __shared__ uint32_t s_tpos[P0_TILE];     // where the staged tuple goes in the run
-    __shared__ uint32_t s_cnt[F1], s_base[F1], s_gpos[F1], s_cur[F1], s_wsum[P0_NT / 64];
+    __shared__ uint4 s_xyzi[P0_TILE];        // the tile's tuples, sorted by bin: x, y, z, idx
+    __shared__ uint2 s_attr[P0_TILE];        //                                    w0, w1
+    __shared__ uint32_t s_meta[P0_TILE];     // bin << 16 | selector
+    __shared__ uint32_t s_cnt[F1], s_base[F1], s_delta[F1], s_cur[F1], s_wsum[P0_NT / 64];
     __shared__ uint32_t s_total;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     s_cur[threadIdx.x] = binoff[threadIdx.x] + cnt_excl[(size_t)blockIdx.x * F1 + threadIdx.x];
@@ -390,15 +473,28 @@ __global__ __launch_bounds__(P0_NT) void k_p0_scatter(DevCols c, DevPred pr, Dev
             }
         }
         bool passes[P0_ITEMS];
-        uint32_t bins[P0_ITEMS], ranks[P0_ITEMS];
+        uint32_t metas[P0_ITEMS], ranks[P0_ITEMS], w0[P0_ITEMS], w1[P0_ITEMS];
 #pragma unroll
-        for (int j = 0; j < P0_ITEMS; j++) {
+        for (int j = 0; j < P0_ITEMS; j++) {  // the attributes of the matches: asked for here, used behind the two barriers
             const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
             passes[j] = i < end && p0_pass<KIND>(c, pr, cur[j]);
+            w0[j] = entry << 8, w1[j] = 0;
             if (!passes[j]) continue;
             if (KIND == PCQ_PRED_CLASS) cur[j].rp = ld_xyz(c, i);
-            bins[j] = bin_of(point_hash<KIND>(c, g, cur[j].rp));
-            ranks[j] = atomicAdd(&s_cnt[bins[j]], 1u);
+            if (c.rgb) {  // last.rs:145-153
+                const uint8_t *q = c.rgb + i * c.rgb_stride;
+                w0[j] |= ld_u16(q) << 16;
+                w1[j] = ld_u16(q + 2) | (ld_u16(q + 4) << 16);
+            }
+            w0[j] |= KIND == PCQ_PRED_CLASS ? cur[j].cls : (c.cls ? c.cls[i * c.cls_stride] : 0);  // last.rs:138-142
+        }
+#pragma unroll
+        for (int j = 0; j < P0_ITEMS; j++) {
+            if (!passes[j]) continue;
+            const uint64_t h = point_hash<KIND>(c, g, cur[j].rp);
+            const uint32_t bin = bin_of(h);
+            metas[j] = bin << 16 | sel16_of(h);
+            ranks[j] = atomicAdd(&s_cnt[bin], 1u);
         }
         __syncthreads();
         {  // exclusive scan of the tile's counts over the bins (thread t = bin t); the workgroup's cursors move on
@@ -417,7 +513,7 @@ __global__ __launch_bounds__(P0_NT) void k_p0_scatter(DevCols c, DevPred pr, Dev
                 total += s_wsum[w];
             }
             s_base[threadIdx.x] = before;
-            s_gpos[threadIdx.x] = s_cur[threadIdx.x];
+            s_delta[threadIdx.x] = s_cur[threadIdx.x] - before;
             s_cur[threadIdx.x] += v;
             s_cnt[threadIdx.x] = 0;
             if (threadIdx.x == 0) s_total = total;
@@ -427,25 +523,23 @@ __global__ __launch_bounds__(P0_NT) void k_p0_scatter(DevCols c, DevPred pr, Dev
         for (int j = 0; j < P0_ITEMS; j++) {
             if (!passes[j]) continue;
             const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
-            uint32_t r = 0, gg = 0, b = 0;
-            if (c.rgb) {  // last.rs:145-153
-                const uint8_t *q = c.rgb + i * c.rgb_stride;
-                r = ld_u16(q), gg = ld_u16(q + 2), b = ld_u16(q + 4);
-            }
-            const uint32_t cls = KIND == PCQ_PRED_CLASS ? cur[j].cls : (c.cls ? c.cls[i * c.cls_stride] : 0);  // last.rs:138-142
-            const uint32_t at = s_base[bins[j]] + ranks[j];
-            s_stage[at * 3] = make_uint2((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y);
-            s_stage[at * 3 + 1] = make_uint2((uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
-            s_stage[at * 3 + 2] = make_uint2(cls | (entry << 8) | (r << 16), gg | (b << 16));
-            s_tpos[at] = s_gpos[bins[j]] + ranks[j];
+            const uint32_t at = s_base[metas[j] >> 16] + ranks[j];
+            s_xyzi[at] = make_uint4((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y, (uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
+            s_attr[at] = make_uint2(w0[j], w1[j]);
+            s_meta[at] = metas[j];
         }
         __syncthreads();
         const uint32_t total = s_total;
-        uint2 *out2 = reinterpret_cast<uint2 *>(out);
         for (uint32_t t = threadIdx.x; t < total; t += P0_NT) {
-            const uint2 a = s_stage[t * 3], b = s_stage[t * 3 + 1], d = s_stage[t * 3 + 2];
-            uint2 *q = out2 + (uint64_t)s_tpos[t] * 3;
-            q[0] = a, q[1] = b, q[2] = d;
+            const uint4 a = s_xyzi[t];
+            const uint2 b = s_attr[t];
+            const uint32_t meta = s_meta[t];
+            const uint32_t pos = s_delta[meta >> 16] + t;
+            uint8_t *q = reinterpret_cast<uint8_t *>(out) + (uint64_t)pos * sizeof(GridTuple);
+            u32x4_a8 va = {a.x, a.y, a.z, a.w};
+            *reinterpret_cast<u32x4_a8 *>(q) = va;
+            *reinterpret_cast<uint2 *>(q + 16) = b;
+            out_sub16[pos] = (uint16_t)meta;
         }
 #pragma unroll
         for (int j = 0; j < P0_ITEMS; j++) cur[j] = nxt[j];
@@ -579,7 +673,7 @@ struct Level2Params {
     uint32_t *ooff2;          // [F1 * f2 + 1]
 };
 
-__global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
+__global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
     __shared__ uint32_t s_hist[F2_MAX], s_cur[F2_MAX], s_ohist[F2_MAX], s_ocur[F2_MAX];
     const uint32_t bin = blockIdx.x, f2 = P.f2;
     for (uint32_t t = threadIdx.x; t < F2_MAX; t += L2_NT) s_hist[t] = 0, s_ohist[t] = 0;
@@ -589,22 +683,22 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
             const GridSeg sg = P.segs[r];
             const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
             for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += L2_NT * L2_UNROLL) {  // the loads of four steps are issued together
-                GridTuple t[L2_UNROLL];
+                uint32_t sel[L2_UNROLL];
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++) {
                     const uint32_t i = i0 + u * L2_NT;
-                    t[u] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
+                    sel[u] = sg.sub16[i < hi ? i : hi - 1];
                 }
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++)
-                    if (i0 + u * L2_NT < hi) atomicAdd(&s_hist[sub_of(hash64(eval_tuple(P.g, P.entries, t[u]).key), f2)], 1u);
+                    if (i0 + u * L2_NT < hi) atomicAdd(&s_hist[sub_from_sel16(sel[u], f2)], 1u);
             }
         }
     if (P.okeys)
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
             const uint64_t base = P.obase[q];
             const uint32_t n = P.ocount[q];
-            for (uint32_t i = threadIdx.x; i < n; i += L2_NT) atomicAdd(&s_ohist[sub_of(hash64(P.okeys[base + i]), f2)], 1u);
+            for (uint32_t i = threadIdx.x; i < n; i += L2_NT) atomicAdd(&s_ohist[sub_of(cell_hash(P.okeys[base + i]), f2)], 1u);
         }
     __syncthreads();
     if (threadIdx.x == 0) {  // f2 <= 256: a serial prefix is a few hundred LDS reads
@@ -629,15 +723,17 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
             const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
             for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += L2_NT * L2_UNROLL) {
                 GridTuple t[L2_UNROLL];
+                uint32_t sel[L2_UNROLL];
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++) {
                     const uint32_t i = i0 + u * L2_NT;
                     t[u] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
+                    sel[u] = sg.sub16[i < hi ? i : hi - 1];
                 }
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++) {
                     if (i0 + u * L2_NT >= hi) continue;
-                    const uint32_t pos = atomicAdd(&s_cur[sub_of(hash64(eval_tuple(P.g, P.entries, t[u]).key), f2)], 1u);
+                    const uint32_t pos = atomicAdd(&s_cur[sub_from_sel16(sel[u], f2)], 1u);
                     st_tuple(P.out + pos, t[u]);
                 }
             }
@@ -648,7 +744,143 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
             const uint32_t n = P.ocount[q];
             for (uint32_t i = threadIdx.x; i < n; i += L2_NT) {
                 const uint64_t key = P.okeys[base + i];
-                const uint32_t pos = atomicAdd(&s_ocur[sub_of(hash64(key), f2)], 1u);
+                const uint32_t pos = atomicAdd(&s_ocur[sub_of(cell_hash(key), f2)], 1u);
+                P.okeys2[pos] = key;
+                const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + (base + i) * 32);
+                uint4 *dp = reinterpret_cast<uint4 *>(P.orecs2 + (uint64_t)pos * 32);
+                dp[0] = sp[0];
+                dp[1] = sp[1];
+            }
+        }
+}
+
+// The staged form (f2 <= 1024): the sub-partition of a tuple comes from its stored selector (no cell arithmetic), the
+// histogram pass reads only the 2-byte selectors, and the scatter pass sorts a tile of 1536 tuples by sub-partition in LDS
+// so that they leave as runs — the direct form's scattered 24-byte stores reached HBM as 6.4 GB for 3.9 GB of tuples
+// (profiles/r02_grid_pmc.txt).
+__global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
+    __shared__ uint32_t s_hist[L2_STAGED_F2], s_cur[L2_STAGED_F2], s_ohist[L2_STAGED_F2], s_ocur[L2_STAGED_F2];
+    __shared__ uint32_t s_cnt[L2_STAGED_F2], s_base[L2_STAGED_F2];
+    __shared__ uint2 s_stage[L2_TILE * 3];
+    __shared__ uint32_t s_tpos[L2_TILE];
+    __shared__ uint32_t s_wsum[L2_NT / 64], s_total;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t bin = blockIdx.x, f2 = P.f2;
+    for (uint32_t t = threadIdx.x; t < L2_STAGED_F2; t += L2_NT) s_hist[t] = 0, s_ohist[t] = 0, s_cnt[t] = 0;
+    __syncthreads();
+    if (P.binbase)
+        for (int r = 0; r < P.nsegs; r++) {
+            const GridSeg sg = P.segs[r];
+            const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
+            for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += L2_NT * L2_UNROLL) {  // the loads of four steps are issued together
+                uint32_t sel[L2_UNROLL];
+#pragma unroll
+                for (int u = 0; u < L2_UNROLL; u++) {
+                    const uint32_t i = i0 + u * L2_NT;
+                    sel[u] = sg.sub16[i < hi ? i : hi - 1];
+                }
+#pragma unroll
+                for (int u = 0; u < L2_UNROLL; u++)
+                    if (i0 + u * L2_NT < hi) atomicAdd(&s_hist[sub_from_sel16(sel[u], f2)], 1u);
+            }
+        }
+    if (P.okeys)
+        for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
+            const uint64_t base = P.obase[q];
+            const uint32_t n = P.ocount[q];
+            for (uint32_t i = threadIdx.x; i < n; i += L2_NT) atomicAdd(&s_ohist[sub_of(cell_hash(P.okeys[base + i]), f2)], 1u);
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // f2 <= 1024: a serial prefix is a thousand LDS reads
+        uint32_t run = P.binbase ? P.binbase[bin] : 0, orun = P.okeys ? P.obinbase[bin] : 0;
+        for (uint32_t s = 0; s < f2; s++) {
+            if (P.binbase) P.off2[bin * f2 + s] = run;
+            s_cur[s] = run;
+            run += s_hist[s];
+            if (P.okeys) P.ooff2[bin * f2 + s] = orun;
+            s_ocur[s] = orun;
+            orun += s_ohist[s];
+        }
+        if (bin == F1 - 1) {
+            if (P.binbase) P.off2[F1 * f2] = run;
+            if (P.okeys) P.ooff2[F1 * f2] = orun;
+        }
+    }
+    __syncthreads();
+    if (P.binbase)
+        for (int r = 0; r < P.nsegs; r++) {
+            const GridSeg sg = P.segs[r];
+            const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
+            for (uint32_t base = lo; base < hi; base += L2_TILE) {
+                GridTuple t[L2_ITEMS];
+                uint32_t subs[L2_ITEMS], ranks[L2_ITEMS];
+                bool valid[L2_ITEMS];
+#pragma unroll
+                for (int j = 0; j < L2_ITEMS; j++) {
+                    const uint32_t i = base + j * L2_NT + threadIdx.x;
+                    valid[j] = i < hi;
+                    t[j] = ld_tuple(sg.tuples + (valid[j] ? i : hi - 1));
+                    subs[j] = sub_from_sel16(sg.sub16[valid[j] ? i : hi - 1], f2);
+                }
+#pragma unroll
+                for (int j = 0; j < L2_ITEMS; j++)
+                    if (valid[j]) ranks[j] = atomicAdd(&s_cnt[subs[j]], 1u);
+                __syncthreads();
+                {  // exclusive scan of the tile's counts over the sub-partitions (two per thread)
+                    const uint32_t s0 = threadIdx.x * 2;
+                    const uint32_t v0 = s_cnt[s0], v1 = s_cnt[s0 + 1];
+                    uint32_t incl = v0 + v1;
+#pragma unroll
+                    for (int off = 1; off < 64; off <<= 1) {
+                        const uint32_t up = __shfl_up(incl, off, 64);
+                        if (lane >= off) incl += up;
+                    }
+                    if (lane == 63) s_wsum[wave] = incl;
+                    __syncthreads();
+                    uint32_t before = incl - v0 - v1, total = 0;
+                    for (int w = 0; w < L2_NT / 64; w++) {
+                        before += w < wave ? s_wsum[w] : 0;
+                        total += s_wsum[w];
+                    }
+                    s_base[s0] = before;
+                    s_base[s0 + 1] = before + v0;
+                    s_cnt[s0] = 0;
+                    s_cnt[s0 + 1] = 0;
+                    if (threadIdx.x == 0) s_total = total;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < L2_ITEMS; j++) {
+                    if (!valid[j]) continue;
+                    const uint32_t at = s_base[subs[j]] + ranks[j];
+                    s_stage[at * 3] = make_uint2((uint32_t)t[j].x, (uint32_t)t[j].y);
+                    s_stage[at * 3 + 1] = make_uint2((uint32_t)t[j].z, t[j].idx);
+                    s_stage[at * 3 + 2] = make_uint2(t[j].w0, t[j].w1);
+                    s_tpos[at] = s_cur[subs[j]] + ranks[j];
+                }
+                __syncthreads();
+                {  // the cursors move on (thread t owns sub-partitions 2t, 2t + 1: their tile counts are s_base differences)
+                    const uint32_t s0 = threadIdx.x * 2, total = s_total;
+                    const uint32_t b0 = s_base[s0], b1 = s_base[s0 + 1], b2 = s0 + 2 < L2_STAGED_F2 ? s_base[s0 + 2] : total;
+                    s_cur[s0] += b1 - b0;
+                    s_cur[s0 + 1] += b2 - b1;
+                    uint2 *out2 = reinterpret_cast<uint2 *>(P.out);
+                    for (uint32_t k = threadIdx.x; k < total; k += L2_NT) {
+                        const uint2 a = s_stage[k * 3], b = s_stage[k * 3 + 1], d = s_stage[k * 3 + 2];
+                        uint2 *q = out2 + (uint64_t)s_tpos[k] * 3;
+                        q[0] = a, q[1] = b, q[2] = d;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    if (P.okeys)
+        for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
+            const uint64_t base = P.obase[q];
+            const uint32_t n = P.ocount[q];
+            for (uint32_t i = threadIdx.x; i < n; i += L2_NT) {
+                const uint64_t key = P.okeys[base + i];
+                const uint32_t pos = atomicAdd(&s_ocur[sub_of(cell_hash(key), f2)], 1u);
                 P.okeys2[pos] = key;
                 const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + (base + i) * 32);
                 uint4 *dp = reinterpret_cast<uint4 *>(P.orecs2 + (uint64_t)pos * 32);
@@ -760,7 +992,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
         // earlier winners first: their distance is recomputed from the record (same f64 expressions, same bits)
         for (uint32_t i = threadIdx.x; i < n_old; i += NT) {
             const uint64_t key = P.okeys[old_base + i];
-            const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, key, hash64(key), &s_ncell);
+            const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, key, cell_hash(key), &s_ncell);
             if (s < 0) {
                 s_over = 1;
                 continue;
@@ -807,7 +1039,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                 if (i >= cnt) continue;
                 const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
                 dbits[k] = ev.dbits;
-                const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, hash64(ev.key), &s_ncell);
+                const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, cell_hash(ev.key), &s_ncell);
                 if (s < 0) {
                     s_over = 1;
                     continue;
@@ -910,7 +1142,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                         if (i >= cnt) continue;
                         const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
                         dbits[k] = ev.dbits;
-                        const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, hash64(ev.key), &s_ncell);
+                        const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, cell_hash(ev.key), &s_ncell);
                         if (s < 0) {
                             s_over = 1;
                             continue;
@@ -1087,7 +1319,7 @@ __global__ __launch_bounds__(BLOCK) void k_alias_replay(const AliasItem *__restr
     if (e >= n) return;
     const uint64_t key = sorted[e].key;
     if (e > 0 && sorted[e - 1].key == key) return;
-    const uint64_t h = hash64(key);
+    const uint64_t h = cell_hash(key);
     const uint32_t p = bin_of(h) * f2 + sub_of(h, f2);
     const uint64_t wb = P.wbase[p];
     const uint32_t wn = P.wcount[p];
@@ -1176,6 +1408,7 @@ __global__ __launch_bounds__(BLOCK) void k_drain(const uint64_t *__restrict__ wk
 // ---------------------------------------------------------------------------------------------------------------
 struct GridRun {
     GridTuple *tuples;
+    uint16_t *sub16;   // per tuple: the second-level selector (same slab, behind the tuples)
     uint64_t cap;      // tuples the run has room for (= points scanned)
     uint32_t *binoff;  // device, F1 + 1
 };
@@ -1253,8 +1486,9 @@ struct Scratch {
 
 static int grid_fold(pcq_ctx *ctx, pcq_collector *c);
 
-static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, GridTuple **out) {
-    const size_t bytes = (size_t)tuples * sizeof(GridTuple);
+static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, GridTuple **out, uint16_t **out_sub16) {
+    const size_t tuple_bytes = ((size_t)tuples * sizeof(GridTuple) + 255) & ~(size_t)255;
+    const size_t bytes = tuple_bytes + (size_t)tuples * sizeof(uint16_t);
     if (bytes > gs->slab_left) {
         size_t slab = 256ull << 20;
         if (slab < bytes) slab = bytes;
@@ -1266,6 +1500,7 @@ static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, GridTup
         gs->slab_left = slab;
     }
     *out = (GridTuple *)gs->slab_cur;
+    *out_sub16 = (uint16_t *)(gs->slab_cur + tuple_bytes);
     const size_t used = (bytes + 255) & ~(size_t)255;
     gs->slab_cur += used < gs->slab_left ? used : gs->slab_left;
     gs->slab_left -= used < gs->slab_left ? used : gs->slab_left;
@@ -1318,7 +1553,7 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         GridRun run;
         run.cap = cols.n;
         run.binoff = gs->binoff_store + gs->runs.size() * (F1 + 1);
-        int rc = grid_tuple_room(ctx, gs, cols.n, &run.tuples);
+        int rc = grid_tuple_room(ctx, gs, cols.n, &run.tuples, &run.sub16);
         if (rc) return rc;
         gs->pending_cap += cols.n;
 
@@ -1338,11 +1573,11 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         hipLaunchKernelGGL(k_p0_scan_blocks, dim3(F1 / WAVES), dim3(BLOCK), 0, s, cnt, (int)nblocks, total);
         hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, total, run.binoff, (uint32_t)F1);
         if (pred.kind == PCQ_PRED_BOUNDS)
-            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_BOUNDS>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
+            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_BOUNDS>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, run.sub16, entry, idx_base);
         else if (pred.kind == PCQ_PRED_CLASS)
-            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_CLASS>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
+            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_CLASS>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, run.sub16, entry, idx_base);
         else
-            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_BOUNDS_F64>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
+            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_BOUNDS_F64>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, run.sub16, entry, idx_base);
         PCQ_HIP(hipGetLastError());
         gs->runs.push_back(run);
     }
@@ -1361,7 +1596,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
 
     // run directory + entries
     std::vector<GridSeg> hsegs(nruns);
-    for (int r = 0; r < nruns; r++) hsegs[r] = GridSeg{gs->runs[r].tuples, gs->runs[r].binoff};
+    for (int r = 0; r < nruns; r++) hsegs[r] = GridSeg{gs->runs[r].tuples, gs->runs[r].binoff, gs->runs[r].sub16};
     GridSeg *d_segs = nullptr;
     GridEntryDev *d_entries = nullptr;
     uint32_t *d_bintot = nullptr, *d_binbase = nullptr;
@@ -1457,11 +1692,12 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 L.okeys = gs->wkeys, L.orecs = gs->wrecs, L.obase = gs->wbase, L.ocount = gs->wcount, L.f2old = gs->f2;
                 L.obinbase = d_obinbase, L.okeys2 = d_okeys2, L.orecs2 = d_orecs2, L.ooff2 = d_ooff2;
             }
-            hipLaunchKernelGGL(k_level2, dim3(F1), dim3(L2_NT), 0, s, L);
+            if (f2 <= (uint32_t)L2_STAGED_F2) hipLaunchKernelGGL(k_level2, dim3(F1), dim3(L2_NT), 0, s, L);
+            else hipLaunchKernelGGL(k_level2_direct, dim3(F1), dim3(L2_NT), 0, s, L);
             PCQ_HIP(hipGetLastError());
             if (f2 > 1) {
                 ctx->grid_level2++;
-                GridSeg one{d_t2, d_off2};
+                GridSeg one{d_t2, d_off2, nullptr};
                 GridSeg *d_one = nullptr;
                 uint32_t *d_tot2 = nullptr;
                 rc = att.get(1, &d_one);

@@ -562,6 +562,9 @@ extern "C" int pcq_collector_new_grid(pcq_ctx *ctx, const double bmin[3], const 
         g.bmax[a] = bmax[a];
         g.dims_f[a] = (double)c->dims[a];
         g.inv_extent[a] = 1.0 / (bmax[a] - bmin[a]);
+        g.qk[a] = g.dims_f[a] / (bmax[a] - bmin[a]);
+        g.qmax[a] = g.dims_f[a] + 2.0 < 0x1p31 ? g.dims_f[a] + 2.0 : 0x1p31;  // every point inside the bounds is below dims + 1
+        g.guard[a] = g.qmax[a] * 0x1p-50;
         g.mask[a] = (1ull << (c->bits[a] & 63)) - 1;  // Rust release `1u64 << n` masks n to 6 bits
     }
     g.cell_size = cell_size;

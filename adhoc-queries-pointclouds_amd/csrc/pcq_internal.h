@@ -102,6 +102,8 @@ struct DevGrid {
     double cell_size;
     double dims_f[3];     // dims as f64 (`self.dimensions.x as f64`, grid_sampling.rs:51)
     double inv_extent[3]; // 1 / (bmax - bmin): only to find the cell WITHOUT the division when that is provably safe (grid.hip cell_of)
+    double qk[3];         // RN(dims / (bmax - bmin)), and the range / boundary guard of the short cell computation (grid.hip cell_fast)
+    double qmax[3], guard[3];
     uint64_t mask[3];     // (1 << bits) - 1
     uint32_t shift[3];    // 0, bits_x, bits_x + bits_y  (already & 63)
 };

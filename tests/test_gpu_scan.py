@@ -253,6 +253,48 @@ def test_grid_collector_on_spatially_coherent_files(oracle, gpu_ctx, cell):
         f.free()
 
 
+@pytest.mark.parametrize("cell,bmin,bmax", [
+    (2.5, (-20.0, -20.0, -5.0), (20.0, 20.0, 5.0)),      # 2.5 / 0.01: every 250th integer coordinate is a cell boundary
+    (0.64, (-32.0, -32.0, -6.4), (32.0, 32.0, 6.4)),     # 0.64 / 0.01 = 64: the snapped third of the points sits on boundaries
+    (1.0, (-10.0, -10.0, -2.0), (10.0, 10.0, 2.0)),      # a grid smaller than the data: the class query brings points below and beyond it
+    (3.0, (5.0, 5.0, 1.0), (5.0, 40.0, 8.0)),            # a flat grid: zero extent along x (0 / 0 and x / 0 in the cell index)
+])
+def test_grid_cells_on_and_next_to_cell_boundaries(oracle, gpu_ctx, cell, bmin, bmax):
+    """The kernels find a point's cell with one multiply and take the reference's division only within a few ulp of a
+    cell boundary, outside the grid's range or for a degenerate grid: files whose coordinates sit ON the boundaries
+    (and one integer step either side), below the grid's minimum (the reference saturates to cell 0) and beyond its
+    maximum must give the reference's cells and winners."""
+    n = 120_011
+    spec = small_spec(4711, n, fmt=2)
+    image = oracle.synth_image(spec, transposed=True).copy()
+    hdr = oracle.parse_header(image[:400].tobytes())
+    otp = hdr.offset_to_point_data
+    xyz = image[otp:otp + 12 * n].view("<i4").reshape(n, 3).copy()
+    rng = np.random.default_rng(99)
+    step = max(1, int(round(cell / 0.01)))
+    snap = rng.random(n) < 0.4
+    xyz[snap] = xyz[snap] // step * step + rng.integers(-1, 2, size=(int(snap.sum()), 3))
+    image[otp:otp + 12 * n] = np.frombuffer(np.ascontiguousarray(xyz).tobytes(), dtype=np.uint8)
+    f = DevFile(gpu_ctx, image, hdr)
+    try:
+        lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+        for pred, search in ((pkg.Predicate.bounds(lmin, lmax), lambda og: oracle.search_last_bounds(image, bmin, bmax, og)),
+                             (pkg.Predicate.classification(1), lambda og: oracle.search_last_class(image, 1, og))):
+            og = oracle.grid_collector(bmin, bmax, cell)
+            assert search(og) == 0
+            gg = gpu_ctx.grid_collector(bmin, bmax, cell)
+            gpu_ctx.scan_dev(f.columns(True), pred, gg)
+            assert gg.point_count() == og.point_count()
+            gp, gk = gg.points(), gg.grid_cells()
+            order_k = np.argsort(gk, kind="stable")
+            assert np.array_equal(gk[order_k], og.grid_cells())
+            assert gp[order_k].tobytes() == og.points().tobytes()
+            gg.free()
+            og.free()
+    finally:
+        f.free()
+
+
 def test_grid_fold_levels_refold_and_forced_fanout(oracle):
     """The grid collector partitions the matches by cell key and folds each partition in LDS (csrc/grid.hip): a coarse
     grid folds its 512 level-1 bins directly (one 6400-slot table per workgroup), a dense one gets a second partition
