@@ -56,6 +56,7 @@ constexpr int P0_MAX_BLOCKS = 1024;    // pass 0: at most this many workgroups (
 constexpr int BIG_SLOTS = 6400, BIG_NT = 1024, BIG_LIMIT = 5440, BIG_DIRECT = 4700;
 constexpr int SMALL_SLOTS = 2048, SMALL_NT = 256, SMALL_K = 6, SMALL_LIMIT = 1740, SMALL_TARGET = 1000;
 constexpr int BIG_K = 4;               // fold: tuples per thread and chunk
+constexpr int DENSE_NT = 512, DENSE_K = 3;  // k_fold_dense: the same chunk (1536 tuples) on twice the waves
 constexpr int L2_NT = 512;             // second level: threads per workgroup (one workgroup per level-1 bin)
 constexpr int L2_UNROLL = 4;
 constexpr int L2_ITEMS = 3;            // second level, staged form: tuples per thread and tile (1536 tuples = 36 KB of LDS)
@@ -160,7 +161,14 @@ struct CellFast {
     double f[3];  // c as f64
     bool ok;
 };
-__device__ __forceinline__ CellFast cell_fast(const DevGrid &g, double px, double py, double pz) {
+// what the short computation reads of the grid (the kernel arguments of k_fold_dense: 32 scalar registers instead of 53)
+struct DevGridFast {
+    double bmin[3], qk[3], qmax[3], guard[3];
+    double cell_size;
+    uint32_t mask[3], shift[3];
+};
+template <typename G>
+__device__ __forceinline__ CellFast cell_fast(const G &g, double px, double py, double pz) {
     const double p[3] = {px, py, pz};
     CellFast r;
     r.ok = true;
@@ -175,7 +183,8 @@ __device__ __forceinline__ CellFast cell_fast(const DevGrid &g, double px, doubl
     }
     return r;
 }
-__device__ __forceinline__ uint64_t key_fast(const DevGrid &g, const CellFast &cf, bool *alias) {
+template <typename G>
+__device__ __forceinline__ uint64_t key_fast(const G &g, const CellFast &cf, bool *alias) {
     uint64_t key = 0;
     uint32_t beyond = 0;
 #pragma unroll
@@ -187,7 +196,8 @@ __device__ __forceinline__ uint64_t key_fast(const DevGrid &g, const CellFast &c
     *alias = beyond != 0;
     return key;
 }
-__device__ __forceinline__ double centre_dist_fast(const DevGrid &g, const CellFast &cf, double px, double py, double pz) {
+template <typename G>
+__device__ __forceinline__ double centre_dist_fast(const G &g, const CellFast &cf, double px, double py, double pz) {
     const double cx = (cf.f[0] + 0.5) * g.cell_size + g.bmin[0];
     const double cy = (cf.f[1] + 0.5) * g.cell_size + g.bmin[1];
     const double cz = (cf.f[2] + 0.5) * g.cell_size + g.bmin[2];
@@ -929,7 +939,9 @@ struct FoldParams {
     uint32_t *wcount;
     uint32_t *palias;              // [P] 1: the partition holds aliased keys
     uint32_t *pay_scratch;         // BIG: the parked payloads, 5 words per slot and partition
-    unsigned long long *stats;     // [0] winners, [1] partitions that overflowed the LDS table, [2] partitions with aliased keys
+    unsigned long long *stats;     // [0] winners, [1] partitions that overflowed the LDS table, [2] partitions with aliased keys,
+                                   // [3] partitions k_fold_dense left to k_fold
+    uint32_t *defer_list;          // k_fold_dense: the partitions it leaves; k_fold: fold these (stats[3] of them) instead of 0..nparts
 };
 
 // Slot of `key` in the LDS table, inserting it if absent; -1 when the table is full (LIMIT cells).
@@ -975,11 +987,19 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
     uint64_t cur_out = 0, nxt_out = 0;
     GridTuple first[XPART ? FOLD_K : 1];
     bool have_first = false;  // first[] holds the first chunk of the current partition (prefetched by the direct path)
-    uint32_t p = blockIdx.x;
-    if (p < nparts) cur_lo = sg0.off[p], cur_cnt = sg0.off[p + 1] - cur_lo, cur_out = P.wbase[p];
-    for (; p < nparts; p += gridDim.x) {
-        const uint32_t pn = p + gridDim.x;
-        if (pn < nparts) nxt_lo = sg0.off[pn], nxt_cnt = sg0.off[pn + 1] - nxt_lo, nxt_out = P.wbase[pn];
+    if (P.defer_list) nparts = (uint32_t)P.stats[3];  // only what k_fold_dense left
+    uint32_t it = blockIdx.x, p = 0, p_next = 0;
+    if (it < nparts) {
+        p_next = P.defer_list ? P.defer_list[it] : it;
+        cur_lo = sg0.off[p_next], cur_cnt = sg0.off[p_next + 1] - cur_lo, cur_out = P.wbase[p_next];
+    }
+    for (; it < nparts; it += gridDim.x) {
+        p = p_next;
+        const uint32_t pn = it + gridDim.x;
+        if (pn < nparts) {
+            p_next = P.defer_list ? P.defer_list[pn] : pn;
+            nxt_lo = sg0.off[p_next], nxt_cnt = sg0.off[p_next + 1] - nxt_lo, nxt_out = P.wbase[p_next];
+        }
         uint32_t *pay = PAY_LDS ? s_pay_lds : P.pay_scratch + (size_t)blockIdx.x * NSLOT * 5;  // HBM scratch of this workgroup
         const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
         const uint64_t old_base = P.okeys ? P.obase[p] : 0;
@@ -1256,6 +1276,182 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
         cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
         __syncthreads();  // the table is cleared for the next partition
     }
+}
+
+// The fold of a dense grid's partitions, on its own: one segment (the second level's output), no earlier winners, the
+// partition's tuples in one chunk of registers.  k_fold handles every case and pays for it in registers (168, three waves
+// per SIMD) — and a small partition is a chain of latencies (its offsets, its tuples, three barriers, the stores), so the
+// waves per CU decide its speed.  This kernel keeps only the common case: 512 threads x 3 tuples, 6 waves per SIMD.
+//  * every thread holds its tuples from the load to the end: the winner of a cell writes the record from registers;
+//  * the table is cleared once: every occupied slot has exactly one winner, which resets the slot behind itself;
+//  * the tuples are loaded and evaluated BEFORE the barrier that separates the partitions;
+//  * a partition with more tuples than a chunk goes on stats[3] / defer_list for k_fold.
+struct DenseParams {
+    const GridTuple *tuples;       // the second level's output and its partition offsets
+    const uint32_t *off;
+    EntryRef entries;
+    DevGridFast g;
+    const DevGrid *gfull;          // device copy of the whole grid: the exact computation next to a cell boundary
+    uint64_t *wkeys;
+    uint8_t *wrecs;
+    const uint64_t *wbase;
+    uint32_t *wcount;
+    uint32_t *palias;
+    unsigned long long *stats;
+    uint32_t *defer_list;
+};
+template <int NSLOT, int NT, int FOLD_K, int LIMIT, int MIN_WAVES>
+__global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uint32_t nparts) {
+    constexpr int CHUNK = NT * FOLD_K;
+    __shared__ uint64_t s_key[NSLOT];
+    __shared__ uint64_t s_dist[NSLOT];
+    __shared__ uint64_t s_ord[NSLOT];
+    __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32];
+    __shared__ uint32_t s_ncell, s_wsum[NT / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const GridTuple *tuples = P.tuples;
+    const uint32_t *off = P.off;
+    for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
+    for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
+    if (threadIdx.x == 0) s_ncell = 0;
+    unsigned long long winners = 0;  // thread 0: this workgroup's winners
+
+    uint32_t cur_lo = 0, cur_cnt = 0, nxt_lo = 0, nxt_cnt = 0;
+    uint64_t cur_out = 0, nxt_out = 0;
+    uint32_t p = blockIdx.x;
+    if (p < nparts) cur_lo = off[p], cur_cnt = off[p + 1] - cur_lo, cur_out = P.wbase[p];
+    for (; p < nparts; p += gridDim.x) {
+        const uint32_t pn = p + gridDim.x;
+        if (pn < nparts) nxt_lo = off[pn], nxt_cnt = off[pn + 1] - nxt_lo, nxt_out = P.wbase[pn];
+        const uint32_t cnt = cur_cnt;
+        if (cnt > (uint32_t)CHUNK) {  // (the same for every thread of the workgroup)
+            if (threadIdx.x == 0) P.defer_list[atomicAdd(&P.stats[3], 1ull)] = p;
+            cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
+            continue;
+        }
+        GridTuple tu[FOLD_K];
+        uint64_t key[FOLD_K], dbits[FOLD_K];
+        bool alias[FOLD_K];
+#pragma unroll
+        for (int k = 0; k < FOLD_K; k++) {
+            const uint32_t i = k * NT + threadIdx.x;
+            tu[k] = ld_tuple(tuples + cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0)));
+        }
+        uint32_t inexact = 0;  // bit k: tuple k is next to a cell boundary (or outside the short computation's range)
+#pragma unroll
+        for (int k = 0; k < FOLD_K; k++) {
+            const GridEntryDev e = P.entries.get((tu[k].w0 >> 8) & 0xff);
+            const double px = world(tu[k].x, e.scale[0], e.offset[0]), py = world(tu[k].y, e.scale[1], e.offset[1]),
+                         pz = world(tu[k].z, e.scale[2], e.offset[2]);
+            const CellFast cf = cell_fast(P.g, px, py, pz);
+            key[k] = key_fast(P.g, cf, &alias[k]);
+            dbits[k] = (uint64_t)__double_as_longlong(centre_dist_fast(P.g, cf, px, py, pz));
+            inexact |= cf.ok ? 0u : 1u << k;
+        }
+        if (__any(inexact != 0)) {  // rare: one copy of the exact computation, off the common path
+#pragma unroll 1
+            for (int kk = 0; kk < FOLD_K; kk++) {
+                if (!((inexact >> kk) & 1)) continue;
+                int32_t x = tu[0].x, y = tu[0].y, z = tu[0].z;
+                uint32_t w0 = tu[0].w0;
+#pragma unroll
+                for (int j = 1; j < FOLD_K; j++)
+                    if (j == kk) x = tu[j].x, y = tu[j].y, z = tu[j].z, w0 = tu[j].w0;
+                const GridEntryDev e = P.entries.get((w0 >> 8) & 0xff);
+                const TupleEval ev = eval_exact(*P.gfull, world(x, e.scale[0], e.offset[0]), world(y, e.scale[1], e.offset[1]), world(z, e.scale[2], e.offset[2]));
+#pragma unroll
+                for (int j = 0; j < FOLD_K; j++)
+                    if (j == kk) key[j] = ev.key, dbits[j] = ev.dbits, alias[j] = ev.alias;
+            }
+        }
+        __syncthreads();  // the table is clean: the previous partition's winners have reset their slots
+        int slot[FOLD_K];
+        bool over = false;
+#pragma unroll
+        for (int k = 0; k < FOLD_K; k++) {  // phase 1: cells and their minimum distance
+            slot[k] = -1;
+            if ((uint32_t)(k * NT) + threadIdx.x >= cnt) continue;
+            const int sl = lds_find_or_insert<NSLOT, LIMIT>(s_key, key[k], cell_hash(key[k]), &s_ncell);
+            if (sl < 0) {
+                over = true;
+                continue;
+            }
+            slot[k] = sl;
+            if (alias[k]) atomicOr(&s_aliasbits[sl >> 5], 1u << (sl & 31));
+            atomicMin((unsigned long long *)&s_dist[sl], (unsigned long long)dbits[k]);
+        }
+        if (__syncthreads_or(over)) {  // more cells than the table holds: the host repeats the fold with more partitions
+            for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
+            for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
+            if (threadIdx.x == 0) {
+                s_ncell = 0;
+                P.wcount[p] = 0;
+                atomicAdd(&P.stats[1], 1ull);
+            }
+            cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
+            continue;
+        }
+        bool cand[FOLD_K];
+#pragma unroll
+        for (int k = 0; k < FOLD_K; k++) {  // phase 2: among the tuples at the minimum, the earliest in file order
+            cand[k] = slot[k] >= 0 && dbits[k] == s_dist[slot[k]];
+            if (cand[k]) atomicMin((unsigned long long *)&s_ord[slot[k]], (unsigned long long)ord_of(tu[k]));
+        }
+        __syncthreads();
+        // every occupied slot has exactly one tuple at (minimum distance, earliest order): its thread writes the cell
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < FOLD_K; k++) {
+            cand[k] = cand[k] && s_ord[slot[k]] == ord_of(tu[k]);
+            mine += cand[k] ? 1 : 0;
+        }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine, total = 0;
+#pragma unroll
+        for (int w = 0; w < NT / 64; w++) {
+            before += w < wave ? s_wsum[w] : 0;
+            total += s_wsum[w];
+        }
+        uint64_t o = cur_out + before;
+#pragma unroll
+        for (int k = 0; k < FOLD_K; k++) {
+            if (!cand[k]) continue;
+            const int sl = slot[k];
+            P.wkeys[o] = key[k];
+            uint8_t *dst = P.wrecs + o * 32;
+            const uint32_t abit = 1u << (sl & 31);
+            if (s_aliasbits[sl >> 5] & abit) {  // left to the exact replay: no point yet, the flag
+                reinterpret_cast<uint4 *>(dst)[0] = make_uint4(0, 0, 0, 0);
+                reinterpret_cast<uint4 *>(dst)[1] = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
+                atomicAnd(&s_aliasbits[sl >> 5], ~abit);
+                if (atomicExch(&P.palias[p], 1u) == 0) atomicAdd(&P.stats[2], 1ull);
+            } else {
+                // (the record's coordinates are computed again from the integers: kept from the evaluation above they would
+                // cost nine registers per tuple across the three barriers — the compiler spills them if it sees the same
+                // expression, hence the opaque copies)
+                int32_t x = tu[k].x, y = tu[k].y, z = tu[k].z;
+                uint32_t w0 = tu[k].w0;
+                asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w0));
+                st_record(dst, P.entries.get((w0 >> 8) & 0xff), x, y, z, w0, tu[k].w1, R_HAS);
+            }
+            s_key[sl] = PCQ_EMPTY_KEY, s_dist[sl] = ~0ull, s_ord[sl] = ~0ull;
+            o++;
+        }
+        if (threadIdx.x == 0) {
+            s_ncell = 0;
+            P.wcount[p] = total;
+            winners += total;
+        }
+        cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
+    }
+    if (threadIdx.x == 0 && winners) atomicAdd(&P.stats[0], winners);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1606,7 +1802,10 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     if (!rc) rc = tmp.get(F1, &d_bintot);
     if (!rc) rc = tmp.get(F1 + 1, &d_binbase);
     if (!rc) rc = tmp.get(8, &d_stats);
+    DevGrid *d_grid = nullptr;
+    if (!rc) rc = tmp.get(1, &d_grid);
     if (rc) return rc;
+    PCQ_HIP(hipMemcpyAsync(d_grid, &g, sizeof g, hipMemcpyHostToDevice, s));
     PCQ_HIP(hipMemcpyAsync(d_segs, hsegs.data(), nruns * sizeof(GridSeg), hipMemcpyHostToDevice, s));
     PCQ_HIP(hipMemcpyAsync(d_entries, gs->entries.data(), gs->entries.size() * sizeof(GridEntryDev), hipMemcpyHostToDevice, s));
     EntryRef eref;
@@ -1721,7 +1920,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         if (wcap >= (1ull << 32)) return pcq_fail(PCQ_ERR_UNSUPPORTED, "grid collector: more than 2^32 cells in one fold");
         uint64_t *n_wkeys = nullptr, *n_wbase = nullptr, *d_room = nullptr, *d_pieces = nullptr, *d_piece_pre = nullptr;
         uint8_t *n_wrecs = nullptr;
-        uint32_t *n_wcount = nullptr, *d_palias = nullptr, *d_pay = nullptr;
+        uint32_t *n_wcount = nullptr, *d_palias = nullptr, *d_pay = nullptr, *d_defer = nullptr;
+        const bool dense = !big && fold_nsegs == 1 && !w_old;  // k_fold_dense first, k_fold for what it leaves
         const uint32_t npieces = (nparts + SCAN_PIECE - 1) / SCAN_PIECE;
         rc = att.get(wcap, &n_wkeys);
         if (!rc) rc = att.get(wcap * 32, &n_wrecs);
@@ -1733,6 +1933,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         if (!rc) rc = att.get((size_t)npieces + 1, &d_piece_pre);
         const uint32_t resident_wgs = (uint32_t)ctx->num_cus * (big ? 1u : 3u);  // what fits the LDS: the rest of the partitions is looped over
         if (!rc) rc = att.get((size_t)resident_wgs * (big ? BIG_SLOTS : SMALL_SLOTS) * 5, &d_pay);  // parked payloads, per resident workgroup
+        if (!rc && dense) rc = att.get(nparts, &d_defer);
         if (rc) return rc;
         hipLaunchKernelGGL(k_winner_room, dim3((nparts + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_tot, w_old ? ocount : nullptr, nparts, limit, d_room);
         hipLaunchKernelGGL(k_scan_piece_sums, dim3(npieces), dim3(1024), 0, s, d_room, nparts, d_pieces);
@@ -1747,6 +1948,18 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         {
             uint32_t resident = resident_wgs;
             if (resident > nparts) resident = nparts;
+            if (dense) {
+                F.defer_list = d_defer;
+                DenseParams D{};
+                D.tuples = fold_seg0.tuples, D.off = fold_seg0.off, D.entries = eref, D.gfull = d_grid;
+                for (int a = 0; a < 3; a++) {
+                    D.g.bmin[a] = g.bmin[a], D.g.qk[a] = g.qk[a], D.g.qmax[a] = g.qmax[a], D.g.guard[a] = g.guard[a];
+                    D.g.mask[a] = (uint32_t)g.mask[a], D.g.shift[a] = g.shift[a];
+                }
+                D.g.cell_size = g.cell_size;
+                D.wkeys = n_wkeys, D.wrecs = n_wrecs, D.wbase = n_wbase, D.wcount = n_wcount, D.palias = d_palias, D.stats = d_stats, D.defer_list = d_defer;
+                hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, 6>), dim3(resident), dim3(DENSE_NT), 0, s, D, nparts);
+            }
             if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
             else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, false, true, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
         }
