@@ -223,18 +223,28 @@ __device__ __forceinline__ uint32_t sub_of(uint64_t h, uint32_t f2) { return sub
 template <int NSLOT>
 __device__ __forceinline__ uint32_t slot_of(uint64_t h) { return (uint32_t)((((h >> 16) & 0x1fffffull) * NSLOT) >> 21); }
 
+// Pointers that a kernel reads out of a table in memory (GridSeg) are "generic" to the compiler: it emits flat loads, and
+// a flat load counts on the LDS counter as well — every wait for an LDS operation (each barrier of the tile loops) would
+// then also wait for the tuples in flight.  Everything here lives in global memory; these say so.
+#define PCQ_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ T ldg(const T *p) {
+    return *(const PCQ_GLOBAL T *)p;
+}
+typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));  // a 16-byte access at an 8-byte aligned address
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ GridTuple ld_tuple(const GridTuple *p) {
-    const uint2 *q = reinterpret_cast<const uint2 *>(p);
-    const uint2 a = q[0], b = q[1], c = q[2];
+    const u32x4_a8 a = *(const PCQ_GLOBAL u32x4_a8 *)p;
+    const u32x2 c = *(const PCQ_GLOBAL u32x2 *)(reinterpret_cast<const uint8_t *>(p) + 16);
     GridTuple t;
-    t.x = (int32_t)a.x, t.y = (int32_t)a.y, t.z = (int32_t)b.x, t.idx = b.y, t.w0 = c.x, t.w1 = c.y;
+    t.x = (int32_t)a.x, t.y = (int32_t)a.y, t.z = (int32_t)a.z, t.idx = a.w, t.w0 = c.x, t.w1 = c.y;
     return t;
 }
 __device__ __forceinline__ void st_tuple(GridTuple *p, const GridTuple &t) {
-    uint2 *q = reinterpret_cast<uint2 *>(p);
-    q[0] = make_uint2((uint32_t)t.x, (uint32_t)t.y);
-    q[1] = make_uint2((uint32_t)t.z, t.idx);
-    q[2] = make_uint2(t.w0, t.w1);
+    u32x4_a8 a = {(uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx};
+    *(PCQ_GLOBAL u32x4_a8 *)p = a;
+    u32x2 c = {t.w0, t.w1};
+    *(PCQ_GLOBAL u32x2 *)(reinterpret_cast<uint8_t *>(p) + 16) = c;
 }
 
 // The entry table as the kernels see it: entry 0 (often the only one) travels in the kernel arguments, so that the
@@ -242,9 +252,16 @@ __device__ __forceinline__ void st_tuple(GridTuple *p, const GridTuple &t) {
 struct EntryRef {
     const GridEntryDev *table;
     GridEntryDev e0;
+    // (written field by field with explicit global loads: as `id == 0 ? e0 : table[id]` the compiler selects between the
+    // two ADDRESSES — kernel argument segment or table — and loads six doubles through flat instructions for every tuple)
     __device__ __forceinline__ GridEntryDev get(uint32_t id) const {
-        if (id == 0) return e0;
-        return table[id];
+        GridEntryDev e = e0;
+        if (id != 0) {
+            const double *src = reinterpret_cast<const double *>(table + id);
+#pragma unroll
+            for (int a = 0; a < 3; a++) e.scale[a] = ldg(src + a), e.offset[a] = ldg(src + 3 + a);
+        }
+        return e;
     }
 };
 
@@ -450,7 +467,6 @@ __global__ __launch_bounds__(1024) void k_excl_scan_u64(const uint64_t *__restri
 // a bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.  A tuple is staged (and stored) as
 // 16 + 8 bytes; next to it one word holds its bin and its second-level selector: the bin gives the tuple's place in the
 // run (the tile's first place in the bin + the tuple's place in the sorted image), the selector goes to sub16.
-typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
 template <int KIND>
 __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
                                                       const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out,
@@ -473,6 +489,11 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
         const uint64_t i = begin + (uint64_t)j * P0_NT + threadIdx.x;
         cur[j] = p0_load<KIND>(c, i < end ? i : end - 1);
     }
+#pragma unroll
+    for (int j = 0; j < P0_ITEMS; j++) {  // (arrived: inside the loop nothing is pending at its head, see below)
+        if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
+        else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
+    }
     for (uint64_t base = begin; base < end; base += P0_TILE) {
         const uint64_t nbase = base + P0_TILE;
         if (nbase < end) {  // the next tile's inputs are on their way while this one is sorted
@@ -482,21 +503,26 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
                 nxt[j] = p0_load<KIND>(c, i < end ? i : end - 1);
             }
         }
+        // gfx950 counts loads and stores in ONE in-order counter (vmcnt): a wait for a load also waits for every store issued
+        // before it, and the compiler cannot count the stores of the copy-out loop — so a load must never be waited for
+        // right behind the copy-out.  Per tile: the attributes of this tile's matches are asked for here (nothing is
+        // computed on them until the staging, two barriers later); the next tile's positions were asked for above and are
+        // waited for BEFORE this tile's stores are issued.
         bool passes[P0_ITEMS];
-        uint32_t metas[P0_ITEMS], ranks[P0_ITEMS], w0[P0_ITEMS], w1[P0_ITEMS];
+        uint32_t metas[P0_ITEMS], ranks[P0_ITEMS], rg[P0_ITEMS], bb[P0_ITEMS], cl[P0_ITEMS];
 #pragma unroll
-        for (int j = 0; j < P0_ITEMS; j++) {  // the attributes of the matches: asked for here, used behind the two barriers
+        for (int j = 0; j < P0_ITEMS; j++) {
             const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
             passes[j] = i < end && p0_pass<KIND>(c, pr, cur[j]);
-            w0[j] = entry << 8, w1[j] = 0;
+            rg[j] = 0, bb[j] = 0, cl[j] = KIND == PCQ_PRED_CLASS ? cur[j].cls : 0;
             if (!passes[j]) continue;
             if (KIND == PCQ_PRED_CLASS) cur[j].rp = ld_xyz(c, i);
             if (c.rgb) {  // last.rs:145-153
                 const uint8_t *q = c.rgb + i * c.rgb_stride;
-                w0[j] |= ld_u16(q) << 16;
-                w1[j] = ld_u16(q + 2) | (ld_u16(q + 4) << 16);
+                rg[j] = ld_u16(q) | (ld_u16(q + 2) << 16);
+                bb[j] = ld_u16(q + 4);
             }
-            w0[j] |= KIND == PCQ_PRED_CLASS ? cur[j].cls : (c.cls ? c.cls[i * c.cls_stride] : 0);  // last.rs:138-142
+            if (KIND != PCQ_PRED_CLASS && c.cls) cl[j] = c.cls[i * c.cls_stride];  // last.rs:138-142
         }
 #pragma unroll
         for (int j = 0; j < P0_ITEMS; j++) {
@@ -535,8 +561,14 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
             const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
             const uint32_t at = s_base[metas[j] >> 16] + ranks[j];
             s_xyzi[at] = make_uint4((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y, (uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
-            s_attr[at] = make_uint2(w0[j], w1[j]);
+            s_attr[at] = make_uint2(cl[j] | (entry << 8) | (rg[j] << 16), (rg[j] >> 16) | (bb[j] << 16));
             s_meta[at] = metas[j];
+        }
+#pragma unroll
+        for (int j = 0; j < P0_ITEMS; j++) {  // the next tile's inputs have arrived (asked for a whole tile ago) — before the stores below
+            cur[j] = nxt[j];
+            if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
+            else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
         }
         __syncthreads();
         const uint32_t total = s_total;
@@ -551,8 +583,6 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
             *reinterpret_cast<uint2 *>(q + 16) = b;
             out_sub16[pos] = (uint16_t)meta;
         }
-#pragma unroll
-        for (int j = 0; j < P0_ITEMS; j++) cur[j] = nxt[j];
         __syncthreads();  // the stage and the bases are rewritten by the next tile
     }
 }
@@ -691,13 +721,13 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
     if (P.binbase)
         for (int r = 0; r < P.nsegs; r++) {
             const GridSeg sg = P.segs[r];
-            const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
+            const uint32_t lo = ldg(sg.off + bin), hi = ldg(sg.off + bin + 1);
             for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += L2_NT * L2_UNROLL) {  // the loads of four steps are issued together
                 uint32_t sel[L2_UNROLL];
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++) {
                     const uint32_t i = i0 + u * L2_NT;
-                    sel[u] = sg.sub16[i < hi ? i : hi - 1];
+                    sel[u] = ldg(sg.sub16 + (i < hi ? i : hi - 1));
                 }
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++)
@@ -730,7 +760,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
     if (P.binbase)
         for (int r = 0; r < P.nsegs; r++) {
             const GridSeg sg = P.segs[r];
-            const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
+            const uint32_t lo = ldg(sg.off + bin), hi = ldg(sg.off + bin + 1);
             for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += L2_NT * L2_UNROLL) {
                 GridTuple t[L2_UNROLL];
                 uint32_t sel[L2_UNROLL];
@@ -738,7 +768,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
                 for (int u = 0; u < L2_UNROLL; u++) {
                     const uint32_t i = i0 + u * L2_NT;
                     t[u] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
-                    sel[u] = sg.sub16[i < hi ? i : hi - 1];
+                    sel[u] = ldg(sg.sub16 + (i < hi ? i : hi - 1));
                 }
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++) {
@@ -771,7 +801,8 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
 __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
     __shared__ uint32_t s_hist[L2_STAGED_F2], s_cur[L2_STAGED_F2], s_ohist[L2_STAGED_F2], s_ocur[L2_STAGED_F2];
     __shared__ uint32_t s_cnt[L2_STAGED_F2], s_base[L2_STAGED_F2];
-    __shared__ uint2 s_stage[L2_TILE * 3];
+    __shared__ uint4 s_xyzi[L2_TILE];   // the tile's tuples, sorted by sub-partition: x, y, z, idx
+    __shared__ uint2 s_attr[L2_TILE];   //                                                 w0, w1
     __shared__ uint32_t s_tpos[L2_TILE];
     __shared__ uint32_t s_wsum[L2_NT / 64], s_total;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -781,13 +812,13 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
     if (P.binbase)
         for (int r = 0; r < P.nsegs; r++) {
             const GridSeg sg = P.segs[r];
-            const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
+            const uint32_t lo = ldg(sg.off + bin), hi = ldg(sg.off + bin + 1);
             for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += L2_NT * L2_UNROLL) {  // the loads of four steps are issued together
                 uint32_t sel[L2_UNROLL];
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++) {
                     const uint32_t i = i0 + u * L2_NT;
-                    sel[u] = sg.sub16[i < hi ? i : hi - 1];
+                    sel[u] = ldg(sg.sub16 + (i < hi ? i : hi - 1));
                 }
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++)
@@ -820,21 +851,36 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
     if (P.binbase)
         for (int r = 0; r < P.nsegs; r++) {
             const GridSeg sg = P.segs[r];
-            const uint32_t lo = sg.off[bin], hi = sg.off[bin + 1];
+            const uint32_t lo = ldg(sg.off + bin), hi = ldg(sg.off + bin + 1);
+            if (lo >= hi) continue;
+            GridTuple t[L2_ITEMS], tn[L2_ITEMS];
+            uint32_t sel[L2_ITEMS], seln[L2_ITEMS];
+#pragma unroll
+            for (int j = 0; j < L2_ITEMS; j++) {
+                const uint32_t i = lo + j * L2_NT + threadIdx.x;
+                t[j] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
+                sel[j] = ldg(sg.sub16 + (i < hi ? i : hi - 1));
+            }
+#pragma unroll
+            for (int j = 0; j < L2_ITEMS; j++)  // (arrived: see k_p0_scatter on the one counter for loads and stores)
+                asm volatile("" ::"v"(t[j].x), "v"(t[j].w0), "v"(sel[j]));
             for (uint32_t base = lo; base < hi; base += L2_TILE) {
-                GridTuple t[L2_ITEMS];
+                if (base + L2_TILE < hi) {  // the next tile is on its way while this one is sorted
+#pragma unroll
+                    for (int j = 0; j < L2_ITEMS; j++) {
+                        const uint32_t i = base + L2_TILE + j * L2_NT + threadIdx.x;
+                        tn[j] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
+                        seln[j] = ldg(sg.sub16 + (i < hi ? i : hi - 1));
+                    }
+                }
                 uint32_t subs[L2_ITEMS], ranks[L2_ITEMS];
                 bool valid[L2_ITEMS];
 #pragma unroll
                 for (int j = 0; j < L2_ITEMS; j++) {
-                    const uint32_t i = base + j * L2_NT + threadIdx.x;
-                    valid[j] = i < hi;
-                    t[j] = ld_tuple(sg.tuples + (valid[j] ? i : hi - 1));
-                    subs[j] = sub_from_sel16(sg.sub16[valid[j] ? i : hi - 1], f2);
-                }
-#pragma unroll
-                for (int j = 0; j < L2_ITEMS; j++)
+                    valid[j] = base + j * L2_NT + threadIdx.x < hi;
+                    subs[j] = sub_from_sel16(sel[j], f2);
                     if (valid[j]) ranks[j] = atomicAdd(&s_cnt[subs[j]], 1u);
+                }
                 __syncthreads();
                 {  // exclusive scan of the tile's counts over the sub-partitions (two per thread)
                     const uint32_t s0 = threadIdx.x * 2;
@@ -863,10 +909,14 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
                 for (int j = 0; j < L2_ITEMS; j++) {
                     if (!valid[j]) continue;
                     const uint32_t at = s_base[subs[j]] + ranks[j];
-                    s_stage[at * 3] = make_uint2((uint32_t)t[j].x, (uint32_t)t[j].y);
-                    s_stage[at * 3 + 1] = make_uint2((uint32_t)t[j].z, t[j].idx);
-                    s_stage[at * 3 + 2] = make_uint2(t[j].w0, t[j].w1);
+                    s_xyzi[at] = make_uint4((uint32_t)t[j].x, (uint32_t)t[j].y, (uint32_t)t[j].z, t[j].idx);
+                    s_attr[at] = make_uint2(t[j].w0, t[j].w1);
                     s_tpos[at] = s_cur[subs[j]] + ranks[j];
+                }
+#pragma unroll
+                for (int j = 0; j < L2_ITEMS; j++) {  // the next tile has arrived — before this tile's stores are issued
+                    t[j] = tn[j], sel[j] = seln[j];
+                    asm volatile("" ::"v"(t[j].x), "v"(t[j].w0), "v"(sel[j]));
                 }
                 __syncthreads();
                 {  // the cursors move on (thread t owns sub-partitions 2t, 2t + 1: their tile counts are s_base differences)
@@ -874,11 +924,13 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
                     const uint32_t b0 = s_base[s0], b1 = s_base[s0 + 1], b2 = s0 + 2 < L2_STAGED_F2 ? s_base[s0 + 2] : total;
                     s_cur[s0] += b1 - b0;
                     s_cur[s0 + 1] += b2 - b1;
-                    uint2 *out2 = reinterpret_cast<uint2 *>(P.out);
                     for (uint32_t k = threadIdx.x; k < total; k += L2_NT) {
-                        const uint2 a = s_stage[k * 3], b = s_stage[k * 3 + 1], d = s_stage[k * 3 + 2];
-                        uint2 *q = out2 + (uint64_t)s_tpos[k] * 3;
-                        q[0] = a, q[1] = b, q[2] = d;
+                        uint8_t *q = reinterpret_cast<uint8_t *>(P.out) + (uint64_t)s_tpos[k] * sizeof(GridTuple);
+                        const uint4 a = s_xyzi[k];
+                        const uint2 b = s_attr[k];
+                        u32x4_a8 va = {a.x, a.y, a.z, a.w};
+                        *reinterpret_cast<u32x4_a8 *>(q) = va;
+                        *reinterpret_cast<uint2 *>(q + 16) = b;
                     }
                 }
                 __syncthreads();
@@ -1138,7 +1190,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
         } else {
             for (int r = 0; r < P.nsegs; r++) {
                 const GridSeg sg = r == 0 ? sg0 : P.segs[r];
-                const uint32_t lo = r == 0 ? cur_lo : sg.off[p], cnt = r == 0 ? cur_cnt : sg.off[p + 1] - lo;
+                const uint32_t lo = r == 0 ? cur_lo : ldg(sg.off + p), cnt = r == 0 ? cur_cnt : ldg(sg.off + p + 1) - lo;
                 if (cnt == 0) continue;
                 for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
                     GridTuple tu[FOLD_K];

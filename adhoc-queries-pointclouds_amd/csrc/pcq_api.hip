@@ -282,6 +282,8 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
         ctx->grid_blocks_per_cu = (int)value;
 #ifdef PCQ_LAB
         ctx->batch_blocks_per_cu = (int)value;
+    } else if (!strcmp(key, "grid_variant")) {
+        ctx->grid_variant = (int)value;
     } else if (!strcmp(key, "k1_variant")) {
         if (value < 0 || value > 14) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..14");
         ctx->k1_variant = (int)value;

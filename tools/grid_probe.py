@@ -1,5 +1,6 @@
 """Developer probe: grid-collector scans of one resident file (for rocprofv3 --kernel-trace).
 usage: grid_probe.py QUERY CELL [POINTS] [REPEATS]; GRID_F2=<n> forces the second-level fan-out;
+GRID_VARIANT=<n>[,<n>...] (with PCQ_LAB=1) picks experimental kernel shapes (pcq_internal.h), one per repeat in turn;
 COHERENT=<metres> reorders the file into x/y strips of that width (points sorted along each strip, like scan
 lines) instead of the generator's random order."""
 import importlib, os, sys, time
@@ -33,7 +34,10 @@ with pkg.Context(0) as ctx:
     bmin, bmax = specs.box(q)
     lmin, lmax = pkg.box_to_local(bmin, bmax, list(spec.scale), list(spec.offset))
     ctx.set_option("grid_f2", int(os.environ.get("GRID_F2", "0")))
-    for _ in range(int(sys.argv[4]) if len(sys.argv) > 4 else 2):
+    variants = [int(v) for v in os.environ.get("GRID_VARIANT", "").split(",") if v]  # PCQ_LAB=1 only; several: one after the other, same buffers
+    for it in range(int(sys.argv[4]) if len(sys.argv) > 4 else 2):
+        if variants:
+            ctx.set_option("grid_variant", variants[it % len(variants)])
         t0 = time.perf_counter()
         g = ctx.grid_collector(bmin, bmax, cell)
         t1 = time.perf_counter()
