@@ -1338,6 +1338,27 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
 //  * the table is cleared once: every occupied slot has exactly one winner, which resets the slot behind itself;
 //  * the tuples are loaded and evaluated BEFORE the barrier that separates the partitions;
 //  * a partition with more tuples than a chunk goes on stats[3] / defer_list for k_fold.
+// k_fold_dense's insert: the compare-and-swap IS the probe (a cell's first tuple — three of four in a dense grid — takes
+// one LDS round trip instead of a read and then the swap), and the probe sequence is double hashing: with linear probing
+// the 64 lanes of a wave leave the loop together, after the longest cluster any of them ran into.  The table can never
+// fill up (at most a chunk of 1536 tuples goes into 2048 slots), so the loop ends; the cells are counted per wave.
+template <int NSLOT>
+__device__ __forceinline__ uint32_t lds_insert_dense(uint64_t *s_key, uint64_t key, uint64_t h, bool *fresh) {
+    static_assert((NSLOT & (NSLOT - 1)) == 0, "the step below visits every slot of a power-of-two table");
+    uint32_t s = slot_of<NSLOT>(h);
+    const uint32_t step = ((uint32_t)(h >> 15) & (NSLOT - 1)) | 1u;
+    *fresh = false;
+    for (;;) {
+        const uint64_t prev = atomicCAS((unsigned long long *)&s_key[s], (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key);
+        if (prev == PCQ_EMPTY_KEY) {
+            *fresh = true;
+            return s;
+        }
+        if (prev == key) return s;
+        s = (s + step) & (NSLOT - 1);
+    }
+}
+
 struct DenseParams {
     const GridTuple *tuples;       // the second level's output and its partition offsets
     const uint32_t *off;
@@ -1351,8 +1372,9 @@ struct DenseParams {
     uint32_t *palias;
     unsigned long long *stats;
     uint32_t *defer_list;
+    uint32_t lab_flags;            // libpcq_lab.so experiments (grid_variant >> 4); 0 in the product
 };
-template <int NSLOT, int NT, int FOLD_K, int LIMIT, int MIN_WAVES>
+template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool PREFETCH, int MIN_WAVES>
 __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uint32_t nparts) {
     constexpr int CHUNK = NT * FOLD_K;
     __shared__ uint64_t s_key[NSLOT];
@@ -1371,23 +1393,47 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     uint32_t cur_lo = 0, cur_cnt = 0, nxt_lo = 0, nxt_cnt = 0;
     uint64_t cur_out = 0, nxt_out = 0;
     uint32_t p = blockIdx.x;
-    if (p < nparts) cur_lo = off[p], cur_cnt = off[p + 1] - cur_lo, cur_out = P.wbase[p];
+    // (the partition's range and output base are the same for the whole workgroup: scalar registers)
+    auto uni32 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto uni64 = [&](uint64_t v) { return (uint64_t)uni32((uint32_t)v) | ((uint64_t)uni32((uint32_t)(v >> 32)) << 32); };
+    if (p < nparts) cur_lo = uni32(off[p]), cur_cnt = uni32(off[p + 1]) - cur_lo, cur_out = uni64(P.wbase[p]);
+    GridTuple tn[PREFETCH ? FOLD_K : 1];  // PREFETCH: the tuples of the partition after the current one, in flight while it is folded
+    if (PREFETCH && p < nparts) {
+#pragma unroll
+        for (int k = 0; k < FOLD_K; k++) {
+            const uint32_t i = k * NT + threadIdx.x;
+            tn[PREFETCH ? k : 0] = ld_tuple(tuples + cur_lo + (i < cur_cnt ? i : (cur_cnt ? cur_cnt - 1 : 0)));
+        }
+    }
     for (; p < nparts; p += gridDim.x) {
         const uint32_t pn = p + gridDim.x;
-        if (pn < nparts) nxt_lo = off[pn], nxt_cnt = off[pn + 1] - nxt_lo, nxt_out = P.wbase[pn];
+        if (pn < nparts) nxt_lo = uni32(off[pn]), nxt_cnt = uni32(off[pn + 1]) - nxt_lo, nxt_out = uni64(P.wbase[pn]);
         const uint32_t cnt = cur_cnt;
+        GridTuple tu[FOLD_K];
+        if (PREFETCH) {
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) tu[k] = tn[PREFETCH ? k : 0];
+            if (pn < nparts) {
+#pragma unroll
+                for (int k = 0; k < FOLD_K; k++) {
+                    const uint32_t i = k * NT + threadIdx.x;
+                    tn[PREFETCH ? k : 0] = ld_tuple(tuples + nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0)));
+                }
+            }
+        }
         if (cnt > (uint32_t)CHUNK) {  // (the same for every thread of the workgroup)
             if (threadIdx.x == 0) P.defer_list[atomicAdd(&P.stats[3], 1ull)] = p;
             cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
             continue;
         }
-        GridTuple tu[FOLD_K];
         uint64_t key[FOLD_K], dbits[FOLD_K];
         bool alias[FOLD_K];
+        if (!PREFETCH) {
 #pragma unroll
-        for (int k = 0; k < FOLD_K; k++) {
-            const uint32_t i = k * NT + threadIdx.x;
-            tu[k] = ld_tuple(tuples + cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0)));
+            for (int k = 0; k < FOLD_K; k++) {
+                const uint32_t i = k * NT + threadIdx.x;
+                tu[k] = ld_tuple(tuples + cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0)));
+            }
         }
         uint32_t inexact = 0;  // bit k: tuple k is next to a cell boundary (or outside the short computation's range)
 #pragma unroll
@@ -1418,19 +1464,23 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
         }
         __syncthreads();  // the table is clean: the previous partition's winners have reset their slots
         int slot[FOLD_K];
-        bool over = false;
+        uint32_t fresh_cells = 0;
 #pragma unroll
         for (int k = 0; k < FOLD_K; k++) {  // phase 1: cells and their minimum distance
             slot[k] = -1;
             if ((uint32_t)(k * NT) + threadIdx.x >= cnt) continue;
-            const int sl = lds_find_or_insert<NSLOT, LIMIT>(s_key, key[k], cell_hash(key[k]), &s_ncell);
-            if (sl < 0) {
-                over = true;
-                continue;
-            }
-            slot[k] = sl;
+            bool fresh;
+            const uint32_t sl = lds_insert_dense<NSLOT>(s_key, key[k], cell_hash(key[k]), &fresh);
+            fresh_cells += fresh ? 1 : 0;
+            slot[k] = (int)sl;
             if (alias[k]) atomicOr(&s_aliasbits[sl >> 5], 1u << (sl & 31));
             atomicMin((unsigned long long *)&s_dist[sl], (unsigned long long)dbits[k]);
+        }
+        bool over = false;
+        {  // cells of the partition so far, counted per wave; beyond LIMIT the partition is given up (like k_fold: the same fan-out rule)
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) fresh_cells += __shfl_xor(fresh_cells, o, 64);
+            if (lane == 0 && fresh_cells) over = atomicAdd(&s_ncell, fresh_cells) + fresh_cells > (uint32_t)LIMIT;
         }
         if (__syncthreads_or(over)) {  // more cells than the table holds: the host repeats the fold with more partitions
             for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
@@ -1471,12 +1521,16 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
             before += w < wave ? s_wsum[w] : 0;
             total += s_wsum[w];
         }
+        if (PREFETCH) {  // the next partition's tuples have arrived — before this one's stores are issued (one counter, k_p0_scatter)
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) asm volatile("" ::"v"(tn[PREFETCH ? k : 0].x), "v"(tn[PREFETCH ? k : 0].w0));
+        }
         uint64_t o = cur_out + before;
 #pragma unroll
         for (int k = 0; k < FOLD_K; k++) {
             if (!cand[k]) continue;
             const int sl = slot[k];
-            P.wkeys[o] = key[k];
+            P.wkeys[o] = s_key[sl];  // (= key[k]: read back instead of kept in two registers per tuple across the barriers)
             uint8_t *dst = P.wrecs + o * 32;
             const uint32_t abit = 1u << (sl & 31);
             if (s_aliasbits[sl >> 5] & abit) {  // left to the exact replay: no point yet, the flag
@@ -1491,7 +1545,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
                 int32_t x = tu[k].x, y = tu[k].y, z = tu[k].z;
                 uint32_t w0 = tu[k].w0;
                 asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w0));
-                st_record(dst, P.entries.get((w0 >> 8) & 0xff), x, y, z, w0, tu[k].w1, R_HAS);
+                if (!(P.lab_flags & 1)) st_record(dst, P.entries.get((w0 >> 8) & 0xff), x, y, z, w0, tu[k].w1, R_HAS);
             }
             s_key[sl] = PCQ_EMPTY_KEY, s_dist[sl] = ~0ull, s_ord[sl] = ~0ull;
             o++;
@@ -2010,7 +2064,13 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 }
                 D.g.cell_size = g.cell_size;
                 D.wkeys = n_wkeys, D.wrecs = n_wrecs, D.wbase = n_wbase, D.wcount = n_wcount, D.palias = d_palias, D.stats = d_stats, D.defer_list = d_defer;
-                hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, 6>), dim3(resident), dim3(DENSE_NT), 0, s, D, nparts);
+#ifdef PCQ_LAB
+                D.lab_flags = (uint32_t)ctx->grid_variant >> 4;  // 16: no winner records (what do their stores cost?)
+                if (ctx->grid_variant & 8)  // two workgroups per CU, the next partition's tuples prefetched into registers
+                    hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, true, 4>), dim3(resident / 3 * 2), dim3(DENSE_NT), 0, s, D, nparts);
+                else
+#endif
+                hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, false, 6>), dim3(resident), dim3(DENSE_NT), 0, s, D, nparts);
             }
             if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
             else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, false, true, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
