@@ -325,11 +325,11 @@ struct P0In {
     RawPoint rp;
     uint32_t cls;
 };
-template <int KIND>
+template <int KIND, bool STREAM = true>
 __device__ __forceinline__ P0In<KIND> p0_load(const DevCols &c, uint64_t i) {
     P0In<KIND> in;
     if (KIND == PCQ_PRED_CLASS) in.cls = c.cls[i * c.cls_stride];
-    else in.rp = ld_xyz(c, i);
+    else in.rp = STREAM ? ld_xyz_stream(c, i) : ld_xyz(c, i);
     return in;
 }
 template <int KIND>
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(1024) void k_excl_scan_u64(const uint64_t *__restri
 // a bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.  A tuple is staged (and stored) as
 // 16 + 8 bytes; next to it one word holds its bin and its second-level selector: the bin gives the tuple's place in the
 // run (the tile's first place in the bin + the tuple's place in the sorted image), the selector goes to sub16.
-template <int KIND>
+template <int KIND, bool STREAM, bool WITH_SEL>
 __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
                                                       const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out,
                                                       uint16_t *__restrict__ out_sub16, uint32_t entry, uint64_t idx_base) {
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
 #pragma unroll
     for (int j = 0; j < P0_ITEMS; j++) {
         const uint64_t i = begin + (uint64_t)j * P0_NT + threadIdx.x;
-        cur[j] = p0_load<KIND>(c, i < end ? i : end - 1);
+        cur[j] = p0_load<KIND, STREAM>(c, i < end ? i : end - 1);
     }
 #pragma unroll
     for (int j = 0; j < P0_ITEMS; j++) {  // (arrived: inside the loop nothing is pending at its head, see below)
@@ -500,7 +500,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
 #pragma unroll
             for (int j = 0; j < P0_ITEMS; j++) {
                 const uint64_t i = nbase + (uint64_t)j * P0_NT + threadIdx.x;
-                nxt[j] = p0_load<KIND>(c, i < end ? i : end - 1);
+                nxt[j] = p0_load<KIND, STREAM>(c, i < end ? i : end - 1);
             }
         }
         // gfx950 counts loads and stores in ONE in-order counter (vmcnt): a wait for a load also waits for every store issued
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
             u32x4_a8 va = {a.x, a.y, a.z, a.w};
             *reinterpret_cast<u32x4_a8 *>(q) = va;
             *reinterpret_cast<uint2 *>(q + 16) = b;
-            out_sub16[pos] = (uint16_t)meta;
+            if (WITH_SEL) out_sub16[pos] = (uint16_t)meta;
         }
         __syncthreads();  // the stage and the bases are rewritten by the next tile
     }
@@ -713,6 +713,12 @@ struct Level2Params {
     uint32_t *ooff2;          // [F1 * f2 + 1]
 };
 
+// A tuple's second-level selector: stored by pass 0 — or, for a run whose scan did not expect a second level (a grid with
+// few cells altogether: no selectors written, GridSeg::sub16 == nullptr), computed from the tuple.
+__device__ __forceinline__ uint32_t tuple_sel16(const Level2Params &P, const GridSeg &sg, uint32_t i) {
+    if (sg.sub16) return ldg(sg.sub16 + i);
+    return sel16_of(cell_hash(eval_tuple(P.g, P.entries, ld_tuple(sg.tuples + i)).key));
+}
 __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
     __shared__ uint32_t s_hist[F2_MAX], s_cur[F2_MAX], s_ohist[F2_MAX], s_ocur[F2_MAX];
     const uint32_t bin = blockIdx.x, f2 = P.f2;
@@ -727,7 +733,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++) {
                     const uint32_t i = i0 + u * L2_NT;
-                    sel[u] = ldg(sg.sub16 + (i < hi ? i : hi - 1));
+                    sel[u] = tuple_sel16(P, sg, i < hi ? i : hi - 1);
                 }
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++)
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
                 for (int u = 0; u < L2_UNROLL; u++) {
                     const uint32_t i = i0 + u * L2_NT;
                     t[u] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
-                    sel[u] = ldg(sg.sub16 + (i < hi ? i : hi - 1));
+                    sel[u] = tuple_sel16(P, sg, i < hi ? i : hi - 1);
                 }
 #pragma unroll
                 for (int u = 0; u < L2_UNROLL; u++) {
@@ -1788,9 +1794,9 @@ struct Scratch {
 
 static int grid_fold(pcq_ctx *ctx, pcq_collector *c);
 
-static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, GridTuple **out, uint16_t **out_sub16) {
+static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, bool with_sel, GridTuple **out, uint16_t **out_sub16) {
     const size_t tuple_bytes = ((size_t)tuples * sizeof(GridTuple) + 255) & ~(size_t)255;
-    const size_t bytes = tuple_bytes + (size_t)tuples * sizeof(uint16_t);
+    const size_t bytes = tuple_bytes + (with_sel ? (size_t)tuples * sizeof(uint16_t) : 0);
     if (bytes > gs->slab_left) {
         size_t slab = 256ull << 20;
         if (slab < bytes) slab = bytes;
@@ -1802,7 +1808,7 @@ static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, GridTup
         gs->slab_left = slab;
     }
     *out = (GridTuple *)gs->slab_cur;
-    *out_sub16 = (uint16_t *)(gs->slab_cur + tuple_bytes);
+    *out_sub16 = with_sel ? (uint16_t *)(gs->slab_cur + tuple_bytes) : nullptr;
     const size_t used = (bytes + 255) & ~(size_t)255;
     gs->slab_cur += used < gs->slab_left ? used : gs->slab_left;
     gs->slab_left -= used < gs->slab_left ? used : gs->slab_left;
@@ -1855,7 +1861,15 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         GridRun run;
         run.cap = cols.n;
         run.binoff = gs->binoff_store + gs->runs.size() * (F1 + 1);
-        int rc = grid_tuple_room(ctx, gs, cols.n, &run.tuples, &run.sub16);
+        // A grid with so few cells ALTOGETHER that a level-1 bin always fits the big fold never sees a second level:
+        // its scans skip the selectors (2-byte fragments in 10-byte pieces, 40 % more write traffic than their size).
+        // Should a second level happen all the same (option grid_f2, a refold), k_level2_direct computes them.
+        const DevGrid &cg = c->grid;
+        bool with_sel = ctx->grid_f2 > 1 || cg.dims_f[0] * cg.dims_f[1] * cg.dims_f[2] > (double)F1 * BIG_DIRECT;
+#ifdef PCQ_LAB
+        if (ctx->grid_variant & 64) with_sel = false;  // what do the selector stores cost?
+#endif
+        int rc = grid_tuple_room(ctx, gs, cols.n, with_sel, &run.tuples, &run.sub16);
         if (rc) return rc;
         gs->pending_cap += cols.n;
 
@@ -1874,12 +1888,19 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         else hipLaunchKernelGGL(k_p0_hist<PCQ_PRED_BOUNDS_F64>, gb, tb, 0, s, cols, pred, g, per_block, cnt);
         hipLaunchKernelGGL(k_p0_scan_blocks, dim3(F1 / WAVES), dim3(BLOCK), 0, s, cnt, (int)nblocks, total);
         hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, total, run.binoff, (uint32_t)F1);
-        if (pred.kind == PCQ_PRED_BOUNDS)
-            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_BOUNDS>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, run.sub16, entry, idx_base);
-        else if (pred.kind == PCQ_PRED_CLASS)
-            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_CLASS>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, run.sub16, entry, idx_base);
+#define PCQ_P0_SCATTER(KIND, STREAM) \
+    do { \
+        if (run.sub16) hipLaunchKernelGGL((k_p0_scatter<KIND, STREAM, true>), gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, run.sub16, entry, idx_base); \
+        else hipLaunchKernelGGL((k_p0_scatter<KIND, STREAM, false>), gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, run.sub16, entry, idx_base); \
+    } while (0)
+#ifdef PCQ_LAB
+        if ((ctx->grid_variant & 32) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, false);  // plain loads of the positions
         else
-            hipLaunchKernelGGL(k_p0_scatter<PCQ_PRED_BOUNDS_F64>, gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, run.sub16, entry, idx_base);
+#endif
+        if (pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, true);
+        else if (pred.kind == PCQ_PRED_CLASS) PCQ_P0_SCATTER(PCQ_PRED_CLASS, true);
+        else PCQ_P0_SCATTER(PCQ_PRED_BOUNDS_F64, true);
+#undef PCQ_P0_SCATTER
         PCQ_HIP(hipGetLastError());
         gs->runs.push_back(run);
     }
@@ -1997,7 +2018,9 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 L.okeys = gs->wkeys, L.orecs = gs->wrecs, L.obase = gs->wbase, L.ocount = gs->wcount, L.f2old = gs->f2;
                 L.obinbase = d_obinbase, L.okeys2 = d_okeys2, L.orecs2 = d_orecs2, L.ooff2 = d_ooff2;
             }
-            if (f2 <= (uint32_t)L2_STAGED_F2) hipLaunchKernelGGL(k_level2, dim3(F1), dim3(L2_NT), 0, s, L);
+            bool all_sel = true;
+            for (int r = 0; r < nruns; r++) all_sel = all_sel && gs->runs[r].sub16 != nullptr;
+            if (f2 <= (uint32_t)L2_STAGED_F2 && all_sel) hipLaunchKernelGGL(k_level2, dim3(F1), dim3(L2_NT), 0, s, L);
             else hipLaunchKernelGGL(k_level2_direct, dim3(F1), dim3(L2_NT), 0, s, L);
             PCQ_HIP(hipGetLastError());
             if (f2 > 1) {

@@ -104,18 +104,29 @@ struct TileIn {
 // the ranks, one dependent round trip per row of 256 points — left the waves waiting 80 % of the time.)
 template <int KIND, bool ATTRS>
 __device__ __forceinline__ void tile_load_and_test(const DevCols &c, const DevPred &pr, uint64_t base, TileIn<KIND, ATTRS> &T) {
+    // No branch around a load: with `c.cls ? c.cls[i] : 0` in the unrolled loop every load sat in its own block and was
+    // waited for at the block's end (eight serial round trips per tile).  A missing column is read from a valid address
+    // with stride 0 and masked instead.
+    const bool has_cls = (ATTRS || KIND == PCQ_PRED_CLASS) && c.cls, has_rgb = ATTRS && c.rgb;
+    const uint8_t *fallback = c.xyz ? c.xyz : c.cls;  // (one of the two exists: the predicate reads it)
+    const uint8_t *clsp = has_cls ? c.cls : fallback, *rgbp = has_rgb ? c.rgb : fallback;
+    const uint64_t cls_stride = has_cls ? c.cls_stride : 0, rgb_stride = has_rgb ? c.rgb_stride : 0;
+    const uint32_t cls_mask = has_cls ? 0xffu : 0u, rg_mask = has_rgb ? 0xffffffffu : 0u, b_mask = has_rgb ? 0xffffu : 0u;
+    uint32_t raw_cls[EMIT_ITEMS], raw_rg[EMIT_ITEMS], raw_b[EMIT_ITEMS];
 #pragma unroll
     for (int j = 0; j < EMIT_ITEMS; j++) {
         const uint64_t i0 = base + (uint64_t)j * BLOCK + threadIdx.x, i = i0 < c.n ? i0 : c.n - 1;
-        T.attr_cls[j] = (ATTRS || KIND == PCQ_PRED_CLASS) && c.cls ? c.cls[i * c.cls_stride] : 0;  // last.rs:138-142
-        T.attr_rg[j] = T.attr_b[j] = 0;
-        if (ATTRS && c.rgb) {  // last.rs:145-153
-            const uint8_t *q = c.rgb + i * c.rgb_stride;
-            T.attr_rg[j] = (uint32_t)ld_u16(q) | ((uint32_t)ld_u16(q + 2) << 16);
-            T.attr_b[j] = ld_u16(q + 4);
+        raw_cls[j] = clsp[i * cls_stride];  // last.rs:138-142
+        raw_rg[j] = raw_b[j] = 0;
+        if (ATTRS) {  // last.rs:145-153
+            const uint8_t *q = rgbp + i * rgb_stride;
+            raw_rg[j] = (uint32_t)ld_u16(q) | ((uint32_t)ld_u16(q + 2) << 16);
+            raw_b[j] = ld_u16(q + 4);
         }
-        if (KIND != PCQ_PRED_CLASS) T.rps[j] = ld_xyz(c, i);
+        if (KIND != PCQ_PRED_CLASS) T.rps[j] = ld_xyz_stream(c, i);
     }
+#pragma unroll
+    for (int j = 0; j < EMIT_ITEMS; j++) T.attr_cls[j] = raw_cls[j] & cls_mask, T.attr_rg[j] = raw_rg[j] & rg_mask, T.attr_b[j] = raw_b[j] & b_mask;
 #pragma unroll
     for (int j = 0; j < EMIT_ITEMS; j++) {
         const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
@@ -295,7 +306,12 @@ __global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, co
             for (uint32_t b0 = threadIdx.x * 16u; b0 < total_b; b0 += BLOCK * 16u) {
                 const uint32_t b1 = b0 + 16u;
                 if (b0 >= pad && b1 <= total_b) {
-                    *reinterpret_cast<uint4 *>(gdst + b0) = *reinterpret_cast<const uint4 *>(stage8 + b0);
+                    {  // written once, read by nobody on the GPU: streamed past the caches' retention
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        const uint4 v = *reinterpret_cast<const uint4 *>(stage8 + b0);
+                        u32x4 w = {v.x, v.y, v.z, v.w};
+                        __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(gdst + b0));
+                    }
                 } else {
                     const uint32_t lo = b0 > pad ? b0 : pad, hi = b1 < total_b ? b1 : total_b;
                     for (uint32_t k = lo; k < hi; k++) gdst[k] = stage8[k];
