@@ -85,12 +85,16 @@ struct GridEntryDev {
     double scale[3], offset[3];
 };
 
-// A list of tuples cut into partitions: partition p is tuples[off[p] .. off[p + 1]).
+// A list of tuples cut into partitions: partition p is tuples[off[p] .. off[p] + cnt[p]) — or, without cnt (pass 0's runs,
+// the exact second level: partitions back to back), tuples[off[p] .. off[p + 1]).
 struct GridSeg {
     const GridTuple *tuples;
     const uint32_t *off;
-    const uint16_t *sub16;  // per tuple: the 16 hash bits the second level partitions by (nullptr behind the second level)
+    const uint32_t *cnt;
 };
+__device__ __forceinline__ uint32_t seg_count(const GridSeg &sg, uint32_t p, uint32_t lo) {
+    return sg.cnt ? *(const __attribute__((address_space(1))) uint32_t *)(sg.cnt + p) : *(const __attribute__((address_space(1))) uint32_t *)(sg.off + p + 1) - lo;
+}
 
 struct AliasItem {  // a tuple of an aliased key, for the exact replay (key at +0, order at +8: alias_sort.hip)
     uint64_t key, ord;
@@ -215,8 +219,7 @@ __device__ __forceinline__ uint64_t cell_hash(uint64_t k) {
     return k * 0x9e3779b97f4a7c15ull;
 }
 __device__ __forceinline__ uint32_t bin_of(uint64_t h) { return (uint32_t)(h >> (64 - F1_BITS)); }
-// the second-level partition comes from the 16 bits under the bin bits: pass 0 stores them next to every tuple (sub16), so
-// that the second level never recomputes a cell
+// the second-level partition comes from the 16 bits under the bin bits
 __device__ __forceinline__ uint32_t sel16_of(uint64_t h) { return (uint32_t)(h >> 37) & 0xffffu; }
 __device__ __forceinline__ uint32_t sub_from_sel16(uint32_t sel16, uint32_t f2) { return (sel16 * f2) >> 16; }
 __device__ __forceinline__ uint32_t sub_of(uint64_t h, uint32_t f2) { return sub_from_sel16(sel16_of(h), f2); }
@@ -465,16 +468,16 @@ __global__ __launch_bounds__(1024) void k_excl_scan_u64(const uint64_t *__restri
 // Per tile of 2560 points: the matches take a rank in their bin (LDS atomics), the tile's tuples are laid out in LDS
 // sorted by bin, and the sorted image is copied out one tuple per lane — consecutive lanes write consecutive tuples of
 // a bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.  A tuple is staged (and stored) as
-// 16 + 8 bytes; next to it one word holds its bin and its second-level selector: the bin gives the tuple's place in the
-// run (the tile's first place in the bin + the tuple's place in the sorted image), the selector goes to sub16.
-template <int KIND, bool STREAM, bool WITH_SEL>
+// 16 + 8 bytes; next to it sits its bin, which gives the tuple's place in the run (the tile's first place in the bin + the
+// tuple's place in the sorted image).
+template <int KIND, bool STREAM>
 __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
                                                       const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out,
-                                                      uint16_t *__restrict__ out_sub16, uint32_t entry, uint64_t idx_base) {
+                                                      uint32_t entry, uint64_t idx_base) {
     static_assert(F1 == P0_NT, "one thread per bin in the per-tile scan");
     __shared__ uint4 s_xyzi[P0_TILE];        // the tile's tuples, sorted by bin: x, y, z, idx
     __shared__ uint2 s_attr[P0_TILE];        //                                    w0, w1
-    __shared__ uint32_t s_meta[P0_TILE];     // bin << 16 | selector
+    __shared__ uint16_t s_bin[P0_TILE];      // its bin
     __shared__ uint32_t s_cnt[F1], s_base[F1], s_delta[F1], s_cur[F1], s_wsum[P0_NT / 64];
     __shared__ uint32_t s_total;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
             if (!passes[j]) continue;
             const uint64_t h = point_hash<KIND>(c, g, cur[j].rp);
             const uint32_t bin = bin_of(h);
-            metas[j] = bin << 16 | sel16_of(h);
+            metas[j] = bin;
             ranks[j] = atomicAdd(&s_cnt[bin], 1u);
         }
         __syncthreads();
@@ -559,10 +562,10 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
         for (int j = 0; j < P0_ITEMS; j++) {
             if (!passes[j]) continue;
             const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
-            const uint32_t at = s_base[metas[j] >> 16] + ranks[j];
+            const uint32_t at = s_base[metas[j]] + ranks[j];
             s_xyzi[at] = make_uint4((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y, (uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
             s_attr[at] = make_uint2(cl[j] | (entry << 8) | (rg[j] << 16), (rg[j] >> 16) | (bb[j] << 16));
-            s_meta[at] = metas[j];
+            s_bin[at] = (uint16_t)metas[j];
         }
 #pragma unroll
         for (int j = 0; j < P0_ITEMS; j++) {  // the next tile's inputs have arrived (asked for a whole tile ago) — before the stores below
@@ -575,13 +578,11 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
         for (uint32_t t = threadIdx.x; t < total; t += P0_NT) {
             const uint4 a = s_xyzi[t];
             const uint2 b = s_attr[t];
-            const uint32_t meta = s_meta[t];
-            const uint32_t pos = s_delta[meta >> 16] + t;
+            const uint32_t pos = s_delta[s_bin[t]] + t;
             uint8_t *q = reinterpret_cast<uint8_t *>(out) + (uint64_t)pos * sizeof(GridTuple);
             u32x4_a8 va = {a.x, a.y, a.z, a.w};
             *reinterpret_cast<u32x4_a8 *>(q) = va;
             *reinterpret_cast<uint2 *>(q + 16) = b;
-            if (WITH_SEL) out_sub16[pos] = (uint16_t)meta;
         }
         __syncthreads();  // the stage and the bases are rewritten by the next tile
     }
@@ -595,7 +596,10 @@ __global__ __launch_bounds__(BLOCK) void k_part_totals(const GridSeg *__restrict
     const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
     if (p >= nparts) return;
     uint32_t t = 0;
-    for (int r = 0; r < nsegs; r++) t += segs[r].off[p + 1] - segs[r].off[p];
+    for (int r = 0; r < nsegs; r++) {
+        const GridSeg sg = segs[r];
+        t += seg_count(sg, p, sg.off[p]);
+    }
     tot[p] = t;
 }
 
@@ -701,6 +705,9 @@ struct Level2Params {
     const uint32_t *binbase;  // [F1 + 1] tuples in front of each bin (prefix over all segments); nullptr: tuples are not moved
     GridTuple *out;
     uint32_t *off2;           // [F1 * f2 + 1]
+    uint32_t *cnt2;           // k_level2: [F1 * f2] tuples per sub-partition; cap = the room each of them has
+    uint32_t cap;
+    unsigned long long *stats;  // k_level2: [5] += 1 when a sub-partition outgrew its room
     // earlier winners, re-cut from f2old partitions per bin into f2 (nullptr: not moved)
     const uint64_t *okeys;
     const uint8_t *orecs;
@@ -713,10 +720,9 @@ struct Level2Params {
     uint32_t *ooff2;          // [F1 * f2 + 1]
 };
 
-// A tuple's second-level selector: stored by pass 0 — or, for a run whose scan did not expect a second level (a grid with
-// few cells altogether: no selectors written, GridSeg::sub16 == nullptr), computed from the tuple.
+// The exact form: a histogram pass over the bin's tuples, then the scatter, sub-partitions back to back (off2 only).  Both
+// passes compute the tuple's cell.  For more than 1024 sub-partitions per bin, and when k_level2's regions did not hold.
 __device__ __forceinline__ uint32_t tuple_sel16(const Level2Params &P, const GridSeg &sg, uint32_t i) {
-    if (sg.sub16) return ldg(sg.sub16 + i);
     return sel16_of(cell_hash(eval_tuple(P.g, P.entries, ld_tuple(sg.tuples + i)).key));
 }
 __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
@@ -800,37 +806,26 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
         }
 }
 
-// The staged form (f2 <= 1024): the sub-partition of a tuple comes from its stored selector (no cell arithmetic), the
-// histogram pass reads only the 2-byte selectors, and the scatter pass sorts a tile of 1536 tuples by sub-partition in LDS
-// so that they leave as runs — the direct form's scattered 24-byte stores reached HBM as 6.4 GB for 3.9 GB of tuples
-// (profiles/r02_grid_pmc.txt).
+// The staged form (f2 <= 1024), ONE pass over the bin's tuples: a tile of 1536 tuples is sorted by sub-partition in LDS and
+// leaves as runs (the direct form's scattered 24-byte stores reached HBM as 6.4 GB for 3.9 GB of tuples).  There is no
+// histogram pass in front: sub-partition p owns the fixed region out[p * cap .. (p + 1) * cap), cap = 1.3 x the mean
+// partition + 64 — the cell keys are hashed, a partition's tuple count is the mean +- a few per cent unless single cells
+// hold hundreds of points — and reports off2[p] = p * cap, cnt2[p] = its tuples.  A partition that outgrows its region
+// raises stats[5]: the host then takes the exact form (k_level2_direct), which counts first.
+// (An earlier shape had pass 0 store every tuple's selector bits so that a histogram pass here could read 2 bytes per
+// tuple: those 2-byte stores cost pass 0 0.2-0.7 ms per 163 M points, more than the pass they fed.)
 __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
-    __shared__ uint32_t s_hist[L2_STAGED_F2], s_cur[L2_STAGED_F2], s_ohist[L2_STAGED_F2], s_ocur[L2_STAGED_F2];
+    __shared__ uint32_t s_cur[L2_STAGED_F2], s_ohist[L2_STAGED_F2], s_ocur[L2_STAGED_F2];
     __shared__ uint32_t s_cnt[L2_STAGED_F2], s_base[L2_STAGED_F2];
     __shared__ uint4 s_xyzi[L2_TILE];   // the tile's tuples, sorted by sub-partition: x, y, z, idx
     __shared__ uint2 s_attr[L2_TILE];   //                                                 w0, w1
     __shared__ uint32_t s_tpos[L2_TILE];
-    __shared__ uint32_t s_wsum[L2_NT / 64], s_total;
+    __shared__ uint32_t s_wsum[L2_NT / 64], s_total, s_overflow;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t bin = blockIdx.x, f2 = P.f2;
-    for (uint32_t t = threadIdx.x; t < L2_STAGED_F2; t += L2_NT) s_hist[t] = 0, s_ohist[t] = 0, s_cnt[t] = 0;
+    const uint32_t bin = blockIdx.x, f2 = P.f2, cap = P.cap;
+    for (uint32_t t = threadIdx.x; t < L2_STAGED_F2; t += L2_NT) s_cur[t] = 0, s_ohist[t] = 0, s_cnt[t] = 0;
+    if (threadIdx.x == 0) s_overflow = 0;
     __syncthreads();
-    if (P.binbase)
-        for (int r = 0; r < P.nsegs; r++) {
-            const GridSeg sg = P.segs[r];
-            const uint32_t lo = ldg(sg.off + bin), hi = ldg(sg.off + bin + 1);
-            for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += L2_NT * L2_UNROLL) {  // the loads of four steps are issued together
-                uint32_t sel[L2_UNROLL];
-#pragma unroll
-                for (int u = 0; u < L2_UNROLL; u++) {
-                    const uint32_t i = i0 + u * L2_NT;
-                    sel[u] = ldg(sg.sub16 + (i < hi ? i : hi - 1));
-                }
-#pragma unroll
-                for (int u = 0; u < L2_UNROLL; u++)
-                    if (i0 + u * L2_NT < hi) atomicAdd(&s_hist[sub_from_sel16(sel[u], f2)], 1u);
-            }
-        }
     if (P.okeys)
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
             const uint64_t base = P.obase[q];
@@ -838,45 +833,37 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
             for (uint32_t i = threadIdx.x; i < n; i += L2_NT) atomicAdd(&s_ohist[sub_of(cell_hash(P.okeys[base + i]), f2)], 1u);
         }
     __syncthreads();
-    if (threadIdx.x == 0) {  // f2 <= 1024: a serial prefix is a thousand LDS reads
-        uint32_t run = P.binbase ? P.binbase[bin] : 0, orun = P.okeys ? P.obinbase[bin] : 0;
+    if (threadIdx.x == 0 && P.okeys) {  // f2 <= 1024: a serial prefix is a thousand LDS reads
+        uint32_t orun = P.obinbase[bin];
         for (uint32_t s = 0; s < f2; s++) {
-            if (P.binbase) P.off2[bin * f2 + s] = run;
-            s_cur[s] = run;
-            run += s_hist[s];
-            if (P.okeys) P.ooff2[bin * f2 + s] = orun;
+            P.ooff2[bin * f2 + s] = orun;
             s_ocur[s] = orun;
             orun += s_ohist[s];
         }
-        if (bin == F1 - 1) {
-            if (P.binbase) P.off2[F1 * f2] = run;
-            if (P.okeys) P.ooff2[F1 * f2] = orun;
-        }
+        if (bin == F1 - 1) P.ooff2[F1 * f2] = orun;
     }
     __syncthreads();
-    if (P.binbase)
+    if (P.out) {
+        const uint64_t region0 = (uint64_t)bin * f2 * cap;  // this bin's sub-partition s: out[region0 + s * cap ...)
         for (int r = 0; r < P.nsegs; r++) {
             const GridSeg sg = P.segs[r];
             const uint32_t lo = ldg(sg.off + bin), hi = ldg(sg.off + bin + 1);
             if (lo >= hi) continue;
             GridTuple t[L2_ITEMS], tn[L2_ITEMS];
-            uint32_t sel[L2_ITEMS], seln[L2_ITEMS];
 #pragma unroll
             for (int j = 0; j < L2_ITEMS; j++) {
                 const uint32_t i = lo + j * L2_NT + threadIdx.x;
                 t[j] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
-                sel[j] = ldg(sg.sub16 + (i < hi ? i : hi - 1));
             }
 #pragma unroll
             for (int j = 0; j < L2_ITEMS; j++)  // (arrived: see k_p0_scatter on the one counter for loads and stores)
-                asm volatile("" ::"v"(t[j].x), "v"(t[j].w0), "v"(sel[j]));
+                asm volatile("" ::"v"(t[j].x), "v"(t[j].w0));
             for (uint32_t base = lo; base < hi; base += L2_TILE) {
                 if (base + L2_TILE < hi) {  // the next tile is on its way while this one is sorted
 #pragma unroll
                     for (int j = 0; j < L2_ITEMS; j++) {
                         const uint32_t i = base + L2_TILE + j * L2_NT + threadIdx.x;
                         tn[j] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
-                        seln[j] = ldg(sg.sub16 + (i < hi ? i : hi - 1));
                     }
                 }
                 uint32_t subs[L2_ITEMS], ranks[L2_ITEMS];
@@ -884,7 +871,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
 #pragma unroll
                 for (int j = 0; j < L2_ITEMS; j++) {
                     valid[j] = base + j * L2_NT + threadIdx.x < hi;
-                    subs[j] = sub_from_sel16(sel[j], f2);
+                    subs[j] = sub_of(cell_hash(eval_tuple(P.g, P.entries, t[j]).key), f2);
                     if (valid[j]) ranks[j] = atomicAdd(&s_cnt[subs[j]], 1u);
                 }
                 __syncthreads();
@@ -917,12 +904,13 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
                     const uint32_t at = s_base[subs[j]] + ranks[j];
                     s_xyzi[at] = make_uint4((uint32_t)t[j].x, (uint32_t)t[j].y, (uint32_t)t[j].z, t[j].idx);
                     s_attr[at] = make_uint2(t[j].w0, t[j].w1);
-                    s_tpos[at] = s_cur[subs[j]] + ranks[j];
+                    const uint32_t within = s_cur[subs[j]] + ranks[j];  // place in the sub-partition's region
+                    s_tpos[at] = within < cap ? subs[j] * cap + within : 0xffffffffu;
                 }
 #pragma unroll
                 for (int j = 0; j < L2_ITEMS; j++) {  // the next tile has arrived — before this tile's stores are issued
-                    t[j] = tn[j], sel[j] = seln[j];
-                    asm volatile("" ::"v"(t[j].x), "v"(t[j].w0), "v"(sel[j]));
+                    t[j] = tn[j];
+                    asm volatile("" ::"v"(t[j].x), "v"(t[j].w0));
                 }
                 __syncthreads();
                 {  // the cursors move on (thread t owns sub-partitions 2t, 2t + 1: their tile counts are s_base differences)
@@ -930,18 +918,29 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
                     const uint32_t b0 = s_base[s0], b1 = s_base[s0 + 1], b2 = s0 + 2 < L2_STAGED_F2 ? s_base[s0 + 2] : total;
                     s_cur[s0] += b1 - b0;
                     s_cur[s0 + 1] += b2 - b1;
+                    if (s_cur[s0] > cap || s_cur[s0 + 1] > cap) s_overflow = 1;
                     for (uint32_t k = threadIdx.x; k < total; k += L2_NT) {
-                        uint8_t *q = reinterpret_cast<uint8_t *>(P.out) + (uint64_t)s_tpos[k] * sizeof(GridTuple);
+                        const uint32_t tp = s_tpos[k];
+                        if (tp == 0xffffffffu) continue;  // beyond the region: the fold's result will not be used
                         const uint4 a = s_xyzi[k];
                         const uint2 b = s_attr[k];
+                        uint8_t *q = reinterpret_cast<uint8_t *>(P.out) + (region0 + tp) * sizeof(GridTuple);
                         u32x4_a8 va = {a.x, a.y, a.z, a.w};
-                        *reinterpret_cast<u32x4_a8 *>(q) = va;
-                        *reinterpret_cast<uint2 *>(q + 16) = b;
+                        *(PCQ_GLOBAL u32x4_a8 *)q = va;
+                        u32x2 vb = {b.x, b.y};
+                        *(PCQ_GLOBAL u32x2 *)(q + 16) = vb;
                     }
                 }
                 __syncthreads();
             }
         }
+        for (uint32_t sp = threadIdx.x; sp < f2; sp += L2_NT) {
+            const uint32_t n = s_cur[sp];
+            P.off2[bin * f2 + sp] = (uint32_t)(region0 + (uint64_t)sp * cap);
+            P.cnt2[bin * f2 + sp] = n < cap ? n : cap;
+        }
+        if (threadIdx.x == 0 && s_overflow) atomicAdd(&P.stats[5], 1ull);
+    }
     if (P.okeys)
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
             const uint64_t base = P.obase[q];
@@ -1049,14 +1048,14 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
     uint32_t it = blockIdx.x, p = 0, p_next = 0;
     if (it < nparts) {
         p_next = P.defer_list ? P.defer_list[it] : it;
-        cur_lo = sg0.off[p_next], cur_cnt = sg0.off[p_next + 1] - cur_lo, cur_out = P.wbase[p_next];
+        cur_lo = sg0.off[p_next], cur_cnt = seg_count(sg0, p_next, cur_lo), cur_out = P.wbase[p_next];
     }
     for (; it < nparts; it += gridDim.x) {
         p = p_next;
         const uint32_t pn = it + gridDim.x;
         if (pn < nparts) {
             p_next = P.defer_list ? P.defer_list[pn] : pn;
-            nxt_lo = sg0.off[p_next], nxt_cnt = sg0.off[p_next + 1] - nxt_lo, nxt_out = P.wbase[p_next];
+            nxt_lo = sg0.off[p_next], nxt_cnt = seg_count(sg0, p_next, nxt_lo), nxt_out = P.wbase[p_next];
         }
         uint32_t *pay = PAY_LDS ? s_pay_lds : P.pay_scratch + (size_t)blockIdx.x * NSLOT * 5;  // HBM scratch of this workgroup
         const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
@@ -1196,7 +1195,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
         } else {
             for (int r = 0; r < P.nsegs; r++) {
                 const GridSeg sg = r == 0 ? sg0 : P.segs[r];
-                const uint32_t lo = r == 0 ? cur_lo : ldg(sg.off + p), cnt = r == 0 ? cur_cnt : ldg(sg.off + p + 1) - lo;
+                const uint32_t lo = r == 0 ? cur_lo : ldg(sg.off + p), cnt = r == 0 ? cur_cnt : seg_count(sg, p, lo);
                 if (cnt == 0) continue;
                 for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
                     GridTuple tu[FOLD_K];
@@ -1366,8 +1365,9 @@ __device__ __forceinline__ uint32_t lds_insert_dense(uint64_t *s_key, uint64_t k
 }
 
 struct DenseParams {
-    const GridTuple *tuples;       // the second level's output and its partition offsets
-    const uint32_t *off;
+    const GridTuple *tuples;       // the second level's output: partition p = tuples[off[p] .. off[p] + cnt[p])
+    const uint32_t *off;           // (cnt == nullptr: .. off[p + 1])
+    const uint32_t *cnt;
     EntryRef entries;
     DevGridFast g;
     const DevGrid *gfull;          // device copy of the whole grid: the exact computation next to a cell boundary
@@ -1402,7 +1402,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     // (the partition's range and output base are the same for the whole workgroup: scalar registers)
     auto uni32 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     auto uni64 = [&](uint64_t v) { return (uint64_t)uni32((uint32_t)v) | ((uint64_t)uni32((uint32_t)(v >> 32)) << 32); };
-    if (p < nparts) cur_lo = uni32(off[p]), cur_cnt = uni32(off[p + 1]) - cur_lo, cur_out = uni64(P.wbase[p]);
+    const uint32_t *cntp = P.cnt;
+    if (p < nparts) cur_lo = uni32(off[p]), cur_cnt = cntp ? uni32(cntp[p]) : uni32(off[p + 1]) - cur_lo, cur_out = uni64(P.wbase[p]);
     GridTuple tn[PREFETCH ? FOLD_K : 1];  // PREFETCH: the tuples of the partition after the current one, in flight while it is folded
     if (PREFETCH && p < nparts) {
 #pragma unroll
@@ -1413,7 +1414,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     }
     for (; p < nparts; p += gridDim.x) {
         const uint32_t pn = p + gridDim.x;
-        if (pn < nparts) nxt_lo = uni32(off[pn]), nxt_cnt = uni32(off[pn + 1]) - nxt_lo, nxt_out = uni64(P.wbase[pn]);
+        if (pn < nparts) nxt_lo = uni32(off[pn]), nxt_cnt = cntp ? uni32(cntp[pn]) : uni32(off[pn + 1]) - nxt_lo, nxt_out = uni64(P.wbase[pn]);
         const uint32_t cnt = cur_cnt;
         GridTuple tu[FOLD_K];
         if (PREFETCH) {
@@ -1587,7 +1588,7 @@ __global__ __launch_bounds__(L2_NT) void k_alias_gather(FoldParams P, AliasItem 
     uint32_t mine = 0;
     for (int r = 0; r < P.nsegs; r++) {
         const GridSeg sg = P.segs[r];
-        const uint32_t lo = sg.off[p], hi = sg.off[p + 1];
+        const uint32_t lo = sg.off[p], hi = lo + seg_count(sg, p, lo);
         for (uint32_t i = lo + threadIdx.x; i < hi; i += L2_NT) {
             const GridTuple t = ld_tuple(sg.tuples + i);
             const uint64_t key = eval_tuple(P.g, P.entries, t).key;
@@ -1716,7 +1717,6 @@ __global__ __launch_bounds__(BLOCK) void k_drain(const uint64_t *__restrict__ wk
 // ---------------------------------------------------------------------------------------------------------------
 struct GridRun {
     GridTuple *tuples;
-    uint16_t *sub16;   // per tuple: the second-level selector (same slab, behind the tuples)
     uint64_t cap;      // tuples the run has room for (= points scanned)
     uint32_t *binoff;  // device, F1 + 1
 };
@@ -1794,9 +1794,8 @@ struct Scratch {
 
 static int grid_fold(pcq_ctx *ctx, pcq_collector *c);
 
-static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, bool with_sel, GridTuple **out, uint16_t **out_sub16) {
-    const size_t tuple_bytes = ((size_t)tuples * sizeof(GridTuple) + 255) & ~(size_t)255;
-    const size_t bytes = tuple_bytes + (with_sel ? (size_t)tuples * sizeof(uint16_t) : 0);
+static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, GridTuple **out) {
+    const size_t bytes = (size_t)tuples * sizeof(GridTuple);
     if (bytes > gs->slab_left) {
         size_t slab = 256ull << 20;
         if (slab < bytes) slab = bytes;
@@ -1808,7 +1807,6 @@ static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, bool wi
         gs->slab_left = slab;
     }
     *out = (GridTuple *)gs->slab_cur;
-    *out_sub16 = with_sel ? (uint16_t *)(gs->slab_cur + tuple_bytes) : nullptr;
     const size_t used = (bytes + 255) & ~(size_t)255;
     gs->slab_cur += used < gs->slab_left ? used : gs->slab_left;
     gs->slab_left -= used < gs->slab_left ? used : gs->slab_left;
@@ -1861,15 +1859,7 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         GridRun run;
         run.cap = cols.n;
         run.binoff = gs->binoff_store + gs->runs.size() * (F1 + 1);
-        // A grid with so few cells ALTOGETHER that a level-1 bin always fits the big fold never sees a second level:
-        // its scans skip the selectors (2-byte fragments in 10-byte pieces, 40 % more write traffic than their size).
-        // Should a second level happen all the same (option grid_f2, a refold), k_level2_direct computes them.
-        const DevGrid &cg = c->grid;
-        bool with_sel = ctx->grid_f2 > 1 || cg.dims_f[0] * cg.dims_f[1] * cg.dims_f[2] > (double)F1 * BIG_DIRECT;
-#ifdef PCQ_LAB
-        if (ctx->grid_variant & 64) with_sel = false;  // what do the selector stores cost?
-#endif
-        int rc = grid_tuple_room(ctx, gs, cols.n, with_sel, &run.tuples, &run.sub16);
+        int rc = grid_tuple_room(ctx, gs, cols.n, &run.tuples);
         if (rc) return rc;
         gs->pending_cap += cols.n;
 
@@ -1889,10 +1879,7 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         hipLaunchKernelGGL(k_p0_scan_blocks, dim3(F1 / WAVES), dim3(BLOCK), 0, s, cnt, (int)nblocks, total);
         hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, total, run.binoff, (uint32_t)F1);
 #define PCQ_P0_SCATTER(KIND, STREAM) \
-    do { \
-        if (run.sub16) hipLaunchKernelGGL((k_p0_scatter<KIND, STREAM, true>), gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, run.sub16, entry, idx_base); \
-        else hipLaunchKernelGGL((k_p0_scatter<KIND, STREAM, false>), gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, run.sub16, entry, idx_base); \
-    } while (0)
+    hipLaunchKernelGGL((k_p0_scatter<KIND, STREAM>), gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base)
 #ifdef PCQ_LAB
         if ((ctx->grid_variant & 32) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, false);  // plain loads of the positions
         else
@@ -1919,7 +1906,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
 
     // run directory + entries
     std::vector<GridSeg> hsegs(nruns);
-    for (int r = 0; r < nruns; r++) hsegs[r] = GridSeg{gs->runs[r].tuples, gs->runs[r].binoff, gs->runs[r].sub16};
+    for (int r = 0; r < nruns; r++) hsegs[r] = GridSeg{gs->runs[r].tuples, gs->runs[r].binoff, nullptr};
     GridSeg *d_segs = nullptr;
     GridEntryDev *d_entries = nullptr;
     uint32_t *d_bintot = nullptr, *d_binbase = nullptr;
@@ -1978,6 +1965,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         }
     }
 
+    bool level2_exact = false;
     for (int attempt = 0;; attempt++) {
         const uint32_t nparts = (uint32_t)F1 * f2;
         Scratch att(ctx);
@@ -1992,14 +1980,18 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         const bool recut_old = w_old && gs->f2 != f2;
         if (f2 > 1 || recut_old) {
             Level2Params L{};
-            L.segs = d_segs, L.nsegs = nruns, L.entries = eref, L.g = g, L.f2 = f2;
+            L.segs = d_segs, L.nsegs = nruns, L.entries = eref, L.g = g, L.f2 = f2, L.stats = d_stats;
             GridTuple *d_t2 = nullptr;
-            uint32_t *d_off2 = nullptr;
+            uint32_t *d_off2 = nullptr, *d_cnt2 = nullptr;
+            // one pass into regions with slack (k_level2), unless that failed for this fold or does not apply
+            const uint64_t cap = (uint64_t)std::ceil((double)m / nparts * 1.3) + 64;
+            const bool staged = f2 <= (uint32_t)L2_STAGED_F2 && !level2_exact && cap * nparts < (1ull << 32);
             if (f2 > 1) {
-                rc = att.get(m, &d_t2);
+                rc = att.get(staged ? (size_t)(cap * nparts) : (size_t)m, &d_t2);
                 if (!rc) rc = att.get((size_t)nparts + 1, &d_off2);
+                if (!rc && staged) rc = att.get((size_t)nparts, &d_cnt2);
                 if (rc) return rc;
-                L.binbase = d_binbase, L.out = d_t2, L.off2 = d_off2;
+                L.binbase = d_binbase, L.out = d_t2, L.off2 = d_off2, L.cnt2 = d_cnt2, L.cap = (uint32_t)cap;
             }
             uint64_t *d_okeys2 = nullptr, *d_obase2 = nullptr;
             uint8_t *d_orecs2 = nullptr;
@@ -2018,21 +2010,28 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 L.okeys = gs->wkeys, L.orecs = gs->wrecs, L.obase = gs->wbase, L.ocount = gs->wcount, L.f2old = gs->f2;
                 L.obinbase = d_obinbase, L.okeys2 = d_okeys2, L.orecs2 = d_orecs2, L.ooff2 = d_ooff2;
             }
-            bool all_sel = true;
-            for (int r = 0; r < nruns; r++) all_sel = all_sel && gs->runs[r].sub16 != nullptr;
-            if (f2 <= (uint32_t)L2_STAGED_F2 && all_sel) hipLaunchKernelGGL(k_level2, dim3(F1), dim3(L2_NT), 0, s, L);
+            PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
+            if (staged) hipLaunchKernelGGL(k_level2, dim3(F1), dim3(L2_NT), 0, s, L);
             else hipLaunchKernelGGL(k_level2_direct, dim3(F1), dim3(L2_NT), 0, s, L);
             PCQ_HIP(hipGetLastError());
             if (f2 > 1) {
-                ctx->grid_level2++;
-                GridSeg one{d_t2, d_off2, nullptr};
+                GridSeg one{d_t2, d_off2, staged ? d_cnt2 : nullptr};
                 GridSeg *d_one = nullptr;
                 uint32_t *d_tot2 = nullptr;
                 rc = att.get(1, &d_one);
                 if (!rc) rc = att.get(nparts, &d_tot2);
                 if (rc) return rc;
+                unsigned long long outgrown = 0;
                 PCQ_HIP(hipMemcpyAsync(d_one, &one, sizeof one, hipMemcpyHostToDevice, s));
+                PCQ_HIP(hipMemcpyAsync(&outgrown, d_stats + 5, 8, hipMemcpyDeviceToHost, s));
                 PCQ_HIP(hipStreamSynchronize(s));  // `one` is on this stack frame
+                if (staged && outgrown) {  // a sub-partition outgrew its region (cells with very many points): count first, then cut
+                    level2_exact = true;
+                    ctx->grid_level2_exact++;
+                    attempt--;
+                    continue;
+                }
+                ctx->grid_level2++;
                 hipLaunchKernelGGL(k_part_totals, dim3((nparts + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_one, 1, nparts, d_tot2);
                 fold_segs = d_one, fold_seg0 = one, fold_nsegs = 1, d_tot = d_tot2;
             }
@@ -2080,7 +2079,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
             if (dense) {
                 F.defer_list = d_defer;
                 DenseParams D{};
-                D.tuples = fold_seg0.tuples, D.off = fold_seg0.off, D.entries = eref, D.gfull = d_grid;
+                D.tuples = fold_seg0.tuples, D.off = fold_seg0.off, D.cnt = fold_seg0.cnt, D.entries = eref, D.gfull = d_grid;
                 for (int a = 0; a < 3; a++) {
                     D.g.bmin[a] = g.bmin[a], D.g.qk[a] = g.qk[a], D.g.qmax[a] = g.qmax[a], D.g.guard[a] = g.guard[a];
                     D.g.mask[a] = (uint32_t)g.mask[a], D.g.shift[a] = g.shift[a];

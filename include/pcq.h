@@ -248,7 +248,7 @@ int pcq_bind_thread_near_device(pcq_ctx *ctx);
  * "allreduce_single_rank", "grid_pending_budget" (matches a grid collector may hold before it folds them; 0 = default),
  * "grid_f2" (tests: the second-level fan-out a fold starts from; 0 = from the measured estimate).  pcq_get_option also
  * reads "numa_node" and the grid diagnostics "grid_folds", "grid_level2" (folds that needed a second partition level),
- * "grid_refolds" (folds repeated with more partitions), "grid_last_f2".  (The kernel-shape experiments of round 1 —
+ * "grid_refolds" (folds repeated with more partitions), "grid_level2_exact" (second levels repeated in the counting form), "grid_last_f2".  (The kernel-shape experiments of round 1 —
  * "k1_variant", "batch_variant", ... — are options of libpcq_lab.so only: include/pcq_lab.h.) */
 int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value);
 int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value);

@@ -350,6 +350,47 @@ def test_grid_fold_levels_refold_and_forced_fanout(oracle):
             f.free()
 
 
+def test_grid_second_level_regions_outgrown_by_hot_cells(oracle):
+    """The second partition level writes each sub-partition into a fixed region (1.3 x the mean partition + 64 tuples)
+    in one pass; a cell holding thousands of points makes its sub-partition outgrow the region, the kernel reports it and
+    the host repeats the cut in the exact form (count, then scatter).  Same cells and winners as the oracle, and the
+    counter shows which way it went."""
+    n = 400_000
+    spec = small_spec(9090, n, fmt=2)
+    image = oracle.synth_image(spec, transposed=True).copy()
+    hdr = oracle.parse_header(image[:400].tobytes())
+    otp = hdr.offset_to_point_data
+    xyz = image[otp:otp + 12 * n].view("<i4").reshape(n, 3).copy()
+    rng = np.random.default_rng(1)
+    hot = rng.random(n) < 0.1
+    xyz[hot] = np.array([1234, -777, 55]) + rng.integers(0, 3, size=(int(hot.sum()), 3))  # 40 000 points in one or two cells
+    image[otp:otp + 12 * n] = np.frombuffer(np.ascontiguousarray(xyz).tobytes(), dtype=np.uint8)
+    bmin, bmax = (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0)
+    lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+    cell = 0.5
+    og = oracle.grid_collector(bmin, bmax, cell)
+    assert oracle.search_last_bounds(image, bmin, bmax, og) == 0
+    with pkg.Context(0) as ctx:
+        f = DevFile(ctx, image, hdr)
+        try:
+            for forced, outgrown in ((4, True), (0, False)):  # 2048 partitions of ~200 tuples: the hot cell does not fit; no second level at all
+                ctx.set_option("grid_f2", forced)
+                before = ctx.get_option("grid_level2_exact")
+                gg = ctx.grid_collector(bmin, bmax, cell)
+                ctx.scan_dev(f.columns(True), pkg.Predicate.bounds(lmin, lmax), gg)
+                assert gg.point_count() == og.point_count()
+                gp, gk = gg.points(), gg.grid_cells()
+                order = np.argsort(gk, kind="stable")
+                assert np.array_equal(gk[order], og.grid_cells())
+                assert gp[order].tobytes() == og.points().tobytes()
+                gg.free()
+                assert (ctx.get_option("grid_level2_exact") - before >= 1) == outgrown
+            ctx.set_option("grid_f2", 0)
+        finally:
+            f.free()
+    og.free()
+
+
 @pytest.mark.parametrize("cell", [1.0, 0.72, 0.25])
 def test_grid_shared_by_several_scans_with_guessed_tables(oracle, cell):
     """Sequential mode (main.rs:129-133): ONE grid folds several files, first seen wins across them — with the files
