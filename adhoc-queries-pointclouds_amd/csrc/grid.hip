@@ -280,6 +280,23 @@ __device__ __forceinline__ TupleEval eval_exact(const DevGrid &g, double px, dou
     r.dbits = (uint64_t)__double_as_longlong(centre_dist(g, ci.cell, px, py, pz));
     return r;
 }
+// The grid as the fold kernels carry it: what the short computation reads, by value (32 scalar registers), and the whole
+// grid behind a pointer for the exact computation — with DevGrid by value (53 registers) next to the other arguments the
+// kernels moved scalars in and out of vector lanes a thousand times (k_fold<BIG>: 1034 v_readlane).
+struct GridRef {
+    DevGridFast f;
+    const DevGrid *full;
+};
+__device__ __forceinline__ TupleEval eval_tuple(const GridRef &g, const EntryRef &entries, const GridTuple &t) {
+    const GridEntryDev e = entries.get((t.w0 >> 8) & 0xff);
+    const double px = world(t.x, e.scale[0], e.offset[0]), py = world(t.y, e.scale[1], e.offset[1]), pz = world(t.z, e.scale[2], e.offset[2]);
+    const CellFast cf = cell_fast(g.f, px, py, pz);
+    if (!cf.ok) return eval_exact(*g.full, px, py, pz);
+    TupleEval r;
+    r.key = key_fast(g.f, cf, &r.alias);
+    r.dbits = (uint64_t)__double_as_longlong(centre_dist_fast(g.f, cf, px, py, pz));
+    return r;
+}
 __device__ __forceinline__ TupleEval eval_tuple(const DevGrid &g, const EntryRef &entries, const GridTuple &t) {
     const GridEntryDev e = entries.get((t.w0 >> 8) & 0xff);
     const double px = world(t.x, e.scale[0], e.offset[0]), py = world(t.y, e.scale[1], e.offset[1]), pz = world(t.z, e.scale[2], e.offset[2]);
@@ -983,7 +1000,7 @@ struct FoldParams {
     int nsegs;
     GridSeg seg0;                  // segs[0] again, in the kernel arguments: one dependent load fewer when nsegs == 1
     EntryRef entries;
-    DevGrid g;
+    GridRef g;
     // earlier winners by partition (okeys == nullptr: none)
     const uint64_t *okeys;
     const uint8_t *orecs;
@@ -1083,9 +1100,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
             } else {
                 const double *pos = reinterpret_cast<const double *>(rec);
                 uint64_t cell[3];
+                const DevGrid &gf = *P.g.full;
 #pragma unroll
-                for (int a = 0; a < 3; a++) cell[a] = (key >> P.g.shift[a]) & P.g.mask[a];  // not aliased: unmasked == masked
-                s_dist[s] = (uint64_t)__double_as_longlong(centre_dist(P.g, cell, pos[0], pos[1], pos[2]));
+                for (int a = 0; a < 3; a++) cell[a] = (key >> gf.shift[a]) & gf.mask[a];  // not aliased: unmasked == masked
+                s_dist[s] = (uint64_t)__double_as_longlong(centre_dist(gf, cell, pos[0], pos[1], pos[2]));
                 s_ord[s] = 0;
             }
         }
@@ -1227,9 +1245,12 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                         slot[k] = s;
                         if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
                         // most tuples of a coarse grid cannot lower the minimum: a plain read first (a stale value is only too large)
-                        if (ev.dbits < __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                        const uint64_t seen = __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (ev.dbits < seen) {
                             const uint64_t old = atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
                             if (ev.dbits < old) s_ord[s] = ~0ull;  // a new minimum: whoever held the cell is out (racing writers store the same value)
+                        } else if (ev.dbits > seen) {
+                            slot[k] = -1;  // the minimum only falls: this tuple is out of phases 2 and 3 (nearly all of a coarse grid's are)
                         }
                     }
                     __syncthreads();
@@ -1369,8 +1390,7 @@ struct DenseParams {
     const uint32_t *off;           // (cnt == nullptr: .. off[p + 1])
     const uint32_t *cnt;
     EntryRef entries;
-    DevGridFast g;
-    const DevGrid *gfull;          // device copy of the whole grid: the exact computation next to a cell boundary
+    GridRef g;                     // (full: device copy of the whole grid, for the exact computation next to a cell boundary)
     uint64_t *wkeys;
     uint8_t *wrecs;
     const uint64_t *wbase;
@@ -1448,9 +1468,9 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
             const GridEntryDev e = P.entries.get((tu[k].w0 >> 8) & 0xff);
             const double px = world(tu[k].x, e.scale[0], e.offset[0]), py = world(tu[k].y, e.scale[1], e.offset[1]),
                          pz = world(tu[k].z, e.scale[2], e.offset[2]);
-            const CellFast cf = cell_fast(P.g, px, py, pz);
-            key[k] = key_fast(P.g, cf, &alias[k]);
-            dbits[k] = (uint64_t)__double_as_longlong(centre_dist_fast(P.g, cf, px, py, pz));
+            const CellFast cf = cell_fast(P.g.f, px, py, pz);
+            key[k] = key_fast(P.g.f, cf, &alias[k]);
+            dbits[k] = (uint64_t)__double_as_longlong(centre_dist_fast(P.g.f, cf, px, py, pz));
             inexact |= cf.ok ? 0u : 1u << k;
         }
         if (__any(inexact != 0)) {  // rare: one copy of the exact computation, off the common path
@@ -1463,7 +1483,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
                 for (int j = 1; j < FOLD_K; j++)
                     if (j == kk) x = tu[j].x, y = tu[j].y, z = tu[j].z, w0 = tu[j].w0;
                 const GridEntryDev e = P.entries.get((w0 >> 8) & 0xff);
-                const TupleEval ev = eval_exact(*P.gfull, world(x, e.scale[0], e.offset[0]), world(y, e.scale[1], e.offset[1]), world(z, e.scale[2], e.offset[2]));
+                const TupleEval ev = eval_exact(*P.g.full, world(x, e.scale[0], e.offset[0]), world(y, e.scale[1], e.offset[1]), world(z, e.scale[2], e.offset[2]));
 #pragma unroll
                 for (int j = 0; j < FOLD_K; j++)
                     if (j == kk) key[j] = ev.key, dbits[j] = ev.dbits, alias[j] = ev.alias;
@@ -1652,8 +1672,9 @@ __global__ __launch_bounds__(BLOCK) void k_alias_replay(const AliasItem *__restr
         if (!has) {
             take = true;  // grid_sampling.rs:73-76
         } else {          // :77-103 — both distances against the NEW point's (unmasked) cell centre
-            const CellInfo ci = cell_of(P.g, px, py, pz);
-            take = centre_dist(P.g, ci.cell, px, py, pz) < centre_dist(P.g, ci.cell, cx, cy, cz);
+            const DevGrid &gf = *P.g.full;
+            const CellInfo ci = cell_of(gf, px, py, pz);
+            take = centre_dist(gf, ci.cell, px, py, pz) < centre_dist(gf, ci.cell, cx, cy, cz);
         }
         if (take) {
             best = it, cx = px, cy = py, cz = pz;
@@ -1920,6 +1941,13 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     if (!rc) rc = tmp.get(1, &d_grid);
     if (rc) return rc;
     PCQ_HIP(hipMemcpyAsync(d_grid, &g, sizeof g, hipMemcpyHostToDevice, s));
+    GridRef gref{};
+    gref.full = d_grid;
+    for (int a = 0; a < 3; a++) {
+        gref.f.bmin[a] = g.bmin[a], gref.f.qk[a] = g.qk[a], gref.f.qmax[a] = g.qmax[a], gref.f.guard[a] = g.guard[a];
+        gref.f.mask[a] = (uint32_t)g.mask[a], gref.f.shift[a] = g.shift[a];
+    }
+    gref.f.cell_size = g.cell_size;
     PCQ_HIP(hipMemcpyAsync(d_segs, hsegs.data(), nruns * sizeof(GridSeg), hipMemcpyHostToDevice, s));
     PCQ_HIP(hipMemcpyAsync(d_entries, gs->entries.data(), gs->entries.size() * sizeof(GridEntryDev), hipMemcpyHostToDevice, s));
     EntryRef eref;
@@ -2070,7 +2098,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         PCQ_HIP(hipMemsetAsync(d_palias, 0, (size_t)nparts * 4, s));
         PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
         FoldParams F{};
-        F.segs = fold_segs, F.nsegs = fold_nsegs, F.seg0 = fold_seg0, F.entries = eref, F.g = g;
+        F.segs = fold_segs, F.nsegs = fold_nsegs, F.seg0 = fold_seg0, F.entries = eref, F.g = gref;
         if (w_old) F.okeys = okeys, F.orecs = orecs, F.obase = obase, F.ocount = ocount;
         F.wkeys = n_wkeys, F.wrecs = n_wrecs, F.wbase = n_wbase, F.wcount = n_wcount, F.palias = d_palias, F.pay_scratch = d_pay, F.stats = d_stats;
         {
@@ -2079,12 +2107,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
             if (dense) {
                 F.defer_list = d_defer;
                 DenseParams D{};
-                D.tuples = fold_seg0.tuples, D.off = fold_seg0.off, D.cnt = fold_seg0.cnt, D.entries = eref, D.gfull = d_grid;
-                for (int a = 0; a < 3; a++) {
-                    D.g.bmin[a] = g.bmin[a], D.g.qk[a] = g.qk[a], D.g.qmax[a] = g.qmax[a], D.g.guard[a] = g.guard[a];
-                    D.g.mask[a] = (uint32_t)g.mask[a], D.g.shift[a] = g.shift[a];
-                }
-                D.g.cell_size = g.cell_size;
+                D.tuples = fold_seg0.tuples, D.off = fold_seg0.off, D.cnt = fold_seg0.cnt, D.entries = eref, D.g = gref;
                 D.wkeys = n_wkeys, D.wrecs = n_wrecs, D.wbase = n_wbase, D.wcount = n_wcount, D.palias = d_palias, D.stats = d_stats, D.defer_list = d_defer;
 #ifdef PCQ_LAB
                 D.lab_flags = (uint32_t)ctx->grid_variant >> 4;  // 16: no winner records (what do their stores cost?)
