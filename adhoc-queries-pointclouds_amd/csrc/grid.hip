@@ -1042,7 +1042,7 @@ __device__ __forceinline__ int lds_find_or_insert(uint64_t *s_key, uint64_t key,
 // SMALL (XPART) keeps the next PARTITION's first chunk in flight and loads further chunks of a partition (rare: a partition
 // is about one chunk) on demand.  BIG loads chunk by chunk: with 16 waves on the CU a register prefetch of the next chunk
 // measured no faster and spilled.
-template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool PAY_LDS, bool XPART, bool DIRECT, int MIN_WAVES>
+template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool PAY_LDS, bool XPART, bool DIRECT, bool CPF, int MIN_WAVES>
 __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t nparts) {
     constexpr int SPT = (NSLOT + NT - 1) / NT;   // slots per thread in the compaction
     constexpr int CHUNK = NT * FOLD_K;
@@ -1215,11 +1215,29 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                 const GridSeg sg = r == 0 ? sg0 : P.segs[r];
                 const uint32_t lo = r == 0 ? cur_lo : ldg(sg.off + p), cnt = r == 0 ? cur_cnt : seg_count(sg, p, lo);
                 if (cnt == 0) continue;
+                GridTuple tn[CPF ? FOLD_K : 1];  // CPF: the next chunk's tuples, in flight while the current chunk is folded
+                if (CPF) {
+#pragma unroll
+                    for (int k = 0; k < FOLD_K; k++) {
+                        const uint32_t i = k * NT + threadIdx.x;
+                        tn[CPF ? k : 0] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
+                    }
+                }
                 for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
                     GridTuple tu[FOLD_K];
                     uint64_t dbits[FOLD_K];
                     int slot[FOLD_K];
-                    if (XPART && r == 0 && c0 == 0 && have_first) {
+                    if (CPF) {
+#pragma unroll
+                        for (int k = 0; k < FOLD_K; k++) tu[k] = tn[CPF ? k : 0];
+                        if (c0 + CHUNK < cnt) {
+#pragma unroll
+                            for (int k = 0; k < FOLD_K; k++) {
+                                const uint32_t i = c0 + CHUNK + k * NT + threadIdx.x;
+                                tn[CPF ? k : 0] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
+                            }
+                        }
+                    } else if (XPART && r == 0 && c0 == 0 && have_first) {
 #pragma unroll
                         for (int k = 0; k < FOLD_K; k++) tu[k] = first[XPART ? k : 0];
                     } else {
@@ -2117,8 +2135,13 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
 #endif
                 hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, false, 6>), dim3(resident), dim3(DENSE_NT), 0, s, D, nparts);
             }
-            if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
-            else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, false, true, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
+#ifdef PCQ_LAB
+            if (big && (ctx->grid_variant & 128)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, 3, BIG_LIMIT, false, false, false, true, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
+            else if (big && (ctx->grid_variant & 256)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, true, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
+            else
+#endif
+            if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
+            else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, false, true, false, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
         }
         PCQ_HIP(hipGetLastError());
         unsigned long long st[4] = {0, 0, 0, 0};
