@@ -18,9 +18,14 @@
 //           tuples into an open-addressing table in LDS — atomicMin on the f64 distance bits, then on the file-order
 //           index among the tuples at the minimum, then the winner parks its payload — and writes one 32-byte record
 //           + key per cell, coalesced.  A coarse grid folds its level-1 bins directly (k_fold<BIG>: a CU's whole LDS
-//           as one 6400-slot table); a denser grid first gets a second partition level (k_level2, fan-out chosen from
-//           a measured estimate of the distinct cells per bin) and folds the small partitions three to a CU
-//           (k_fold<SMALL>).
+//           as one 6400-slot table); a denser grid first gets a second partition level (k_level2: one pass into
+//           fixed regions with slack, fan-out chosen from a measured estimate of the distinct cells per bin) and
+//           folds the small partitions three workgroups to a CU (k_fold_dense; k_fold<SMALL> for what that leaves:
+//           earlier winners, several segments, partitions longer than a chunk).
+// What the kernels had to learn about gfx950: every pass is bound by vector instructions before it is
+// bound by memory unless the cell arithmetic is cut down (cell_fast); loads and stores share one in-order counter, so a
+// prefetch must be waited for before the stores behind it are issued; pointers loaded from memory make flat loads,
+// which also hold every LDS wait.
 // The folded winners are kept grouped by partition, so a later fold (more scans into the same collector: sequential
 // mode shares one grid, main.rs:129-133; a file streamed in chunks) merges them with the new tuples partition by
 // partition: an old winner is earlier in file order than every new tuple and its distance is recomputed from its
@@ -31,7 +36,7 @@
 // result depends on the visiting order; their slots are flagged during the fold and the key is re-folded exactly,
 // in file order, from its tuples (k_alias_*: gather, rank sort, sequential replay of insert_point).
 //
-// Integer / f64 work bound by HBM streaming (tuples written once and read once or twice); not reshaped into GEMMs.
+// Integer / f64 work over streamed tuples (written and read once per partition level); not reshaped into GEMMs.
 #include <algorithm>
 #include <cmath>
 
@@ -46,13 +51,14 @@ constexpr int F1 = 1 << F1_BITS;       // level-1 bins: the top F1_BITS bits of 
 constexpr int F2_MAX = 4096;           // largest second-level fan-out
 constexpr int P0_NT = 512;             // pass 0: threads per workgroup
 constexpr int P0_ITEMS = 5;            // pass 0: points per thread and tile
-constexpr int P0_TILE = P0_NT * P0_ITEMS;  // 2560 points: their tuples (60 KB) and bin / selector words (10 KB) are staged in LDS, two workgroups per CU
+constexpr int P0_TILE = P0_NT * P0_ITEMS;  // 2560 points: their tuples (60 KB) and bins (5 KB) are staged in LDS, two workgroups per CU
 constexpr int P0_MAX_BLOCKS = 1024;    // pass 0: at most this many workgroups (rows of the count table)
-// The fold comes in two shapes.  BIG: one 1024-thread workgroup owns a CU's whole LDS — 6400 slots of {key, distance,
-// file order}, the winner's payload parked in HBM scratch — and folds a level-1 bin directly (coarse grids: few cells,
-// many tuples per cell).  SMALL: 2048 slots, three 256-thread workgroups per CU, seven tuples per thread — a whole
-// partition of the second level (about 1100 cells, 1500 tuples) in registers, so that the winner of a cell writes its
-// record straight from there (dense grids: about one tuple per cell, many small partitions).
+// The fold's shapes.  BIG: one 1024-thread workgroup owns a CU's whole LDS — 6400 slots of {key, distance, file order},
+// the winner's payload parked in HBM scratch — and folds a level-1 bin directly (coarse grids: few cells, many tuples
+// per cell).  SMALL / DENSE: 2048 slots, three workgroups per CU, a whole partition of the second level (about 1000
+// cells, 1330 tuples) in registers, so that the winner of a cell writes its record straight from there (dense grids:
+// about one tuple per cell, many small partitions) — 256 threads x 6 tuples in the general kernel, 512 x 3 in
+// k_fold_dense.
 constexpr int BIG_SLOTS = 6400, BIG_NT = 1024, BIG_LIMIT = 5440, BIG_DIRECT = 4700;
 constexpr int SMALL_SLOTS = 2048, SMALL_NT = 256, SMALL_K = 6, SMALL_LIMIT = 1740, SMALL_TARGET = 1000;
 constexpr int BIG_K = 4;               // fold: tuples per thread and chunk
