@@ -52,6 +52,9 @@ constexpr int F2_MAX = 4096;           // largest second-level fan-out
 constexpr int P0_NT = 512;             // pass 0: threads per workgroup
 constexpr int P0_ITEMS = 5;            // pass 0: points per thread and tile
 constexpr int P0_TILE = P0_NT * P0_ITEMS;  // 2560 points: their tuples (60 KB) and bins (5 KB) are staged in LDS, two workgroups per CU
+constexpr int SC_NT = 1024, SC_ITEMS = 5;  // k_p0_scatter: one workgroup per CU sorts tiles of 5120 points in 141 KB of LDS — a bin's run
+                                       // out of a tile is 10 tuples (240 bytes) instead of 5: 2.50 -> 2.19 ms against two 512-thread
+                                       // workgroups with 2560-point tiles, same process (256 threads x 10 points on that tile: no change)
 constexpr int P0_MAX_BLOCKS = 1024;    // pass 0: at most this many workgroups (rows of the count table)
 // The fold's shapes.  BIG: one 1024-thread workgroup owns a CU's whole LDS — 6400 slots of {key, distance, file order},
 // the winner's payload parked in HBM scratch — and folds a level-1 bin directly (coarse grids: few cells, many tuples
@@ -65,8 +68,7 @@ constexpr int BIG_K = 4;               // fold: tuples per thread and chunk
 constexpr int DENSE_NT = 512, DENSE_K = 3;  // k_fold_dense: the same chunk (1536 tuples) on twice the waves
 constexpr int L2_NT = 512;             // second level: threads per workgroup (one workgroup per level-1 bin)
 constexpr int L2_UNROLL = 4;
-constexpr int L2_ITEMS = 3;            // second level, staged form: tuples per thread and tile (1536 tuples = 36 KB of LDS)
-constexpr int L2_TILE = L2_NT * L2_ITEMS;
+constexpr int L2S_NT = 1024, L2S_ITEMS = 4, L2S_TILE = L2S_NT * L2S_ITEMS;  // k_level2: one workgroup per CU, tiles of 4096 tuples (132 KB of LDS)
 constexpr int L2_STAGED_F2 = 1024;     // largest fan-out of the staged form (its per-tile tables live in LDS)
 constexpr int PROBE_BINS = 2;          // bins whose distinct cells are counted to estimate the grid's density
 constexpr uint64_t ALIAS_QUADRATIC = 8192;  // aliased tuples up to which the replay order comes from the quadratic rank kernel
@@ -372,31 +374,31 @@ __device__ __forceinline__ bool p0_pass(const DevCols &c, const DevPred &pr, con
 
 // Workgroup b owns the points [b * per_block, (b + 1) * per_block): cnt[b][bin] = its matches per level-1 bin.
 // The inputs of the next tile are loaded before the current one is evaluated.
-template <int KIND>
-__global__ __launch_bounds__(P0_NT) void k_p0_hist(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, uint32_t *__restrict__ cnt) {
+template <int KIND, int NT>
+__global__ __launch_bounds__(NT) void k_p0_hist(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, uint32_t *__restrict__ cnt) {
     __shared__ uint32_t hist[F1];
-    for (int t = threadIdx.x; t < F1; t += P0_NT) hist[t] = 0;
+    for (int t = threadIdx.x; t < F1; t += NT) hist[t] = 0;
     __syncthreads();
     const uint64_t begin = (uint64_t)blockIdx.x * per_block;
     const uint64_t end = begin + per_block < c.n ? begin + per_block : c.n;
     P0In<KIND> cur[P0_ITEMS], nxt[P0_ITEMS];
 #pragma unroll
     for (int j = 0; j < P0_ITEMS; j++) {
-        const uint64_t i = begin + (uint64_t)j * P0_NT + threadIdx.x;
+        const uint64_t i = begin + (uint64_t)j * NT + threadIdx.x;
         cur[j] = p0_load<KIND>(c, i < end ? i : end - 1);
     }
-    for (uint64_t base = begin; base < end; base += P0_TILE) {
-        const uint64_t nbase = base + P0_TILE;
+    for (uint64_t base = begin; base < end; base += (NT * P0_ITEMS)) {
+        const uint64_t nbase = base + (NT * P0_ITEMS);
         if (nbase < end) {
 #pragma unroll
             for (int j = 0; j < P0_ITEMS; j++) {
-                const uint64_t i = nbase + (uint64_t)j * P0_NT + threadIdx.x;
+                const uint64_t i = nbase + (uint64_t)j * NT + threadIdx.x;
                 nxt[j] = p0_load<KIND>(c, i < end ? i : end - 1);
             }
         }
 #pragma unroll
         for (int j = 0; j < P0_ITEMS; j++) {
-            const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
+            const uint64_t i = base + (uint64_t)j * NT + threadIdx.x;
             if (i >= end || !p0_pass<KIND>(c, pr, cur[j])) continue;
             if (KIND == PCQ_PRED_CLASS) cur[j].rp = ld_xyz(c, i);
             atomicAdd(&hist[bin_of(point_hash<KIND>(c, g, cur[j].rp))], 1u);
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(P0_NT) void k_p0_hist(DevCols c, DevPred pr, DevGri
         for (int j = 0; j < P0_ITEMS; j++) cur[j] = nxt[j];
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < F1; t += P0_NT) cnt[(size_t)blockIdx.x * F1 + t] = hist[t];
+    for (int t = threadIdx.x; t < F1; t += NT) cnt[(size_t)blockIdx.x * F1 + t] = hist[t];
 }
 
 // cnt[b][bin] -> exclusive prefix over the workgroups b, per bin (one wave per bin); total[bin] = the bin's tuples.
@@ -493,39 +495,43 @@ __global__ __launch_bounds__(1024) void k_excl_scan_u64(const uint64_t *__restri
 // a bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.  A tuple is staged (and stored) as
 // 16 + 8 bytes; next to it sits its bin, which gives the tuple's place in the run (the tile's first place in the bin + the
 // tuple's place in the sorted image).
-template <int KIND, bool STREAM>
-__global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
+template <int KIND, bool STREAM, int NT, int ITEMS>
+__global__ __launch_bounds__(NT, NT == 512 ? 4 : (NT == 1024 ? 4 : 2)) void k_p0_scatter(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
                                                       const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out,
                                                       uint32_t entry, uint64_t idx_base) {
-    static_assert(F1 == P0_NT, "one thread per bin in the per-tile scan");
-    __shared__ uint4 s_xyzi[P0_TILE];        // the tile's tuples, sorted by bin: x, y, z, idx
-    __shared__ uint2 s_attr[P0_TILE];        //                                    w0, w1
-    __shared__ uint16_t s_bin[P0_TILE];      // its bin
-    __shared__ uint32_t s_cnt[F1], s_base[F1], s_delta[F1], s_cur[F1], s_wsum[P0_NT / 64];
+    constexpr int TILE = NT * ITEMS;
+    static_assert(TILE % P0_TILE == 0 && (F1 % NT == 0 || NT % F1 == 0), "whole tiles of the histogram pass; whole bins per thread in the per-tile scan");
+    constexpr int BPT = F1 >= NT ? F1 / NT : 1;  // bins per thread in the scan (threads beyond the bins idle there)
+    __shared__ uint4 s_xyzi[TILE];        // the tile's tuples, sorted by bin: x, y, z, idx
+    __shared__ uint2 s_attr[TILE];        //                                    w0, w1
+    __shared__ uint16_t s_bin[TILE];      // its bin
+    __shared__ uint32_t s_cnt[F1], s_base[F1], s_delta[F1], s_cur[F1], s_wsum[NT / 64];
     __shared__ uint32_t s_total;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    s_cur[threadIdx.x] = binoff[threadIdx.x] + cnt_excl[(size_t)blockIdx.x * F1 + threadIdx.x];
-    s_cnt[threadIdx.x] = 0;
+    for (int t = threadIdx.x; t < F1; t += NT) {
+        s_cur[t] = binoff[t] + cnt_excl[(size_t)blockIdx.x * F1 + t];
+        s_cnt[t] = 0;
+    }
     __syncthreads();
     const uint64_t begin = (uint64_t)blockIdx.x * per_block;
     const uint64_t end = begin + per_block < c.n ? begin + per_block : c.n;
-    P0In<KIND> cur[P0_ITEMS], nxt[P0_ITEMS];
+    P0In<KIND> cur[ITEMS], nxt[ITEMS];
 #pragma unroll
-    for (int j = 0; j < P0_ITEMS; j++) {
-        const uint64_t i = begin + (uint64_t)j * P0_NT + threadIdx.x;
+    for (int j = 0; j < ITEMS; j++) {
+        const uint64_t i = begin + (uint64_t)j * NT + threadIdx.x;
         cur[j] = p0_load<KIND, STREAM>(c, i < end ? i : end - 1);
     }
 #pragma unroll
-    for (int j = 0; j < P0_ITEMS; j++) {  // (arrived: inside the loop nothing is pending at its head, see below)
+    for (int j = 0; j < ITEMS; j++) {  // (arrived: inside the loop nothing is pending at its head, see below)
         if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
         else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
     }
-    for (uint64_t base = begin; base < end; base += P0_TILE) {
-        const uint64_t nbase = base + P0_TILE;
+    for (uint64_t base = begin; base < end; base += TILE) {
+        const uint64_t nbase = base + TILE;
         if (nbase < end) {  // the next tile's inputs are on their way while this one is sorted
 #pragma unroll
-            for (int j = 0; j < P0_ITEMS; j++) {
-                const uint64_t i = nbase + (uint64_t)j * P0_NT + threadIdx.x;
+            for (int j = 0; j < ITEMS; j++) {
+                const uint64_t i = nbase + (uint64_t)j * NT + threadIdx.x;
                 nxt[j] = p0_load<KIND, STREAM>(c, i < end ? i : end - 1);
             }
         }
@@ -534,11 +540,11 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
         // right behind the copy-out.  Per tile: the attributes of this tile's matches are asked for here (nothing is
         // computed on them until the staging, two barriers later); the next tile's positions were asked for above and are
         // waited for BEFORE this tile's stores are issued.
-        bool passes[P0_ITEMS];
-        uint32_t metas[P0_ITEMS], ranks[P0_ITEMS], rg[P0_ITEMS], bb[P0_ITEMS], cl[P0_ITEMS];
+        bool passes[ITEMS];
+        uint32_t metas[ITEMS], ranks[ITEMS], rg[ITEMS], bb[ITEMS], cl[ITEMS];
 #pragma unroll
-        for (int j = 0; j < P0_ITEMS; j++) {
-            const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
+        for (int j = 0; j < ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * NT + threadIdx.x;
             passes[j] = i < end && p0_pass<KIND>(c, pr, cur[j]);
             rg[j] = 0, bb[j] = 0, cl[j] = KIND == PCQ_PRED_CLASS ? cur[j].cls : 0;
             if (!passes[j]) continue;
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
             if (KIND != PCQ_PRED_CLASS && c.cls) cl[j] = c.cls[i * c.cls_stride];  // last.rs:138-142
         }
 #pragma unroll
-        for (int j = 0; j < P0_ITEMS; j++) {
+        for (int j = 0; j < ITEMS; j++) {
             if (!passes[j]) continue;
             const uint64_t h = point_hash<KIND>(c, g, cur[j].rp);
             const uint32_t bin = bin_of(h);
@@ -559,9 +565,11 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
             ranks[j] = atomicAdd(&s_cnt[bin], 1u);
         }
         __syncthreads();
-        {  // exclusive scan of the tile's counts over the bins (thread t = bin t); the workgroup's cursors move on
-            const uint32_t v = s_cnt[threadIdx.x];
-            uint32_t incl = v;
+        {  // exclusive scan of the tile's counts over the bins (thread t = bins t * BPT ...); the workgroup's cursors move on
+            uint32_t v[BPT], mine = 0;
+#pragma unroll
+            for (int q = 0; q < BPT; q++) v[q] = threadIdx.x * BPT + q < F1 ? s_cnt[threadIdx.x * BPT + q] : 0, mine += v[q];
+            uint32_t incl = mine;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t up = __shfl_up(incl, off, 64);
@@ -569,36 +577,42 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_scatter(DevCols c, DevPred pr, 
             }
             if (lane == 63) s_wsum[wave] = incl;
             __syncthreads();
-            uint32_t before = incl - v, total = 0;
-            for (int w = 0; w < P0_NT / 64; w++) {
+            uint32_t before = incl - mine, total = 0;
+            for (int w = 0; w < NT / 64; w++) {
                 before += w < wave ? s_wsum[w] : 0;
                 total += s_wsum[w];
             }
-            s_base[threadIdx.x] = before;
-            s_delta[threadIdx.x] = s_cur[threadIdx.x] - before;
-            s_cur[threadIdx.x] += v;
-            s_cnt[threadIdx.x] = 0;
+#pragma unroll
+            for (int q = 0; q < BPT; q++) {
+                const int bin = threadIdx.x * BPT + q;
+                if (bin >= F1) continue;
+                s_base[bin] = before;
+                s_delta[bin] = s_cur[bin] - before;
+                s_cur[bin] += v[q];
+                s_cnt[bin] = 0;
+                before += v[q];
+            }
             if (threadIdx.x == 0) s_total = total;
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < P0_ITEMS; j++) {
+        for (int j = 0; j < ITEMS; j++) {
             if (!passes[j]) continue;
-            const uint64_t i = base + (uint64_t)j * P0_NT + threadIdx.x;
+            const uint64_t i = base + (uint64_t)j * NT + threadIdx.x;
             const uint32_t at = s_base[metas[j]] + ranks[j];
             s_xyzi[at] = make_uint4((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y, (uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
             s_attr[at] = make_uint2(cl[j] | (entry << 8) | (rg[j] << 16), (rg[j] >> 16) | (bb[j] << 16));
             s_bin[at] = (uint16_t)metas[j];
         }
 #pragma unroll
-        for (int j = 0; j < P0_ITEMS; j++) {  // the next tile's inputs have arrived (asked for a whole tile ago) — before the stores below
+        for (int j = 0; j < ITEMS; j++) {  // the next tile's inputs have arrived (asked for a whole tile ago) — before the stores below
             cur[j] = nxt[j];
             if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
             else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
         }
         __syncthreads();
         const uint32_t total = s_total;
-        for (uint32_t t = threadIdx.x; t < total; t += P0_NT) {
+        for (uint32_t t = threadIdx.x; t < total; t += NT) {
             const uint4 a = s_xyzi[t];
             const uint2 b = s_attr[t];
             const uint32_t pos = s_delta[s_bin[t]] + t;
@@ -837,23 +851,25 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
 // raises stats[5]: the host then takes the exact form (k_level2_direct), which counts first.
 // (An earlier shape had pass 0 store every tuple's selector bits so that a histogram pass here could read 2 bytes per
 // tuple: those 2-byte stores cost pass 0 0.2-0.7 ms per 163 M points, more than the pass they fed.)
-__global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
+__global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
+    constexpr int BPT = L2_STAGED_F2 / L2S_NT;  // sub-partitions per thread in the per-tile scan
+    static_assert(BPT >= 1 && BPT * L2S_NT == L2_STAGED_F2, "whole sub-partitions per thread");
     __shared__ uint32_t s_cur[L2_STAGED_F2], s_ohist[L2_STAGED_F2], s_ocur[L2_STAGED_F2];
     __shared__ uint32_t s_cnt[L2_STAGED_F2], s_base[L2_STAGED_F2];
-    __shared__ uint4 s_xyzi[L2_TILE];   // the tile's tuples, sorted by sub-partition: x, y, z, idx
-    __shared__ uint2 s_attr[L2_TILE];   //                                                 w0, w1
-    __shared__ uint32_t s_tpos[L2_TILE];
-    __shared__ uint32_t s_wsum[L2_NT / 64], s_total, s_overflow;
+    __shared__ uint4 s_xyzi[L2S_TILE];   // the tile's tuples, sorted by sub-partition: x, y, z, idx
+    __shared__ uint2 s_attr[L2S_TILE];   //                                                 w0, w1
+    __shared__ uint32_t s_tpos[L2S_TILE];
+    __shared__ uint32_t s_wsum[L2S_NT / 64], s_total, s_overflow;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t bin = blockIdx.x, f2 = P.f2, cap = P.cap;
-    for (uint32_t t = threadIdx.x; t < L2_STAGED_F2; t += L2_NT) s_cur[t] = 0, s_ohist[t] = 0, s_cnt[t] = 0;
+    for (uint32_t t = threadIdx.x; t < L2_STAGED_F2; t += L2S_NT) s_cur[t] = 0, s_ohist[t] = 0, s_cnt[t] = 0;
     if (threadIdx.x == 0) s_overflow = 0;
     __syncthreads();
     if (P.okeys)
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
             const uint64_t base = P.obase[q];
             const uint32_t n = P.ocount[q];
-            for (uint32_t i = threadIdx.x; i < n; i += L2_NT) atomicAdd(&s_ohist[sub_of(cell_hash(P.okeys[base + i]), f2)], 1u);
+            for (uint32_t i = threadIdx.x; i < n; i += L2S_NT) atomicAdd(&s_ohist[sub_of(cell_hash(P.okeys[base + i]), f2)], 1u);
         }
     __syncthreads();
     if (threadIdx.x == 0 && P.okeys) {  // f2 <= 1024: a serial prefix is a thousand LDS reads
@@ -872,36 +888,38 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
             const GridSeg sg = P.segs[r];
             const uint32_t lo = ldg(sg.off + bin), hi = ldg(sg.off + bin + 1);
             if (lo >= hi) continue;
-            GridTuple t[L2_ITEMS], tn[L2_ITEMS];
+            GridTuple t[L2S_ITEMS], tn[L2S_ITEMS];
 #pragma unroll
-            for (int j = 0; j < L2_ITEMS; j++) {
-                const uint32_t i = lo + j * L2_NT + threadIdx.x;
+            for (int j = 0; j < L2S_ITEMS; j++) {
+                const uint32_t i = lo + j * L2S_NT + threadIdx.x;
                 t[j] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
             }
 #pragma unroll
-            for (int j = 0; j < L2_ITEMS; j++)  // (arrived: see k_p0_scatter on the one counter for loads and stores)
+            for (int j = 0; j < L2S_ITEMS; j++)  // (arrived: see k_p0_scatter on the one counter for loads and stores)
                 asm volatile("" ::"v"(t[j].x), "v"(t[j].w0));
-            for (uint32_t base = lo; base < hi; base += L2_TILE) {
-                if (base + L2_TILE < hi) {  // the next tile is on its way while this one is sorted
+            for (uint32_t base = lo; base < hi; base += L2S_TILE) {
+                if (base + L2S_TILE < hi) {  // the next tile is on its way while this one is sorted
 #pragma unroll
-                    for (int j = 0; j < L2_ITEMS; j++) {
-                        const uint32_t i = base + L2_TILE + j * L2_NT + threadIdx.x;
+                    for (int j = 0; j < L2S_ITEMS; j++) {
+                        const uint32_t i = base + L2S_TILE + j * L2S_NT + threadIdx.x;
                         tn[j] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
                     }
                 }
-                uint32_t subs[L2_ITEMS], ranks[L2_ITEMS];
-                bool valid[L2_ITEMS];
+                uint32_t subs[L2S_ITEMS], ranks[L2S_ITEMS];
+                bool valid[L2S_ITEMS];
 #pragma unroll
-                for (int j = 0; j < L2_ITEMS; j++) {
-                    valid[j] = base + j * L2_NT + threadIdx.x < hi;
+                for (int j = 0; j < L2S_ITEMS; j++) {
+                    valid[j] = base + j * L2S_NT + threadIdx.x < hi;
                     subs[j] = sub_of(cell_hash(eval_tuple(P.g, P.entries, t[j]).key), f2);
                     if (valid[j]) ranks[j] = atomicAdd(&s_cnt[subs[j]], 1u);
                 }
                 __syncthreads();
-                {  // exclusive scan of the tile's counts over the sub-partitions (two per thread)
-                    const uint32_t s0 = threadIdx.x * 2;
-                    const uint32_t v0 = s_cnt[s0], v1 = s_cnt[s0 + 1];
-                    uint32_t incl = v0 + v1;
+                {  // exclusive scan of the tile's counts over the sub-partitions (BPT per thread)
+                    const uint32_t s0 = threadIdx.x * BPT;
+                    uint32_t v[BPT], mine = 0;
+#pragma unroll
+                    for (int q = 0; q < BPT; q++) v[q] = s_cnt[s0 + q], mine += v[q];
+                    uint32_t incl = mine;
 #pragma unroll
                     for (int off = 1; off < 64; off <<= 1) {
                         const uint32_t up = __shfl_up(incl, off, 64);
@@ -909,20 +927,22 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
                     }
                     if (lane == 63) s_wsum[wave] = incl;
                     __syncthreads();
-                    uint32_t before = incl - v0 - v1, total = 0;
-                    for (int w = 0; w < L2_NT / 64; w++) {
+                    uint32_t before = incl - mine, total = 0;
+                    for (int w = 0; w < L2S_NT / 64; w++) {
                         before += w < wave ? s_wsum[w] : 0;
                         total += s_wsum[w];
                     }
-                    s_base[s0] = before;
-                    s_base[s0 + 1] = before + v0;
-                    s_cnt[s0] = 0;
-                    s_cnt[s0 + 1] = 0;
+#pragma unroll
+                    for (int q = 0; q < BPT; q++) {
+                        s_base[s0 + q] = before;
+                        s_cnt[s0 + q] = 0;
+                        before += v[q];
+                    }
                     if (threadIdx.x == 0) s_total = total;
                 }
                 __syncthreads();
 #pragma unroll
-                for (int j = 0; j < L2_ITEMS; j++) {
+                for (int j = 0; j < L2S_ITEMS; j++) {
                     if (!valid[j]) continue;
                     const uint32_t at = s_base[subs[j]] + ranks[j];
                     s_xyzi[at] = make_uint4((uint32_t)t[j].x, (uint32_t)t[j].y, (uint32_t)t[j].z, t[j].idx);
@@ -931,18 +951,20 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
                     s_tpos[at] = within < cap ? subs[j] * cap + within : 0xffffffffu;
                 }
 #pragma unroll
-                for (int j = 0; j < L2_ITEMS; j++) {  // the next tile has arrived — before this tile's stores are issued
+                for (int j = 0; j < L2S_ITEMS; j++) {  // the next tile has arrived — before this tile's stores are issued
                     t[j] = tn[j];
                     asm volatile("" ::"v"(t[j].x), "v"(t[j].w0));
                 }
                 __syncthreads();
-                {  // the cursors move on (thread t owns sub-partitions 2t, 2t + 1: their tile counts are s_base differences)
-                    const uint32_t s0 = threadIdx.x * 2, total = s_total;
-                    const uint32_t b0 = s_base[s0], b1 = s_base[s0 + 1], b2 = s0 + 2 < L2_STAGED_F2 ? s_base[s0 + 2] : total;
-                    s_cur[s0] += b1 - b0;
-                    s_cur[s0 + 1] += b2 - b1;
-                    if (s_cur[s0] > cap || s_cur[s0 + 1] > cap) s_overflow = 1;
-                    for (uint32_t k = threadIdx.x; k < total; k += L2_NT) {
+                {  // the cursors move on (a thread's sub-partitions: their tile counts are s_base differences)
+                    const uint32_t s0 = threadIdx.x * BPT, total = s_total;
+#pragma unroll
+                    for (int q = 0; q < BPT; q++) {
+                        const uint32_t lo_b = s_base[s0 + q], hi_b = s0 + q + 1 < L2_STAGED_F2 ? s_base[s0 + q + 1] : total;
+                        s_cur[s0 + q] += hi_b - lo_b;
+                        if (s_cur[s0 + q] > cap) s_overflow = 1;
+                    }
+                    for (uint32_t k = threadIdx.x; k < total; k += L2S_NT) {
                         const uint32_t tp = s_tpos[k];
                         if (tp == 0xffffffffu) continue;  // beyond the region: the fold's result will not be used
                         const uint4 a = s_xyzi[k];
@@ -957,7 +979,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
                 __syncthreads();
             }
         }
-        for (uint32_t sp = threadIdx.x; sp < f2; sp += L2_NT) {
+        for (uint32_t sp = threadIdx.x; sp < f2; sp += L2S_NT) {
             const uint32_t n = s_cur[sp];
             P.off2[bin * f2 + sp] = (uint32_t)(region0 + (uint64_t)sp * cap);
             P.cnt2[bin * f2 + sp] = n < cap ? n : cap;
@@ -968,7 +990,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2(Level2Params P) {
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
             const uint64_t base = P.obase[q];
             const uint32_t n = P.ocount[q];
-            for (uint32_t i = threadIdx.x; i < n; i += L2_NT) {
+            for (uint32_t i = threadIdx.x; i < n; i += L2S_NT) {
                 const uint64_t key = P.okeys[base + i];
                 const uint32_t pos = atomicAdd(&s_ocur[sub_of(cell_hash(key), f2)], 1u);
                 P.okeys2[pos] = key;
@@ -1909,29 +1931,35 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         gs->pending_cap += cols.n;
 
         uint64_t nblocks = (cols.n + P0_TILE - 1) / P0_TILE;
-        uint64_t maxb = (uint64_t)ctx->num_cus * 2;  // two workgroups per CU are resident (LDS); each owns one piece of every bin
+        uint64_t maxb = (uint64_t)ctx->num_cus;  // one scatter workgroup per CU is resident (LDS); each owns one piece of every bin
+#ifdef PCQ_LAB
+        if (ctx->grid_variant & (512 | 1024)) maxb = (uint64_t)ctx->num_cus * 2;  // the 2560-point tile shapes: two per CU
+#endif
         if (maxb > P0_MAX_BLOCKS) maxb = P0_MAX_BLOCKS;
         if (nblocks > maxb) nblocks = maxb;
         uint64_t per_block = (cols.n + nblocks - 1) / nblocks;
-        per_block = (per_block + P0_TILE - 1) / P0_TILE * P0_TILE;
+        const uint64_t tile_round = SC_NT * SC_ITEMS;  // whole tiles of the scatter (= two of the histogram pass)
+        per_block = (per_block + tile_round - 1) / tile_round * tile_round;
         nblocks = (cols.n + per_block - 1) / per_block;
         uint32_t *cnt = ctx->d_grid_cnt, *total = ctx->d_grid_cnt + (size_t)P0_MAX_BLOCKS * F1;
         const DevGrid &g = c->grid;
-        const dim3 gb((unsigned)nblocks), tb(P0_NT);
-        if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_p0_hist<PCQ_PRED_BOUNDS>, gb, tb, 0, s, cols, pred, g, per_block, cnt);
-        else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_p0_hist<PCQ_PRED_CLASS>, gb, tb, 0, s, cols, pred, g, per_block, cnt);
-        else hipLaunchKernelGGL(k_p0_hist<PCQ_PRED_BOUNDS_F64>, gb, tb, 0, s, cols, pred, g, per_block, cnt);
+        const dim3 gb((unsigned)nblocks), tb(SC_NT);  // the same workgroups (ranges of points) in the histogram pass and the scatter
+        if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL((k_p0_hist<PCQ_PRED_BOUNDS, SC_NT>), gb, tb, 0, s, cols, pred, g, per_block, cnt);
+        else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL((k_p0_hist<PCQ_PRED_CLASS, SC_NT>), gb, tb, 0, s, cols, pred, g, per_block, cnt);
+        else hipLaunchKernelGGL((k_p0_hist<PCQ_PRED_BOUNDS_F64, SC_NT>), gb, tb, 0, s, cols, pred, g, per_block, cnt);
         hipLaunchKernelGGL(k_p0_scan_blocks, dim3(F1 / WAVES), dim3(BLOCK), 0, s, cnt, (int)nblocks, total);
         hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, total, run.binoff, (uint32_t)F1);
-#define PCQ_P0_SCATTER(KIND, STREAM) \
-    hipLaunchKernelGGL((k_p0_scatter<KIND, STREAM>), gb, tb, 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base)
+#define PCQ_P0_SCATTER(KIND, STREAM, NT, ITEMS) \
+    hipLaunchKernelGGL((k_p0_scatter<KIND, STREAM, NT, ITEMS>), gb, dim3(NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base)
 #ifdef PCQ_LAB
-        if ((ctx->grid_variant & 32) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, false);  // plain loads of the positions
+        if ((ctx->grid_variant & 32) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, false, SC_NT, SC_ITEMS);  // plain loads of the positions
+        else if ((ctx->grid_variant & 512) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, true, 256, 10);  // 2560-point tiles on 256 threads
+        else if ((ctx->grid_variant & 1024) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, true, 512, 5);  // 2560-point tiles on 512 threads
         else
 #endif
-        if (pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, true);
-        else if (pred.kind == PCQ_PRED_CLASS) PCQ_P0_SCATTER(PCQ_PRED_CLASS, true);
-        else PCQ_P0_SCATTER(PCQ_PRED_BOUNDS_F64, true);
+        if (pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, true, SC_NT, SC_ITEMS);
+        else if (pred.kind == PCQ_PRED_CLASS) PCQ_P0_SCATTER(PCQ_PRED_CLASS, true, SC_NT, SC_ITEMS);
+        else PCQ_P0_SCATTER(PCQ_PRED_BOUNDS_F64, true, SC_NT, SC_ITEMS);
 #undef PCQ_P0_SCATTER
         PCQ_HIP(hipGetLastError());
         gs->runs.push_back(run);
@@ -2063,7 +2091,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 L.obinbase = d_obinbase, L.okeys2 = d_okeys2, L.orecs2 = d_orecs2, L.ooff2 = d_ooff2;
             }
             PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
-            if (staged) hipLaunchKernelGGL(k_level2, dim3(F1), dim3(L2_NT), 0, s, L);
+            if (staged) hipLaunchKernelGGL(k_level2, dim3(F1), dim3(L2S_NT), 0, s, L);
             else hipLaunchKernelGGL(k_level2_direct, dim3(F1), dim3(L2_NT), 0, s, L);
             PCQ_HIP(hipGetLastError());
             if (f2 > 1) {
