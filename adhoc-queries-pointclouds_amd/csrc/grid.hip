@@ -1070,7 +1070,7 @@ __device__ __forceinline__ int lds_find_or_insert(uint64_t *s_key, uint64_t key,
 // SMALL (XPART) keeps the next PARTITION's first chunk in flight and loads further chunks of a partition (rare: a partition
 // is about one chunk) on demand.  BIG loads chunk by chunk: with 16 waves on the CU a register prefetch of the next chunk
 // measured no faster and spilled.
-template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool PAY_LDS, bool XPART, bool DIRECT, bool CPF, int MIN_WAVES>
+template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool PAY_LDS, bool XPART, bool DIRECT, bool CPF, bool LOCKED, int MIN_WAVES>
 __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t nparts) {
     constexpr int SPT = (NSLOT + NT - 1) / NT;   // slots per thread in the compaction
     constexpr int CHUNK = NT * FOLD_K;
@@ -1079,9 +1079,13 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
     __shared__ uint64_t s_ord[NSLOT];    // file order of the winner: 0 = an earlier fold's winner, ~0 = none yet
     __shared__ uint32_t s_pay_lds[PAY_LDS ? NSLOT * 5 : 1];  // winner's x, y, z, w0, w1 — or, for an earlier winner, its index (two words)
     __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32], s_oldbits[(NSLOT + 31) / 32];
+    __shared__ uint32_t s_lock[LOCKED ? (NSLOT + 31) / 32 : 1];  // LOCKED: one bit per slot, held while a tuple replaces the slot's winner
     __shared__ uint32_t s_ncell, s_over, s_wsum[NT / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const GridSeg sg0 = P.seg0;
+    if (LOCKED) {
+        for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_lock[t] = 0;  // (every holder releases: cleared once)
+    }
 
     // pipeline state: the first segment's range and the output base of the current and the next partition,
     // and the first chunk of the current partition's tuples
@@ -1292,13 +1296,54 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                         if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
                         // most tuples of a coarse grid cannot lower the minimum: a plain read first (a stale value is only too large)
                         const uint64_t seen = __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (ev.dbits < seen) {
+                        if (LOCKED) {
+                            // No phases and no barriers between the chunks: a tuple that can still win (at or below the minimum
+                            // it sees) takes the slot's lock bit, compares (distance, file order) with what the slot holds and,
+                            // if it is earlier, becomes the slot's winner — payload included — before it lets go.  The 64 lanes
+                            // of a wave retry together; whoever gets a bit finishes and releases it in the same round, so lanes
+                            // (and waves) that want the same slot pass one after the other.
+                            const uint64_t ord = ord_of(tu[k]);
+                            const uint32_t bit = 1u << (s & 31);
+                            bool pending = ev.dbits <= seen;
+                            // The loop condition is the same for the whole wave (a vote), and the holder releases inside the
+                            // round it acquired in: a loop that each lane leaves on its own can be compiled into "spin until
+                            // acquired, then the critical section behind the loop", which never ends when two lanes of one wave
+                            // want the same slot.  A bound on the rounds turns anything unforeseen into an error, not a hang.
+                            for (uint32_t round = 0; __any(pending); round++) {
+                                bool got = false;
+                                if (pending) {
+                                    const uint32_t held = __hip_atomic_fetch_or(&s_lock[s >> 5], bit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    got = !(held & bit);
+                                }
+                                if (got) {
+                                    const uint64_t cd = __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    const uint64_t co = __hip_atomic_load(&s_ord[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    if (ev.dbits < cd || (ev.dbits == cd && ord < co)) {
+                                        __hip_atomic_store(&s_dist[s], ev.dbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        __hip_atomic_store(&s_ord[s], ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                        pay[s * 5] = (uint32_t)tu[k].x, pay[s * 5 + 1] = (uint32_t)tu[k].y, pay[s * 5 + 2] = (uint32_t)tu[k].z;
+                                        pay[s * 5 + 3] = tu[k].w0, pay[s * 5 + 4] = tu[k].w1;
+                                        atomicAnd(&s_oldbits[s >> 5], ~bit);
+                                        // (payload parked in HBM: the next holder's stores must land after these — acknowledged first)
+                                        if (!PAY_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                    }
+                                    __hip_atomic_fetch_and(&s_lock[s >> 5], ~bit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    pending = false;
+                                }
+                                if (round > (1u << 24)) {  // (a holder's critical section is microseconds)
+                                    if (pending) atomicAdd(&P.stats[6], 1ull);
+                                    pending = false;
+                                }
+                            }
+                            slot[k] = -1;
+                        } else if (ev.dbits < seen) {
                             const uint64_t old = atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
                             if (ev.dbits < old) s_ord[s] = ~0ull;  // a new minimum: whoever held the cell is out (racing writers store the same value)
                         } else if (ev.dbits > seen) {
                             slot[k] = -1;  // the minimum only falls: this tuple is out of phases 2 and 3 (nearly all of a coarse grid's are)
                         }
                     }
+                    if (LOCKED) continue;  // (everything happened under the locks)
                     __syncthreads();
                     // phase 2: among the tuples at the minimum, the earliest in file order
 #pragma unroll
@@ -2170,17 +2215,18 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, false, 6>), dim3(resident), dim3(DENSE_NT), 0, s, D, nparts);
             }
 #ifdef PCQ_LAB
-            if (big && (ctx->grid_variant & 128)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, 3, BIG_LIMIT, false, false, false, true, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
-            else if (big && (ctx->grid_variant & 256)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, true, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
+            if (big && (ctx->grid_variant & 128)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);  // phases + barriers
+            else if (big && (ctx->grid_variant & 256)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, true, true, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);  // locks + chunk prefetch
             else
 #endif
-            if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
-            else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, false, true, false, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
+            if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, false, true, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
+            else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, false, true, false, false, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
         }
         PCQ_HIP(hipGetLastError());
-        unsigned long long st[4] = {0, 0, 0, 0};
+        unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         PCQ_HIP(hipMemcpyAsync(st, d_stats, sizeof st, hipMemcpyDeviceToHost, s));
         PCQ_HIP(hipStreamSynchronize(s));
+        if (st[6]) return pcq_fail(PCQ_ERR_HIP, "grid fold: a slot lock was not released (internal error)");
         if (st[1]) {  // a partition held more cells than the LDS table: more partitions
             if (f2 >= F2_MAX || attempt > 8) return pcq_fail(PCQ_ERR_UNSUPPORTED, "grid collector: a partition does not fit the LDS table at the largest fan-out");
             ctx->grid_refolds++;

@@ -4,7 +4,7 @@
 TAG=${1:-grid}
 O=$GRAFT_REPO_ROOT/gpurun_out/r02; mkdir -p $O
 cd $GRAFT_REPO_ROOT
-timeout -k 10 420 python -m pytest tests/test_gpu_scan.py tests/test_gpu_host.py -m gpu -x -q -k "grid or golden or density or alias" > $O/${TAG}_tests.log 2>&1
+timeout -k 10 240 python -m pytest tests/test_gpu_scan.py tests/test_gpu_host.py -m gpu -x -q -k "grid or golden or density or alias" > $O/${TAG}_tests.log 2>&1
 rc=$?; tail -3 $O/${TAG}_tests.log
 [ $rc -ne 0 ] && exit $rc
 cd /tmp && export TMPDIR=/tmp
