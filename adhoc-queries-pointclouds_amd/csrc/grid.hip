@@ -1069,14 +1069,11 @@ __device__ __forceinline__ int lds_find_or_insert(uint64_t *s_key, uint64_t key,
     return -1;
 }
 
-// Workgroups are persistent: each folds the partitions blockIdx.x, blockIdx.x + gridDim.x, ...  A small partition is a
-// chain of dependent round trips (its offsets, then its tuples, then the fold, then the stores), so the loop is
-// software-pipelined: the offsets of the partition after the next and the first chunk of tuples of the next one are
-// loaded while the current one is folded.
-// SMALL (XPART) keeps the next PARTITION's first chunk in flight and loads further chunks of a partition (rare: a partition
-// is about one chunk) on demand.  BIG loads chunk by chunk: with 16 waves on the CU a register prefetch of the next chunk
-// measured no faster and spilled.
-template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool PAY_LDS, bool XPART, bool DIRECT, bool CPF, bool LOCKED, int MIN_WAVES>
+// Workgroups are persistent: each folds the partitions blockIdx.x, blockIdx.x + gridDim.x, ... (or the partitions
+// k_fold_dense left on its list); the offsets of the next partition are loaded while the current one is folded.  Tuples are
+// loaded chunk by chunk: a register prefetch of the next chunk (CPF, lab) measured 1.72 -> 1.68 ms for the big shape at the
+// price of 40 spilled registers, and LOCKED (lab) is the big fold with a lock bit per slot instead of the phases.
+template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool PAY_LDS, bool DIRECT, bool CPF, bool LOCKED, int MIN_WAVES>
 __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t nparts) {
     constexpr int SPT = (NSLOT + NT - 1) / NT;   // slots per thread in the compaction
     constexpr int CHUNK = NT * FOLD_K;
@@ -1097,8 +1094,6 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
     // and the first chunk of the current partition's tuples
     uint32_t cur_lo = 0, cur_cnt = 0, nxt_lo = 0, nxt_cnt = 0;
     uint64_t cur_out = 0, nxt_out = 0;
-    GridTuple first[XPART ? FOLD_K : 1];
-    bool have_first = false;  // first[] holds the first chunk of the current partition (prefetched by the direct path)
     if (P.defer_list) nparts = (uint32_t)P.stats[3];  // only what k_fold_dense left
     uint32_t it = blockIdx.x, p = 0, p_next = 0;
     if (it < nparts) {
@@ -1155,15 +1150,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
             GridTuple tu[FOLD_K];
             uint64_t dbits[FOLD_K];
             int slot[FOLD_K];
-            if (XPART && have_first) {
 #pragma unroll
-                for (int k = 0; k < FOLD_K; k++) tu[k] = first[XPART ? k : 0];
-            } else {
-#pragma unroll
-                for (int k = 0; k < FOLD_K; k++) {
-                    const uint32_t i = k * NT + threadIdx.x;
-                    tu[k] = ld_tuple(sg0.tuples + cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0)));
-                }
+            for (int k = 0; k < FOLD_K; k++) {
+                const uint32_t i = k * NT + threadIdx.x;
+                tu[k] = ld_tuple(sg0.tuples + cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0)));
             }
 #pragma unroll
             for (int k = 0; k < FOLD_K; k++) {  // phase 1: cells and their minimum distance
@@ -1181,14 +1171,6 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                 if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
                 if (ev.dbits < __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
                     atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
-            }
-            have_first = XPART && pn < nparts;
-            if (have_first) {  // the next partition's tuples are on their way while this one is finished
-#pragma unroll
-                for (int k = 0; k < FOLD_K; k++) {
-                    const uint32_t i = k * NT + threadIdx.x;
-                    first[XPART ? k : 0] = ld_tuple(sg0.tuples + nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0)));
-                }
             }
             __syncthreads();
 #pragma unroll
@@ -1275,9 +1257,6 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                                 tn[CPF ? k : 0] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
                             }
                         }
-                    } else if (XPART && r == 0 && c0 == 0 && have_first) {
-#pragma unroll
-                        for (int k = 0; k < FOLD_K; k++) tu[k] = first[XPART ? k : 0];
                     } else {
 #pragma unroll
                         for (int k = 0; k < FOLD_K; k++) {
@@ -1373,7 +1352,6 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                     // about to be replaced, and every thread passes the barrier behind it before anyone parks again
                 }
             }
-            have_first = false;  // the generic path does not prefetch
             if (!PAY_LDS) __threadfence();  // the parked payloads are read back by other threads of the workgroup
             __syncthreads();
             if (s_over) {  // more cells than the table holds: the host repeats the fold with more partitions
@@ -2226,12 +2204,12 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
             // the big fold with a lock bit per slot instead of the three phases per chunk: 1.58 vs 1.75 ms on the uniform synthetic
             // file — not shipped: every tuple that improves a cell parks its payload under the lock with a store round trip, so a
             // file sorted towards a cell centre (one coarse cell, points along a drive) serialises on one slot
-            if (big && (ctx->grid_variant & 128)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, false, true, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
-            else if (big && (ctx->grid_variant & 256)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, true, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);  // phases + chunk prefetch
+            if (big && (ctx->grid_variant & 128)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, true, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
+            else if (big && (ctx->grid_variant & 256)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, true, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);  // phases + chunk prefetch
             else
 #endif
-            if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
-            else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, false, true, false, false, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
+            if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
+            else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, true, false, false, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
         }
         PCQ_HIP(hipGetLastError());
         unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
