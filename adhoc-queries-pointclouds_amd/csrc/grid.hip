@@ -495,7 +495,7 @@ __global__ __launch_bounds__(1024) void k_excl_scan_u64(const uint64_t *__restri
 // a bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.  A tuple is staged (and stored) as
 // 16 + 8 bytes; next to it sits its bin, which gives the tuple's place in the run (the tile's first place in the bin + the
 // tuple's place in the sorted image).
-template <int KIND, bool STREAM, int NT, int ITEMS, bool NTS = false>
+template <int KIND, bool STREAM, int NT, int ITEMS, int NTS = 0>
 __global__ __launch_bounds__(NT, NT == 512 ? 4 : (NT == 1024 ? 4 : 2)) void k_p0_scatter(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
                                                       const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out,
                                                       uint32_t entry, uint64_t idx_base) {
@@ -615,10 +615,16 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (NT == 1024 ? 4 : 2)) void k_p0
         for (uint32_t t = threadIdx.x; t < total; t += NT) {
             const uint4 a = s_xyzi[t];
             const uint2 b = s_attr[t];
-            const uint32_t pos = s_delta[s_bin[t]] + t;
+            uint32_t pos = s_delta[s_bin[t]] + t;
+            if (NTS == 2) pos = (uint32_t)(base + t);  // (lab, WRONG results: the tile leaves in one piece — what do the scattered runs cost?)
+            if (NTS == 3) {  // (lab, WRONG results: groups of 16 tuples = three whole 128-byte lines, each group at a random place)
+                uint32_t grp = (uint32_t)((base + t) >> 4) * 2654435761u;
+                grp ^= grp >> 15;
+                pos = (grp % (uint32_t)(c.n >> 4)) * 16u + (t & 15u);
+            }
             uint8_t *q = reinterpret_cast<uint8_t *>(out) + (uint64_t)pos * sizeof(GridTuple);
             u32x4_a8 va = {a.x, a.y, a.z, a.w};
-            if (NTS) {  // (lab: streaming stores)
+            if (NTS == 1) {  // (lab: streaming stores)
                 u32x2 vb = {b.x, b.y};
                 __builtin_nontemporal_store(va, reinterpret_cast<u32x4_a8 *>(q));
                 __builtin_nontemporal_store(vb, reinterpret_cast<u32x2 *>(q + 16));
@@ -1983,7 +1989,11 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
 #ifdef PCQ_LAB
         if ((ctx->grid_variant & 32) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, false, SC_NT, SC_ITEMS);  // plain loads of the positions
         else if ((ctx->grid_variant & 2048) && pred.kind == PCQ_PRED_BOUNDS)  // streaming stores of the tuples
-            hipLaunchKernelGGL((k_p0_scatter<PCQ_PRED_BOUNDS, true, SC_NT, SC_ITEMS, true>), gb, dim3(SC_NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
+            hipLaunchKernelGGL((k_p0_scatter<PCQ_PRED_BOUNDS, true, SC_NT, SC_ITEMS, 1>), gb, dim3(SC_NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
+        else if ((ctx->grid_variant & 8192) && pred.kind == PCQ_PRED_BOUNDS)  // WRONG results: whole lines at random places (timing experiment only)
+            hipLaunchKernelGGL((k_p0_scatter<PCQ_PRED_BOUNDS, true, SC_NT, SC_ITEMS, 3>), gb, dim3(SC_NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
+        else if ((ctx->grid_variant & 4096) && pred.kind == PCQ_PRED_BOUNDS)  // WRONG results: tiles written in one piece (timing experiment only)
+            hipLaunchKernelGGL((k_p0_scatter<PCQ_PRED_BOUNDS, true, SC_NT, SC_ITEMS, 2>), gb, dim3(SC_NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
         else if ((ctx->grid_variant & 512) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, true, 256, 10);  // 2560-point tiles on 256 threads
         else if ((ctx->grid_variant & 1024) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, true, 512, 5);  // 2560-point tiles on 512 threads
         else
