@@ -637,6 +637,162 @@ __global__ __launch_bounds__(NT, NT == 512 ? 4 : (NT == 1024 ? 4 : 2)) void k_p0
     }
 }
 
+#ifdef PCQ_LAB
+// (lab) The scatter with whole-line stores: per bin a carry of up to 15 eight-byte words stays in LDS across the tiles, so
+// that every store to a bin's piece is a whole, aligned 128-byte line (except the piece's first and last) — the runs of the
+// shipped kernel reach the L2 as partial lines that the next tile has to complete (profiles/r02_grid_progress.txt).
+// A tuple is three words; the stream of a (workgroup, bin) piece is carry words followed by the tile's new tuples.
+constexpr int SL_NT = 1024, SL_ITEMS = 3, SL_TILE = SL_NT * SL_ITEMS;  // 72 KB of staged words + 64 KB of carries
+constexpr int SL_MAXLINES = (SL_TILE * 3 + 15 * F1) / 16 + 1;
+template <int KIND>
+__global__ __launch_bounds__(SL_NT, 4) void k_p0_scatter_lines(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
+                                                               const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out, uint32_t entry,
+                                                               uint64_t idx_base) {
+    __shared__ uint2 s_words[SL_TILE * 3];   // the tile's tuples, sorted by bin, as 8-byte words
+    __shared__ uint2 s_carry[F1 * 16];       // per bin: words not yet written (the bin's global cursor is line-aligned in front of them)
+    __shared__ uint4 s_info[F1];             // per bin and tile: {first line among the tile's lines, stage word index - word index,
+                                             //                    global line - tile line, carry words | phantom words << 8}
+    __shared__ uint32_t s_gline[F1], s_cw[F1], s_skip[F1];  // per bin: global line of the carry's first word, carry words (incl. phantom), phantom words
+    __shared__ uint32_t s_cnt[F1], s_base[F1], s_v[F1];
+    __shared__ uint16_t s_linebin[SL_MAXLINES];
+    __shared__ unsigned long long s_wsum[SL_NT / 64];
+    __shared__ uint32_t s_total_lines;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint2 *out_words = reinterpret_cast<uint2 *>(out);
+    for (int t = threadIdx.x; t < F1; t += SL_NT) {
+        const uint64_t w0 = 3ull * (binoff[t] + cnt_excl[(size_t)blockIdx.x * F1 + t]);  // the piece's first word
+        s_gline[t] = (uint32_t)(w0 >> 4);
+        s_cw[t] = s_skip[t] = (uint32_t)(w0 & 15);  // the words in front of the piece on its first line belong to the previous workgroup
+        s_cnt[t] = 0;
+    }
+    __syncthreads();
+    const uint64_t begin = (uint64_t)blockIdx.x * per_block;
+    const uint64_t end = begin + per_block < c.n ? begin + per_block : c.n;
+    P0In<KIND> cur[SL_ITEMS], nxt[SL_ITEMS];
+#pragma unroll
+    for (int j = 0; j < SL_ITEMS; j++) {
+        const uint64_t i = begin + (uint64_t)j * SL_NT + threadIdx.x;
+        cur[j] = p0_load<KIND, true>(c, i < end ? i : end - 1);
+    }
+#pragma unroll
+    for (int j = 0; j < SL_ITEMS; j++) {
+        if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
+        else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
+    }
+    for (uint64_t base = begin; base < end; base += SL_TILE) {
+        const uint64_t nbase = base + SL_TILE;
+        if (nbase < end) {
+#pragma unroll
+            for (int j = 0; j < SL_ITEMS; j++) {
+                const uint64_t i = nbase + (uint64_t)j * SL_NT + threadIdx.x;
+                nxt[j] = p0_load<KIND, true>(c, i < end ? i : end - 1);
+            }
+        }
+        bool passes[SL_ITEMS];
+        uint32_t bins[SL_ITEMS], ranks[SL_ITEMS], rg[SL_ITEMS], bb[SL_ITEMS], cl[SL_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * SL_NT + threadIdx.x;
+            passes[j] = i < end && p0_pass<KIND>(c, pr, cur[j]);
+            rg[j] = 0, bb[j] = 0, cl[j] = KIND == PCQ_PRED_CLASS ? cur[j].cls : 0;
+            if (!passes[j]) continue;
+            if (KIND == PCQ_PRED_CLASS) cur[j].rp = ld_xyz(c, i);
+            if (c.rgb) {
+                const uint8_t *q = c.rgb + i * c.rgb_stride;
+                rg[j] = ld_u16(q) | (ld_u16(q + 2) << 16);
+                bb[j] = ld_u16(q + 4);
+            }
+            if (KIND != PCQ_PRED_CLASS && c.cls) cl[j] = c.cls[i * c.cls_stride];
+        }
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; j++) {
+            if (!passes[j]) continue;
+            bins[j] = bin_of(point_hash<KIND>(c, g, cur[j].rp));
+            ranks[j] = atomicAdd(&s_cnt[bins[j]], 1u);
+        }
+        __syncthreads();
+        {  // per bin (thread t < 512): the tile's tuples and the lines its stream now fills; both prefix sums in one scan
+            const bool active = threadIdx.x < F1;
+            const uint32_t v = active ? s_cnt[threadIdx.x] : 0, cw = active ? s_cw[threadIdx.x] : 0;
+            const uint32_t tot = cw + 3 * v, nl = active ? tot >> 4 : 0;
+            const unsigned long long mine = ((unsigned long long)nl << 32) | v;
+            unsigned long long incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned long long up = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += up;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            unsigned long long before = incl - mine, total = 0;
+            for (int w = 0; w < SL_NT / 64; w++) {
+                before += w < wave ? s_wsum[w] : 0;
+                total += s_wsum[w];
+            }
+            if (active) {
+                const uint32_t tbase = (uint32_t)before, lstart = (uint32_t)(before >> 32);
+                s_base[threadIdx.x] = tbase;
+                s_v[threadIdx.x] = v;
+                s_info[threadIdx.x] = make_uint4(lstart, 3 * tbase - cw, s_gline[threadIdx.x] - lstart, cw | (s_skip[threadIdx.x] << 8));
+                for (uint32_t i = 0; i < nl; i++) s_linebin[lstart + i] = (uint16_t)threadIdx.x;
+                s_cnt[threadIdx.x] = 0;
+            }
+            if (threadIdx.x == 0) s_total_lines = (uint32_t)(total >> 32);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; j++) {
+            if (!passes[j]) continue;
+            const uint64_t i = base + (uint64_t)j * SL_NT + threadIdx.x;
+            const uint32_t at = 3 * (s_base[bins[j]] + ranks[j]);
+            s_words[at] = make_uint2((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y);
+            s_words[at + 1] = make_uint2((uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
+            s_words[at + 2] = make_uint2(cl[j] | (entry << 8) | (rg[j] << 16), (rg[j] >> 16) | (bb[j] << 16));
+        }
+#pragma unroll
+        for (int j = 0; j < SL_ITEMS; j++) {  // the next tile's inputs have arrived — before the stores below
+            cur[j] = nxt[j];
+            if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
+            else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
+        }
+        __syncthreads();
+        {  // the whole lines: 16 lanes per line, one word each
+            const uint32_t total_lines = s_total_lines, j = threadIdx.x & 15;
+            for (uint32_t L = threadIdx.x >> 4; L < total_lines; L += SL_NT / 16) {
+                const uint32_t bin = s_linebin[L];
+                const uint4 inf = s_info[bin];
+                const uint32_t li = L - inf.x, w = 16 * li + j, cw = inf.w & 0xff, skip = inf.w >> 8;
+                if (li == 0 && j < skip) continue;  // (the previous workgroup's words on the piece's first line)
+                const uint2 v = w < cw ? s_carry[bin * 16 + w] : s_words[inf.y + w];
+                out_words[(uint64_t)(inf.z + L) * 16 + j] = v;
+            }
+        }
+        __syncthreads();
+        {  // what is left of each stream becomes the bin's carry (two threads per bin)
+            const uint32_t bin = threadIdx.x >> 1, h = threadIdx.x & 1;
+            const uint32_t cw = s_cw[bin], tot = cw + 3 * s_v[bin], nl = tot >> 4, rem = tot & 15, off = s_info[bin].y;
+            if (nl) {
+                for (uint32_t i = h; i < rem; i += 2) s_carry[bin * 16 + i] = s_words[off + 16 * nl + i];
+            } else {
+                for (uint32_t i = cw + h; i < tot; i += 2) s_carry[bin * 16 + i] = s_words[off + i];
+            }
+            __syncthreads();  // (both halves of a pair have read s_cw)
+            if (h == 0) {
+                s_cw[bin] = rem;
+                s_gline[bin] += nl;
+                if (nl) s_skip[bin] = 0;
+            }
+        }
+        __syncthreads();
+    }
+    for (int t = threadIdx.x; t < F1; t += SL_NT) {  // the last, partial line of every piece
+        const uint32_t cw = s_cw[t], skip = s_skip[t];
+        for (uint32_t w = skip; w < cw; w++) out_words[(uint64_t)s_gline[t] * 16 + w] = s_carry[t * 16 + w];
+    }
+}
+
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // fold preparation
 // ---------------------------------------------------------------------------------------------------------------
@@ -1990,6 +2146,8 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         if ((ctx->grid_variant & 32) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, false, SC_NT, SC_ITEMS);  // plain loads of the positions
         else if ((ctx->grid_variant & 2048) && pred.kind == PCQ_PRED_BOUNDS)  // streaming stores of the tuples
             hipLaunchKernelGGL((k_p0_scatter<PCQ_PRED_BOUNDS, true, SC_NT, SC_ITEMS, 1>), gb, dim3(SC_NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
+        else if ((ctx->grid_variant & 16384) && pred.kind == PCQ_PRED_BOUNDS)  // whole-line stores with a carry per bin
+            hipLaunchKernelGGL(k_p0_scatter_lines<PCQ_PRED_BOUNDS>, gb, dim3(SL_NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
         else if ((ctx->grid_variant & 8192) && pred.kind == PCQ_PRED_BOUNDS)  // WRONG results: whole lines at random places (timing experiment only)
             hipLaunchKernelGGL((k_p0_scatter<PCQ_PRED_BOUNDS, true, SC_NT, SC_ITEMS, 3>), gb, dim3(SC_NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
         else if ((ctx->grid_variant & 4096) && pred.kind == PCQ_PRED_BOUNDS)  // WRONG results: tiles written in one piece (timing experiment only)
