@@ -51,7 +51,7 @@ constexpr int F1 = 1 << F1_BITS;       // level-1 bins: the top F1_BITS bits of 
 constexpr int F2_MAX = 4096;           // largest second-level fan-out
 constexpr int P0_NT = 512;             // pass 0: threads per workgroup
 constexpr int P0_ITEMS = 5;            // pass 0: points per thread and tile
-constexpr int P0_TILE = P0_NT * P0_ITEMS;  // 2560 points: their tuples (60 KB) and bins (5 KB) are staged in LDS, two workgroups per CU
+constexpr int P0_TILE = P0_NT * P0_ITEMS;  // 2560 points: the granule of a workgroup's range (and the lab shapes' tile)
 constexpr int SC_NT = 1024, SC_ITEMS = 5;  // k_p0_scatter: one workgroup per CU sorts tiles of 5120 points in 141 KB of LDS — a bin's run
                                        // out of a tile is 10 tuples (240 bytes) instead of 5: 2.50 -> 2.19 ms against two 512-thread
                                        // workgroups with 2560-point tiles, same process (256 threads x 10 points on that tile: no change)
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(1024) void k_excl_scan_u64(const uint64_t *__restri
 }
 
 // The second reading of the scan: every match becomes a tuple at binoff[bin] + (workgroup's offset in the bin) + rank.
-// Per tile of 2560 points: the matches take a rank in their bin (LDS atomics), the tile's tuples are laid out in LDS
+// Per tile (NT x ITEMS points; 5120 as shipped): the matches take a rank in their bin (LDS atomics), the tile's tuples are laid out in LDS
 // sorted by bin, and the sorted image is copied out one tuple per lane — consecutive lanes write consecutive tuples of
 // a bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.  A tuple is staged (and stored) as
 // 16 + 8 bytes; next to it sits its bin, which gives the tuple's place in the run (the tile's first place in the bin + the
