@@ -373,7 +373,9 @@ def test_grid_second_level_regions_outgrown_by_hot_cells(oracle):
     with pkg.Context(0) as ctx:
         f = DevFile(ctx, image, hdr)
         try:
-            for forced, outgrown in ((4, True), (0, False)):  # 2048 partitions of ~200 tuples: the hot cell does not fit; no second level at all
+            # 2048 partitions of ~200 tuples: the hot cell does not fit · no second level at all · more sub-partitions per bin than
+            # the one-pass form handles (1024): the counting form from the start
+            for forced, outgrown in ((4, True), (0, False), (1500, False)):
                 ctx.set_option("grid_f2", forced)
                 before = ctx.get_option("grid_level2_exact")
                 gg = ctx.grid_collector(bmin, bmax, cell)
