@@ -201,6 +201,10 @@ int pcq_pool_alloc(pcq_ctx *ctx, size_t bytes, void **out) {
         return pcq_fail(PCQ_ERR_NOMEM, "device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
     }
     ctx->pool.push_back(PoolBlock{p, bytes, true});
+    if (bytes >= (64u << 20)) {
+        static const bool timing = getenv("PCQ_TIMING") && getenv("PCQ_TIMING")[0] == '1';
+        if (timing) fprintf(stderr, "pcq: pool block %p (%zu MiB, address mod 2 MiB = %zu KiB)\n", p, bytes >> 20, ((size_t)p & ((2u << 20) - 1)) >> 10);
+    }
     *out = p;
     return PCQ_OK;
 }

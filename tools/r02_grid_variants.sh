@@ -1,5 +1,5 @@
 #!/bin/bash
-# Lab: the grid probe at one cell size cycling through GRID_VARIANT shapes in ONE process (same buffers: run-to-run placement
+# Lab: the grid probe at one cell size cycling through GRID_VARIANT shapes in ONE process (same box, same buffers: box-to-box spread
 # moves the partition kernels by +-15 %), kernel stats by kernel name.
 # usage (on the GPU box): bash tools/r02_grid_variants.sh CELL "V,V,..." REPEATS TAG
 CELL=${1:-10}; VARS=${2:-"0,1,2,3"}; REP=${3:-12}; TAG=${4:-var}

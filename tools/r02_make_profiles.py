@@ -19,7 +19,7 @@ def kstats(path, lim_us=1.0):
 L = ["# round 2 (final state, git %s): grid collector per kernel, one synthetic ca13 file of 163 M points resident in HBM, query ca13_XL, 4 repeats each" % head,
      "# (tools/grid_probe.py under rocprofv3 --kernel-trace --stats; tools/r02_measure_b.sh).  scan = pass 0 (k_p0_hist, two small scans,",
      "# k_p0_scatter), asynchronous; count = the fold that the first accessor triggers (probe, [k_level2,] k_fold / k_fold_dense, directory kernels).",
-     "# The partition kernels move by +-15 % from process to process on the same code (placement of the buffers): see r02_grid_progress.txt.", ""]
+     "# The partition kernels move by +-15 % from GPU box to GPU box on the same code: see r02_grid_progress.txt.", ""]
 for cell in (100, 10):
     L.append(f"== ca13_XL --density {cell} ==")
     L += ["  " + l.strip() for l in open(f"{O}/grid_probe_{cell}.log") if "cells" in l]
