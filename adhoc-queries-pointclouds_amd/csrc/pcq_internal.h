@@ -171,7 +171,7 @@ struct pcq_ctx {
     int class_batch_loads = 4;
     int class_batch_waves_per_cu = 4;
     int class_batch_pipe = 1;
-    int grid_variant = 0;         // bit 0: second level without the tile prefetch · bit 1: second level reads tuples as three 8-byte words
+    int grid_variant = 0;         // experimental shapes of the grid collector's kernels, one bit each: include/pcq_lab.h
 #endif
     int numa_node = -1;               // NUMA node the GPU hangs off (sysfs), -1 if unknown
     cpu_set_t node_cpus;              // its CPUs (empty if unknown)
