@@ -170,6 +170,7 @@ def load_library() -> C.CDLL:
         "pcq_collector_grid_cells": (C.c_int, [vp, vp, u64, P(u64)]),
         "pcq_collector_grid_params": (C.c_int, [vp, P(u64), P(u64)]),
         "pcq_collector_reset": (C.c_int, [vp]),
+        "pcq_collector_flush": (C.c_int, [vp]),
         "pcq_scan_dev": (C.c_int, [vp, P(Columns), P(Predicate), vp, vp]),
         "pcq_scan_host": (C.c_int, [vp, P(Columns), P(Predicate), vp]),
         "pcq_scan_fd": (C.c_int, [vp, C.c_int, P(Columns), P(Predicate), vp]),
@@ -286,6 +287,9 @@ class Collector:
 
     def reset(self) -> None:
         _check(self.ctx.lib.pcq_collector_reset(self.handle))
+
+    def flush(self) -> None:
+        _check(self.ctx.lib.pcq_collector_flush(self.handle))
 
     def free(self) -> None:
         if self.handle:

@@ -6,26 +6,34 @@
 // same unmasked cell (always, except the mask-aliasing case below) that fold is the lexicographic arg-min of
 // (squared distance, file-order index).
 //
-// A hash table in HBM costs one random 128-byte line per matched point (round 1: 29 ms per 163 M-point file at 10 m,
-// ~40 x the algorithmic bytes).  Here the random access happens in LDS instead:
-//   pass 0  (per scan, asynchronous)  a counting-sort partition of the matched points by the high bits of hash(key)
-//           into F1 = 512 bins: k_p0_hist counts per (workgroup, bin), two small scan kernels turn the counts into
-//           exact offsets, and k_p0_scatter writes one 24-byte tuple {x, y, z, index, class | entry | colour} per
-//           match into its bin.  Every workgroup owns a private, contiguous piece of every bin — no global atomics, no
-//           slack, no overflow — and a tile's tuples are sorted by bin in LDS first, so that they leave as contiguous
-//           runs (scattered 24-byte stores were measured at 1.2 TB/s: profiles/r02_grid_first_cut_kernel_stats.txt).
-//   fold    (lazy: when a result is asked for, or when too much is pending)  one workgroup per partition folds its
-//           tuples into an open-addressing table in LDS — atomicMin on the f64 distance bits, then on the file-order
-//           index among the tuples at the minimum, then the winner parks its payload — and writes one 32-byte record
-//           + key per cell, coalesced.  A coarse grid folds its level-1 bins directly (k_fold<BIG>: a CU's whole LDS
-//           as one 6400-slot table); a denser grid first gets a second partition level (k_level2: one pass into
-//           fixed regions with slack, fan-out chosen from a measured estimate of the distinct cells per bin) and
-//           folds the small partitions three workgroups to a CU (k_fold_dense; k_fold<SMALL> for what that leaves:
-//           earlier winners, several segments, partitions longer than a chunk).
-// What the kernels had to learn about gfx950: every pass is bound by vector instructions before it is
-// bound by memory unless the cell arithmetic is cut down (cell_fast); loads and stores share one in-order counter, so a
-// prefetch must be waited for before the stores behind it are issued; pointers loaded from memory make flat loads,
-// which also hold every LDS wait.
+// A hash table in HBM costs one random 128-byte line per matched point (round 1: 29 ms per 163 M-point file at 10 m).
+// Here the random access happens in LDS, and what travels through HBM in between is written and read in order:
+//   pass 0  (per scan, asynchronous, ONE reading of the points)  k_p0_part: a tile of 5120 points becomes one
+//           BLOCK of tuples {x, y, z, index, class | entry [, colour]} (20 or 24 bytes), sorted in LDS by the level-1
+//           bin of the tuple's cell key (top 9 bits of hash(key)) and written to its own place — tile t's block is at
+//           t x 5120 tuples — as one sequential stream, next to a 513-entry directory row (where each bin starts in
+//           the block).  No histogram pass, no cursors, no atomics in global memory, nothing read back (round 2
+//           counted first — a second reading of the points — and scattered runs of 10 tuples to 131 072 cursors).
+//           Before the sort a tile FOLDS ITS OWN DUPLICATES: the tuples of one cell key inside a tile are
+//           consecutive in file order, so for a key without aliased tuples the fold's result cannot change when
+//           only the tile's (distance, file order) minimum travels on (proof at k_p0_part).  A scan-ordered file
+//           (flight lines: hundreds of consecutive points per coarse cell) sheds most of its tuples there; a file in
+//           random order sheds none, and a workgroup that sees that stops trying for a while.
+//   fold    (lazy: when a result is asked for, or when too much is pending)  the directory rows are transposed
+//           into per-bin fragment lists (k_dir_transpose, k_bin_prefix): bin b = the pieces [start, start + count)
+//           of every tile's block.  A reader keeps a window of that list in LDS and turns "tuples j .. j + chunk of
+//           bin b" into addresses by binary search, so the consumers still see dense chunks.  One workgroup per
+//           partition folds its tuples into an open-addressing table in LDS — atomicMin on the f64 distance bits, then
+//           on the file order among the tuples at the minimum, then the winner parks its payload — and writes one
+//           32-byte record + key per cell, coalesced.  A coarse grid folds its level-1 bins directly (k_fold<BIG>:
+//           a CU's whole LDS as one 6400-slot table); a denser grid first gets a second partition level (k_level2:
+//           one pass into fixed regions with slack, fan-out chosen from a measured estimate of the distinct cells per
+//           bin) and folds the small partitions three workgroups to a CU (k_fold_dense; k_fold<SMALL> for what that
+//           leaves: earlier winners, partitions longer than a chunk).
+// What the kernels had to learn about gfx950: every pass is bound by vector instructions before
+// it is bound by memory unless the cell arithmetic is cut down (cell_fast); loads and stores share one in-order
+// counter, so a prefetch must be waited for before the stores behind it are issued; pointers loaded from memory make
+// flat loads, which also hold every LDS wait.
 // The folded winners are kept grouped by partition, so a later fold (more scans into the same collector: sequential
 // mode shares one grid, main.rs:129-133; a file streamed in chunks) merges them with the new tuples partition by
 // partition: an old winner is earlier in file order than every new tuple and its distance is recomputed from its
@@ -49,13 +57,13 @@ namespace {
 constexpr int F1_BITS = 9;
 constexpr int F1 = 1 << F1_BITS;       // level-1 bins: the top F1_BITS bits of hash(key)
 constexpr int F2_MAX = 4096;           // largest second-level fan-out
-constexpr int P0_NT = 512;             // pass 0: threads per workgroup
-constexpr int P0_ITEMS = 5;            // pass 0: points per thread and tile
-constexpr int P0_TILE = P0_NT * P0_ITEMS;  // 2560 points: the granule of a workgroup's range (and the lab shapes' tile)
-constexpr int SC_NT = 1024, SC_ITEMS = 5;  // k_p0_scatter: one workgroup per CU sorts tiles of 5120 points in 141 KB of LDS — a bin's run
-                                       // out of a tile is 10 tuples (240 bytes) instead of 5: 2.50 -> 2.19 ms against two 512-thread
-                                       // workgroups with 2560-point tiles, same process (256 threads x 10 points on that tile: no change)
-constexpr int P0_MAX_BLOCKS = 1024;    // pass 0: at most this many workgroups (rows of the count table)
+constexpr int P0_NT = 1024, P0_ITEMS = 5;      // pass 0: one workgroup per CU sorts tiles of 5120 points in LDS
+constexpr int P0_TILE = P0_NT * P0_ITEMS;      // points per tile = tuples a tile's block has room for
+constexpr int DIR_STRIDE = 520;        // u16 per directory row: [b] = first place of bin b in the block, [512] = tuples in the block
+constexpr int DIR_WORDS = F1 / 2 + 1;  // the 513 entries as 32-bit words
+constexpr int AGG_SLOTS = 8192;        // pass 0: slots of the tile's duplicate table
+constexpr int AGG_POS_BITS = 13;       // a tuple's place in its tile (< 5120) in the low bits of a table word
+static_assert(P0_TILE <= (1 << AGG_POS_BITS) && P0_TILE <= 65535, "tile places fit the table word and the 16-bit directory");
 // The fold's shapes.  BIG: one 1024-thread workgroup owns a CU's whole LDS — 6400 slots of {key, distance, file order},
 // the winner's payload parked in HBM scratch — and folds a level-1 bin directly (coarse grids: few cells, many tuples
 // per cell).  SMALL / DENSE: 2048 slots, three workgroups per CU, a whole partition of the second level (about 1000
@@ -65,27 +73,33 @@ constexpr int P0_MAX_BLOCKS = 1024;    // pass 0: at most this many workgroups (
 constexpr int BIG_SLOTS = 6400, BIG_NT = 1024, BIG_LIMIT = 5440, BIG_DIRECT = 4700;
 constexpr int SMALL_SLOTS = 2048, SMALL_NT = 256, SMALL_K = 6, SMALL_LIMIT = 1740, SMALL_TARGET = 1000;
 constexpr int BIG_K = 4;               // fold: tuples per thread and chunk
+constexpr int BIG_FB = 512;            // big fold: fragments in the reader's window (what is left of the LDS)
 constexpr int DENSE_NT = 512, DENSE_K = 3;  // k_fold_dense: the same chunk (1536 tuples) on twice the waves
-constexpr int L2_NT = 512;             // second level: threads per workgroup (one workgroup per level-1 bin)
+constexpr int L2_NT = 512;             // exact second level: threads per workgroup (one workgroup per level-1 bin)
 constexpr int L2_UNROLL = 4;
-constexpr int L2S_NT = 1024, L2S_ITEMS = 4, L2S_TILE = L2S_NT * L2S_ITEMS;  // k_level2: one workgroup per CU, tiles of 4096 tuples (132 KB of LDS)
+constexpr int L2_FB = 1024;            // exact second level, alias gather: fragments in the reader's window
+constexpr int L2S_NT = 1024, L2S_ITEMS = 4, L2S_TILE = L2S_NT * L2S_ITEMS;  // k_level2: one workgroup per CU, tiles of 4096 tuples
+constexpr int L2S_FB = 2048;           // k_level2: fragments in the reader's window (about five tiles)
 constexpr int L2_STAGED_F2 = 1024;     // largest fan-out of the staged form (its per-tile tables live in LDS)
 constexpr int PROBE_BINS = 2;          // bins whose distinct cells are counted to estimate the grid's density
 constexpr uint64_t ALIAS_QUADRATIC = 8192;  // aliased tuples up to which the replay order comes from the quadratic rank kernel
 constexpr int MAX_RUNS = 1024;         // pending pass-0 runs per collector before a fold is forced
-constexpr uint64_t RUN_POINTS = 1ull << 30;  // points per pass-0 run (tuple offsets are 32-bit)
+constexpr uint64_t RUN_POINTS = 1ull << 30;  // points per pass-0 run
+constexpr uint64_t PENDING_MAX = (1ull << 32) - RUN_POINTS - 1;  // tuple counts and offsets of a fold are 32-bit
 
 constexpr uint8_t R_HAS = 1;    // byte 31 of a winner record: the record holds a point
 constexpr uint8_t R_ALIAS = 2;  // the key has seen a point whose unmasked cell differs from the masked one (sticky)
 
-// One matched point on its way to the fold.  `idx` is the file-order index relative to its entry's base index.
-struct __attribute__((aligned(8))) GridTuple {
+// One matched point on its way to the fold, as the kernels hold it.  `idx` is the file-order index relative to its
+// entry's base index.  In memory: 20 bytes {x, y, z, idx, w0}, or 24 with w1 when the scan had a colour column
+// (synthetic ca13 is format 1: no colour — a sixth less to move through every partition level).
+struct GridTuple {
     int32_t x, y, z;
     uint32_t idx;
     uint32_t w0;  // classification | entry << 8 | red << 16
     uint32_t w1;  // green | blue << 16
 };
-static_assert(sizeof(GridTuple) == 24, "tuple layout");
+__host__ __device__ __forceinline__ uint32_t tuple_bytes(bool wide) { return wide ? 24u : 20u; }
 
 // What turns a tuple's integers back into a position: the header scale / offset of the file it came from
 // (last.rs:156-160).  Consecutive scans with the same scale and offset share one entry.
@@ -93,16 +107,23 @@ struct GridEntryDev {
     double scale[3], offset[3];
 };
 
-// A list of tuples cut into partitions: partition p is tuples[off[p] .. off[p] + cnt[p]) — or, without cnt (pass 0's runs,
-// the exact second level: partitions back to back), tuples[off[p] .. off[p + 1]).
+// Tuples cut into partitions, back to back or in regions (the second level's output): partition p is the tuples
+// off[p] .. off[p] + cnt[p] — or, without cnt, .. off[p + 1] — of `tuples`, `wide` saying how long a tuple is.
 struct GridSeg {
-    const GridTuple *tuples;
+    const uint8_t *tuples;
     const uint32_t *off;
     const uint32_t *cnt;
+    uint32_t wide;
 };
-__device__ __forceinline__ uint32_t seg_count(const GridSeg &sg, uint32_t p, uint32_t lo) {
-    return sg.cnt ? *(const __attribute__((address_space(1))) uint32_t *)(sg.cnt + p) : *(const __attribute__((address_space(1))) uint32_t *)(sg.off + p + 1) - lo;
-}
+
+// Pass 0's output as the fold reads it: bin b = fragment t of every tile t (all pending runs, in scan order), fragment
+// (b, t) = startT[b][t] .. of tile t's block, preT[b][t] tuples of the bin in front of it.
+struct BinSrc {
+    const uint32_t *preT;       // [F1][Tp1]; preT[b][T] = the bin's tuples
+    const uint16_t *startT;     // [F1][Tp]
+    const uint64_t *tile_addr;  // [T] the block's address | 1 when its tuples are 24 bytes
+    uint32_t T, Tp1, Tp;
+};
 
 struct AliasItem {  // a tuple of an aliased key, for the exact replay (key at +0, order at +8: alias_sort.hip)
     uint64_t key, ord;
@@ -234,7 +255,8 @@ __device__ __forceinline__ uint32_t sub_of(uint64_t h, uint32_t f2) { return sub
 template <int NSLOT>
 __device__ __forceinline__ uint32_t slot_of(uint64_t h) { return (uint32_t)((((h >> 16) & 0x1fffffull) * NSLOT) >> 21); }
 
-// Pointers that a kernel reads out of a table in memory (GridSeg) are "generic" to the compiler: it emits flat loads, and
+
+// Pointers that a kernel reads out of a table in memory are "generic" to the compiler: it emits flat loads, and
 // a flat load counts on the LDS counter as well — every wait for an LDS operation (each barrier of the tile loops) would
 // then also wait for the tuples in flight.  Everything here lives in global memory; these say so.
 #define PCQ_GLOBAL __attribute__((address_space(1)))
@@ -242,21 +264,24 @@ template <typename T>
 __device__ __forceinline__ T ldg(const T *p) {
     return *(const PCQ_GLOBAL T *)p;
 }
-typedef uint32_t u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));  // a 16-byte access at an 8-byte aligned address
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ GridTuple ld_tuple(const GridTuple *p) {
-    const u32x4_a8 a = *(const PCQ_GLOBAL u32x4_a8 *)p;
-    const u32x2 c = *(const PCQ_GLOBAL u32x2 *)(reinterpret_cast<const uint8_t *>(p) + 16);
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte access at a 4-byte aligned address
+// (every tuple buffer ends in 64 spare bytes: the word behind a 20-byte tuple is always readable, so the second colour
+// word costs a select instead of a load in a branch of its own — see k_p0_part on loads in branches)
+__device__ __forceinline__ GridTuple ld_tuple(const uint8_t *p, bool wide) {
+    const u32x4_a4 a = *(const PCQ_GLOBAL u32x4_a4 *)p;
+    const uint32_t b = *(const PCQ_GLOBAL uint32_t *)(p + 16), c = *(const PCQ_GLOBAL uint32_t *)(p + 20);
     GridTuple t;
-    t.x = (int32_t)a.x, t.y = (int32_t)a.y, t.z = (int32_t)a.z, t.idx = a.w, t.w0 = c.x, t.w1 = c.y;
+    t.x = (int32_t)a.x, t.y = (int32_t)a.y, t.z = (int32_t)a.z, t.idx = a.w, t.w0 = b, t.w1 = wide ? c : 0u;
     return t;
 }
-__device__ __forceinline__ void st_tuple(GridTuple *p, const GridTuple &t) {
-    u32x4_a8 a = {(uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx};
-    *(PCQ_GLOBAL u32x4_a8 *)p = a;
-    u32x2 c = {t.w0, t.w1};
-    *(PCQ_GLOBAL u32x2 *)(reinterpret_cast<uint8_t *>(p) + 16) = c;
+__device__ __forceinline__ void st_tuple(uint8_t *p, const GridTuple &t, bool wide) {
+    u32x4_a4 a = {(uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx};
+    *(PCQ_GLOBAL u32x4_a4 *)p = a;
+    *(PCQ_GLOBAL uint32_t *)(p + 16) = t.w0;
+    if (wide) *(PCQ_GLOBAL uint32_t *)(p + 20) = t.w1;
 }
+__device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ __forceinline__ uint64_t uni64(uint64_t v) { return (uint64_t)uni32((uint32_t)v) | ((uint64_t)uni32((uint32_t)(v >> 32)) << 32); }
 
 // The entry table as the kernels see it: entry 0 (often the only one) travels in the kernel arguments, so that the
 // common case costs no dependent global load.
@@ -295,9 +320,9 @@ struct GridRef {
     DevGridFast f;
     const DevGrid *full;
 };
-__device__ __forceinline__ TupleEval eval_tuple(const GridRef &g, const EntryRef &entries, const GridTuple &t) {
-    const GridEntryDev e = entries.get((t.w0 >> 8) & 0xff);
-    const double px = world(t.x, e.scale[0], e.offset[0]), py = world(t.y, e.scale[1], e.offset[1]), pz = world(t.z, e.scale[2], e.offset[2]);
+// key, alias flag and distance bits of a world position: THE definition every pass uses (pass 0's duplicate fold must see
+// the bits the fold will see).
+__device__ __forceinline__ TupleEval eval_world(const GridRef &g, double px, double py, double pz) {
     const CellFast cf = cell_fast(g.f, px, py, pz);
     if (!cf.ok) return eval_exact(*g.full, px, py, pz);
     TupleEval r;
@@ -305,15 +330,18 @@ __device__ __forceinline__ TupleEval eval_tuple(const GridRef &g, const EntryRef
     r.dbits = (uint64_t)__double_as_longlong(centre_dist_fast(g.f, cf, px, py, pz));
     return r;
 }
-__device__ __forceinline__ TupleEval eval_tuple(const DevGrid &g, const EntryRef &entries, const GridTuple &t) {
-    const GridEntryDev e = entries.get((t.w0 >> 8) & 0xff);
-    const double px = world(t.x, e.scale[0], e.offset[0]), py = world(t.y, e.scale[1], e.offset[1]), pz = world(t.z, e.scale[2], e.offset[2]);
+__device__ __forceinline__ TupleEval eval_world(const DevGrid &g, double px, double py, double pz) {
     const CellFast cf = cell_fast(g, px, py, pz);
     if (!cf.ok) return eval_exact(g, px, py, pz);
     TupleEval r;
     r.key = key_fast(g, cf, &r.alias);
     r.dbits = (uint64_t)__double_as_longlong(centre_dist_fast(g, cf, px, py, pz));
     return r;
+}
+template <typename G>
+__device__ __forceinline__ TupleEval eval_tuple(const G &g, const EntryRef &entries, const GridTuple &t) {
+    const GridEntryDev e = entries.get((t.w0 >> 8) & 0xff);
+    return eval_world(g, world(t.x, e.scale[0], e.offset[0]), world(t.y, e.scale[1], e.offset[1]), world(t.z, e.scale[2], e.offset[2]));
 }
 // file order among tuples: entries are numbered in scan order; 0 is reserved for an earlier fold's winner
 __device__ __forceinline__ uint64_t ord_of(const GridTuple &t) { return ((uint64_t)((t.w0 >> 8) & 0xff) << 32 | t.idx) + 1; }
@@ -335,29 +363,80 @@ __device__ __forceinline__ void st_record(uint8_t *dst32, const GridEntryDev &e,
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// pass 0: counting-sort partition of the matched points of one scan
+// reading a bin of pass 0's output: a window of the bin's fragment list in LDS
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t key_exact(const DevGrid &g, double px, double py, double pz) { return cell_of(g, px, py, pz).key; }
-template <int KIND>
-__device__ __forceinline__ uint64_t point_hash(const DevCols &c, const DevGrid &g, const RawPoint &rp) {
-    const double px = world(rp.x, c.scale[0], c.offset[0]), py = world(rp.y, c.scale[1], c.offset[1]), pz = world(rp.z, c.scale[2], c.offset[2]);
-    const CellFast cf = cell_fast(g, px, py, pz);
-    if (!cf.ok) return cell_hash(key_exact(g, px, py, pz));
-    bool alias;
-    return cell_hash(key_fast(g, cf, &alias));
+// Window = fragments f_lo .. f_lo + nfr of bin `bin`: s_pre[0 .. nfr] (tuples of the bin in front of each, and behind the
+// last), s_addr[0 .. nfr) (address of the fragment's first tuple | 1 when its tuples are 24 bytes).
+__device__ __forceinline__ uint64_t frag_addr(const BinSrc &S, uint32_t bin, uint32_t f) {
+    const uint64_t ta = ldg(S.tile_addr + f);
+    const uint32_t st = ldg(S.startT + (size_t)bin * S.Tp + f);
+    return ((ta & ~1ull) + (uint64_t)st * tuple_bytes(ta & 1)) | (ta & 1);
+}
+template <int NT>
+__device__ __forceinline__ void frag_window_fill(const BinSrc &S, uint32_t bin, uint32_t f_lo, uint32_t nfr, uint32_t *s_pre, uint64_t *s_addr) {
+    for (uint32_t t = threadIdx.x; t <= nfr; t += NT) {
+        s_pre[t] = ldg(S.preT + (size_t)bin * S.Tp1 + f_lo + t);
+        if (t < nfr) s_addr[t] = frag_addr(S, bin, f_lo + t);
+    }
+}
+// The fragment of the window that holds tuple j of the bin (s_pre[0] <= j < s_pre[nfr]): the last f with s_pre[f] <= j.
+// Empty fragments repeat their neighbour's value and are never the answer.
+__device__ __forceinline__ uint32_t frag_find(const uint32_t *s_pre, uint32_t nfr, uint32_t j) {
+    uint32_t lo = 0, hi = nfr;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (s_pre[mid] <= j) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+__device__ __forceinline__ GridTuple frag_ld_tuple(const uint32_t *s_pre, const uint64_t *s_addr, uint32_t nfr, uint32_t j) {
+    const uint32_t f = frag_find(s_pre, nfr, j);
+    const uint64_t a = s_addr[f];
+    const bool wide = a & 1;
+    return ld_tuple(reinterpret_cast<const uint8_t *>(a & ~1ull) + (uint64_t)(j - s_pre[f]) * tuple_bytes(wide), wide);
 }
 
+// body(tuple) for every tuple of bin `bin`, some thread each, no particular order; whole workgroup, ends on a barrier.
+template <int NT, int FB, int UNROLL, typename F>
+__device__ __forceinline__ void bin_for_each(const BinSrc &S, uint32_t bin, uint32_t *s_pre, uint64_t *s_addr, F &&body) {
+    const uint32_t total = uni32(ldg(S.preT + (size_t)bin * S.Tp1 + S.T));
+    uint32_t f_lo = 0, j0 = 0;
+    while (j0 < total) {  // (the same for every thread)
+        const uint32_t nfr = S.T - f_lo < (uint32_t)FB ? S.T - f_lo : (uint32_t)FB;
+        frag_window_fill<NT>(S, bin, f_lo, nfr, s_pre, s_addr);
+        __syncthreads();
+        const uint32_t wend = s_pre[nfr];
+        for (uint32_t i0 = j0 + threadIdx.x; i0 < wend; i0 += NT * UNROLL) {  // the loads of UNROLL steps are issued together
+            GridTuple t[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++) {
+                const uint32_t j = i0 + u * NT;
+                t[u] = frag_ld_tuple(s_pre, s_addr, nfr, j < wend ? j : wend - 1);
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; u++)
+                if (i0 + u * NT < wend) body(t[u]);
+        }
+        j0 = wend, f_lo += nfr;
+        __syncthreads();  // the window is rewritten
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// pass 0: one reading of a scan's points -> per tile one block of tuples sorted by level-1 bin + a directory row
+// ---------------------------------------------------------------------------------------------------------------
 // What the predicate reads of a point: its position (bounds kinds) or its class byte.
 template <int KIND>
 struct P0In {
     RawPoint rp;
     uint32_t cls;
 };
-template <int KIND, bool STREAM = true>
+template <int KIND>
 __device__ __forceinline__ P0In<KIND> p0_load(const DevCols &c, uint64_t i) {
     P0In<KIND> in;
     if (KIND == PCQ_PRED_CLASS) in.cls = c.cls[i * c.cls_stride];
-    else in.rp = STREAM ? ld_xyz_stream(c, i) : ld_xyz(c, i);
+    else in.rp = ld_xyz_stream(c, i);
     return in;
 }
 template <int KIND>
@@ -371,63 +450,312 @@ __device__ __forceinline__ bool p0_pass(const DevCols &c, const DevPred &pr, con
                  wz = c.offset[2] + c.scale[2] * (double)rp.z;
     return !((wx < pr.wmin[0]) | (wy < pr.wmin[1]) | (wz < pr.wmin[2]) | (wx > pr.wmax[0]) | (wy > pr.wmax[1]) | (wz > pr.wmax[2]));
 }
+__device__ __forceinline__ uint64_t key_only(const DevGrid &g, double px, double py, double pz) {
+    const CellFast cf = cell_fast(g, px, py, pz);
+    if (!cf.ok) return cell_of(g, px, py, pz).key;
+    bool alias;
+    return key_fast(g, cf, &alias);
+}
 
-// Workgroup b owns the points [b * per_block, (b + 1) * per_block): cnt[b][bin] = its matches per level-1 bin.
-// The inputs of the next tile are loaded before the current one is evaluated.
-template <int KIND, int NT>
-__global__ __launch_bounds__(NT) void k_p0_hist(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, uint32_t *__restrict__ cnt) {
-    __shared__ uint32_t hist[F1];
-    for (int t = threadIdx.x; t < F1; t += NT) hist[t] = 0;
+// Workgroup w takes the tiles w, w + gridDim.x, ...: tile t = points t * 5120 .. of the scan; its matches leave as tile
+// t's block (out + t * 5120 * tuple bytes: the tuples sorted by level-1 bin, written front to back as one stream) and
+// directory row (dir + t * DIR_STRIDE: where each bin starts in the block; [512] = the block's tuples).  The inputs of the
+// next tile are on their way while this one is sorted.
+//
+// The tile's own fold (`agg`).  insert_point (grid_sampling.rs:72-103) on a key's state P with a new point q, both
+// measured against the centre of q's cell: P' = q if P is empty or d(q) < d(P), else P.  Take the tuples q1 .. qn of one
+// key inside one tile, none of them aliased: they share one unmasked cell, hence one centre, and they are CONSECUTIVE
+// among the key's tuples in file order (a tile is a range of the file).  Applying q1 .. qn to any state P gives the
+// earliest qi of least distance if that distance is below d(P), else P — exactly what applying that one qi gives.  So
+// the tile may drop every tuple of the key except its (distance, file order) minimum m, and any superset of {m} is as
+// good; the fold downstream (and the exact replay, should the key turn out aliased elsewhere) sees an equivalent
+// sequence.  A key with an aliased tuple in the tile keeps all its tuples.
+// Mechanics: one 64-bit LDS word per table slot, atomicMin of (distance bits >> 13 + 1) << 13 | place in the tile — the
+// truncation keeps the minimum a minimum and only lets near-ties survive together; an aliased tuple (or a distance that
+// is not finite) enters as 0 << 13 | place and so wins its slot.  Afterwards a tuple reads its slot: the winner is of
+// another key (compared through the tile's key array) -> kept, nothing is known; of its own key with the 0 mark -> kept;
+// otherwise kept iff its truncated distance equals the winner's.  No key is stored in the table and nothing probes.
+// A file in random order has no duplicates inside a tile: when a tile sheds less than a quarter of its matches the
+// workgroup leaves the next 2, 4, .. 16 tiles alone before it tries again (agg_mode 0; 1 = every tile, 2 = never —
+// the result is the same in every mode, only the number of tuples that travel differs).
+//
+// gfx950 counts loads and stores in ONE in-order counter (vmcnt): a wait for a load also waits for every store issued
+// before it, and the compiler cannot count the stores of the copy-out loop — so a load must never be waited for right
+// behind the copy-out.  Per tile: the attributes of this tile's matches are asked for at its head (nothing is computed on
+// them until the staging); the next tile's positions were asked for before that and are waited for BEFORE this tile's
+// stores are issued.  A load in a branch of its own (`c.cls ? c.cls[i] : 0` in an unrolled loop) is a serial round trip
+// per point.
+template <int KIND, bool RGB>
+__global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, DevGrid g, uint32_t ntiles, uint8_t *__restrict__ out,
+                                                      uint16_t *__restrict__ dir, uint32_t entry, uint64_t idx_base, int agg_mode) {
+    constexpr int NT = P0_NT, ITEMS = P0_ITEMS;
+    constexpr uint32_t TS = RGB ? 24 : 20;
+    constexpr int STAGE_BYTES = P0_TILE * 16 + P0_TILE * 4 * (RGB ? 2 : 1);
+    constexpr int AGG_BYTES = P0_TILE * 8 + AGG_SLOTS * 8;
+    constexpr int RAW_BYTES = STAGE_BYTES > AGG_BYTES ? STAGE_BYTES : AGG_BYTES;
+    __shared__ __attribute__((aligned(16))) uint8_t s_raw[RAW_BYTES];  // the tile's sorted image; before that, the duplicate table
+    uint4 *s_xyzi = reinterpret_cast<uint4 *>(s_raw);                          // x, y, z, idx
+    uint32_t *s_w0 = reinterpret_cast<uint32_t *>(s_raw + P0_TILE * 16);       // w0 [, w1]
+    uint32_t *s_w1 = s_w0 + P0_TILE;
+    uint64_t *s_akey = reinterpret_cast<uint64_t *>(s_raw);                    // the cell key of every place in the tile
+    uint64_t *s_atab = s_akey + P0_TILE;                                       // the table
+    __shared__ uint32_t s_cnt[F1], s_base[F1 + 1], s_wsum[NT / 64], s_npass[2];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t t = tid; t < F1; t += NT) s_cnt[t] = 0;
+    if (tid < 2) s_npass[tid] = 0;
     __syncthreads();
-    const uint64_t begin = (uint64_t)blockIdx.x * per_block;
-    const uint64_t end = begin + per_block < c.n ? begin + per_block : c.n;
-    P0In<KIND> cur[P0_ITEMS], nxt[P0_ITEMS];
+    uint32_t agg_skip = 0, agg_backoff = 1, parity = 0;
+    uint32_t tile = blockIdx.x;
+    P0In<KIND> cur[ITEMS], nxt[ITEMS];
+    if (tile < ntiles) {
 #pragma unroll
-    for (int j = 0; j < P0_ITEMS; j++) {
-        const uint64_t i = begin + (uint64_t)j * NT + threadIdx.x;
-        cur[j] = p0_load<KIND>(c, i < end ? i : end - 1);
+        for (int j = 0; j < ITEMS; j++) {
+            const uint64_t i = (uint64_t)tile * P0_TILE + (uint64_t)j * NT + tid;
+            cur[j] = p0_load<KIND>(c, i < c.n ? i : c.n - 1);
+        }
     }
-    for (uint64_t base = begin; base < end; base += (NT * P0_ITEMS)) {
-        const uint64_t nbase = base + (NT * P0_ITEMS);
-        if (nbase < end) {
 #pragma unroll
-            for (int j = 0; j < P0_ITEMS; j++) {
-                const uint64_t i = nbase + (uint64_t)j * NT + threadIdx.x;
-                nxt[j] = p0_load<KIND>(c, i < end ? i : end - 1);
+    for (int j = 0; j < ITEMS; j++) {  // (arrived: inside the loop nothing is pending at its head)
+        if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
+        else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
+    }
+    for (; tile < ntiles; tile += gridDim.x, parity ^= 1) {
+        const uint64_t base = (uint64_t)tile * P0_TILE;
+        const uint32_t ntile = tile + gridDim.x;
+        if (ntile < ntiles) {
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                const uint64_t i = (uint64_t)ntile * P0_TILE + (uint64_t)j * NT + tid;
+                nxt[j] = p0_load<KIND>(c, i < c.n ? i : c.n - 1);
+            }
+        }
+        const bool agg = agg_mode == 1 || (agg_mode == 0 && agg_skip == 0);  // (the same for the whole workgroup)
+        bool passes[ITEMS];
+        uint32_t metas[ITEMS], ranks[ITEMS], rg[ITEMS], bb[ITEMS], cl[ITEMS];
+        uint64_t pk[ITEMS];
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const uint64_t i = base + (uint64_t)j * NT + tid;
+            passes[j] = i < c.n && p0_pass<KIND>(c, pr, cur[j]);
+            rg[j] = 0, bb[j] = 0, cl[j] = KIND == PCQ_PRED_CLASS ? cur[j].cls : 0;
+            pk[j] = 0, metas[j] = 0, ranks[j] = 0;
+            if (!passes[j]) continue;
+            if (KIND == PCQ_PRED_CLASS) cur[j].rp = ld_xyz(c, i);
+            if (RGB) {  // last.rs:145-153
+                const uint8_t *q = c.rgb + i * c.rgb_stride;
+                rg[j] = ld_u16(q) | (ld_u16(q + 2) << 16);
+                bb[j] = ld_u16(q + 4);
+            }
+            if (KIND != PCQ_PRED_CLASS && c.cls) cl[j] = c.cls[i * c.cls_stride];  // last.rs:138-142
+        }
+        if (agg)
+            for (uint32_t k = tid; k < (uint32_t)AGG_SLOTS; k += NT) s_atab[k] = ~0ull;
+        uint32_t npass = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            if (!passes[j]) continue;
+            npass++;
+            const double px = world(cur[j].rp.x, c.scale[0], c.offset[0]), py = world(cur[j].rp.y, c.scale[1], c.offset[1]),
+                         pz = world(cur[j].rp.z, c.scale[2], c.offset[2]);
+            if (agg) {
+                const TupleEval ev = eval_world(g, px, py, pz);
+                const uint64_t h = cell_hash(ev.key);
+                const uint32_t place = (uint32_t)j * NT + tid;
+                s_akey[place] = ev.key;
+                const bool through = ev.alias || ev.dbits >= 0x7ff0000000000000ull;
+                pk[j] = (through ? 0ull : ((ev.dbits >> AGG_POS_BITS) + 1) << AGG_POS_BITS) | place;
+                metas[j] = bin_of(h) | (((uint32_t)(h >> 24) & (AGG_SLOTS - 1)) << F1_BITS);
+            } else {
+                metas[j] = bin_of(cell_hash(key_only(g, px, py, pz)));
+            }
+        }
+        if (agg) {
+            __syncthreads();  // the table is clear, the keys are in place
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++)
+                if (passes[j]) atomicMin((unsigned long long *)&s_atab[metas[j] >> F1_BITS], (unsigned long long)pk[j]);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++) {
+                if (!passes[j]) continue;
+                const uint64_t w = s_atab[metas[j] >> F1_BITS];
+                const uint64_t wkey = s_akey[(uint32_t)w & ((1u << AGG_POS_BITS) - 1)], mykey = s_akey[(uint32_t)j * NT + tid];
+                passes[j] = wkey != mykey || (w >> AGG_POS_BITS) == 0 || (w >> AGG_POS_BITS) == (pk[j] >> AGG_POS_BITS);
             }
         }
 #pragma unroll
-        for (int j = 0; j < P0_ITEMS; j++) {
-            const uint64_t i = base + (uint64_t)j * NT + threadIdx.x;
-            if (i >= end || !p0_pass<KIND>(c, pr, cur[j])) continue;
-            if (KIND == PCQ_PRED_CLASS) cur[j].rp = ld_xyz(c, i);
-            atomicAdd(&hist[bin_of(point_hash<KIND>(c, g, cur[j].rp))], 1u);
+        for (int j = 0; j < ITEMS; j++)
+            if (passes[j]) ranks[j] = atomicAdd(&s_cnt[metas[j] & (F1 - 1)], 1u);
+        {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) npass += __shfl_xor(npass, o, 64);
+            if (lane == 0 && npass) atomicAdd(&s_npass[parity], npass);
+        }
+        __syncthreads();
+        {  // exclusive scan of the tile's counts over the bins (thread t = bin t); the counters are cleared for the next tile
+            const uint32_t v = tid < (uint32_t)F1 ? s_cnt[tid] : 0;
+            uint32_t incl = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if (lane >= (uint32_t)off) incl += up;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = incl - v, total = 0;
+            for (int w = 0; w < NT / 64; w++) {
+                before += (uint32_t)w < wave ? s_wsum[w] : 0;
+                total += s_wsum[w];
+            }
+            if (tid < (uint32_t)F1) {
+                s_base[tid] = before;
+                s_cnt[tid] = 0;
+            }
+            if (tid == 0) s_base[F1] = total;
+        }
+        __syncthreads();
+        const uint32_t total = s_base[F1], matched = s_npass[parity];
+        if (tid < (uint32_t)DIR_WORDS) {  // the directory row, two entries per word
+            const uint32_t lo = s_base[2 * tid], hi = 2 * tid + 1 <= (uint32_t)F1 ? s_base[2 * tid + 1] : 0;
+            *(PCQ_GLOBAL uint32_t *)(reinterpret_cast<uint32_t *>(dir + (size_t)tile * DIR_STRIDE) + tid) = lo | (hi << 16);
         }
 #pragma unroll
-        for (int j = 0; j < P0_ITEMS; j++) cur[j] = nxt[j];
+        for (int j = 0; j < ITEMS; j++) {
+            if (!passes[j]) continue;
+            const uint64_t i = base + (uint64_t)j * NT + tid;
+            const uint32_t at = s_base[metas[j] & (F1 - 1)] + ranks[j];
+            s_xyzi[at] = make_uint4((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y, (uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
+            s_w0[at] = cl[j] | (entry << 8) | (rg[j] << 16);
+            if (RGB) s_w1[at] = (rg[j] >> 16) | (bb[j] << 16);
+        }
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {  // the next tile's inputs have arrived (asked for a whole tile ago) — before the stores below
+            cur[j] = nxt[j];
+            if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
+            else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
+        }
+        if (tid == 0) s_npass[parity ^ 1] = 0;
+        __syncthreads();
+        uint8_t *blk = out + (uint64_t)tile * P0_TILE * TS;
+        for (uint32_t t = tid; t < total; t += NT) {  // the block, front to back
+            const uint4 a = s_xyzi[t];
+            uint8_t *q = blk + (uint64_t)t * TS;
+            u32x4_a4 va = {a.x, a.y, a.z, a.w};
+            *(PCQ_GLOBAL u32x4_a4 *)q = va;
+            *(PCQ_GLOBAL uint32_t *)(q + 16) = s_w0[t];
+            if (RGB) *(PCQ_GLOBAL uint32_t *)(q + 20) = s_w1[t];
+        }
+        __syncthreads();  // the image is rewritten by the next tile
+        if (agg && agg_mode == 0) {
+            if (total * 4 > matched * 3) {  // less than a quarter shed: not worth the table for a while
+                agg_backoff = agg_backoff < 16 ? agg_backoff * 2 : 16;
+                agg_skip = agg_backoff;
+            } else {
+                agg_backoff = 1;
+            }
+        } else if (agg_skip) {
+            agg_skip--;
+        }
     }
-    __syncthreads();
-    for (int t = threadIdx.x; t < F1; t += NT) cnt[(size_t)blockIdx.x * F1 + t] = hist[t];
 }
 
-// cnt[b][bin] -> exclusive prefix over the workgroups b, per bin (one wave per bin); total[bin] = the bin's tuples.
-__global__ __launch_bounds__(BLOCK) void k_p0_scan_blocks(uint32_t *__restrict__ cnt, int nblocks, uint32_t *__restrict__ total) {
-    const int lane = threadIdx.x & 63;
-    const int bin = blockIdx.x * WAVES + (threadIdx.x >> 6);
-    uint32_t running = 0;
-    for (int b0 = 0; b0 < nblocks; b0 += 64) {
-        const int b = b0 + lane;
-        const uint32_t v = b < nblocks ? cnt[(size_t)b * F1 + bin] : 0;
-        uint32_t incl = v;
+// ---------------------------------------------------------------------------------------------------------------
+// fold preparation: the directory rows, transposed into per-bin fragment lists
+// ---------------------------------------------------------------------------------------------------------------
+struct DevRun {        // one pending pass-0 run
+    const uint8_t *tuples;
+    const uint16_t *dir;
+    uint32_t tile0;    // its first tile among all pending tiles
+    uint32_t ntiles;
+    uint32_t wide, _pad;
+};
+
+// 64 tiles per workgroup: their directory rows through LDS; lane = tile, so that what leaves are whole lines of
+// startT[b] / preT[b] (preT gets the fragment's COUNT here; k_bin_prefix turns the counts into the prefix).
+__global__ __launch_bounds__(BLOCK) void k_dir_transpose(const DevRun *__restrict__ runs, int nruns, uint32_t T, uint32_t Tp, uint32_t Tp1,
+                                                         uint16_t *__restrict__ startT, uint32_t *__restrict__ preT, uint64_t *__restrict__ tile_addr) {
+    __shared__ uint32_t s_rows[64 * DIR_WORDS];  // 64 rows of 257 words: lane r reads word r * 257 + k — no two lanes in one bank
+    __shared__ uint64_t s_rowptr[64];
+    const uint32_t t0 = blockIdx.x * 64;
+    if (threadIdx.x < 64) {
+        const uint32_t t = t0 + threadIdx.x;
+        uint64_t rowptr = 0;
+        if (t < T) {
+            int lo = 0, hi = nruns;  // the last run with tile0 <= t
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (runs[mid].tile0 <= t) lo = mid;
+                else hi = mid;
+            }
+            const DevRun r = runs[lo];
+            const uint32_t local = t - r.tile0;
+            rowptr = reinterpret_cast<uint64_t>(r.dir + (size_t)local * DIR_STRIDE);
+            tile_addr[t] = reinterpret_cast<uint64_t>(r.tuples + (uint64_t)local * P0_TILE * tuple_bytes(r.wide)) | (r.wide ? 1u : 0u);
+        }
+        s_rowptr[threadIdx.x] = rowptr;
+    }
+    __syncthreads();
+    for (int r = 0; r < 64; r++) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(s_rowptr[r]);
+        for (int w = threadIdx.x; w < DIR_WORDS; w += BLOCK) s_rows[r * DIR_WORDS + w] = row ? ldg(row + w) : 0u;
+    }
+    __syncthreads();
+    const uint32_t r = threadIdx.x & 63;
+    if (t0 + r >= T) return;
+    for (uint32_t b = threadIdx.x >> 6; b < (uint32_t)F1; b += WAVES) {
+        const uint32_t w0 = s_rows[r * DIR_WORDS + (b >> 1)], w1 = s_rows[r * DIR_WORDS + ((b + 1) >> 1)];
+        const uint32_t v0 = (b & 1) ? w0 >> 16 : w0 & 0xffffu, v1 = ((b + 1) & 1) ? w1 >> 16 : w1 & 0xffffu;
+        startT[(size_t)b * Tp + t0 + r] = (uint16_t)v0;
+        preT[(size_t)b * Tp1 + t0 + r] = v1 - v0;
+    }
+}
+
+// preT[b][0 .. T): counts -> exclusive prefix, preT[b][T] = bintot[b] = the bin's tuples.  One workgroup per bin.
+__global__ __launch_bounds__(1024) void k_bin_prefix(uint32_t *__restrict__ preT, uint32_t T, uint32_t Tp1, uint32_t *__restrict__ bintot) {
+    __shared__ uint32_t s_wave[16];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *row = preT + (size_t)blockIdx.x * Tp1;
+    uint32_t carry = 0;
+    for (uint32_t c0 = 0; c0 < T; c0 += 4096) {
+        const uint32_t i0 = c0 + threadIdx.x * 4;
+        uint32_t v[4], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            v[k] = i0 + k < T ? row[i0 + k] : 0;
+            sum += v[k];
+        }
+        uint32_t incl = sum;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t up = __shfl_up(incl, off, 64);
             if (lane >= off) incl += up;
         }
-        if (b < nblocks) cnt[(size_t)b * F1 + bin] = running + incl - v;
-        running += __shfl(incl, 63, 64);
+        if (lane == 63) s_wave[wave] = incl;
+        __syncthreads();
+        uint32_t run = carry + incl - sum, total = 0;
+        for (int w = 0; w < 16; w++) {
+            run += w < wave ? s_wave[w] : 0;
+            total += s_wave[w];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (i0 + k < T) row[i0 + k] = run;
+            run += v[k];
+        }
+        carry += total;
+        __syncthreads();  // s_wave is rewritten
     }
-    if (lane == 0) total[bin] = running;
+    if (threadIdx.x == 0) {
+        row[T] = carry;
+        bintot[blockIdx.x] = carry;
+    }
+}
+
+// tot[p] = tuples of partition p of the second level's output.
+__global__ __launch_bounds__(BLOCK) void k_part_totals(GridSeg sg, uint32_t nparts, uint32_t *__restrict__ tot) {
+    const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
+    if (p >= nparts) return;
+    tot[p] = sg.cnt ? sg.cnt[p] : sg.off[p + 1] - sg.off[p];
 }
 
 // out[0..n] = exclusive prefix of in[0..n) (out[n] = the sum); one workgroup, any n.
@@ -487,325 +815,6 @@ __global__ __launch_bounds__(1024) void k_excl_scan_u64(const uint64_t *__restri
     if (threadIdx.x == 1023) s_carry = wave_off + incl;
     __syncthreads();
     if (threadIdx.x == 0) out[n] = s_carry;
-}
-
-// The second reading of the scan: every match becomes a tuple at binoff[bin] + (workgroup's offset in the bin) + rank.
-// Per tile (NT x ITEMS points; 5120 as shipped): the matches take a rank in their bin (LDS atomics), the tile's tuples are laid out in LDS
-// sorted by bin, and the sorted image is copied out one tuple per lane — consecutive lanes write consecutive tuples of
-// a bin's run, so what reaches HBM are contiguous pieces instead of 24-byte fragments.  A tuple is staged (and stored) as
-// 16 + 8 bytes; next to it sits its bin, which gives the tuple's place in the run (the tile's first place in the bin + the
-// tuple's place in the sorted image).
-template <int KIND, bool STREAM, int NT, int ITEMS, int NTS = 0>
-__global__ __launch_bounds__(NT, NT == 512 ? 4 : (NT == 1024 ? 4 : 2)) void k_p0_scatter(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
-                                                      const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out,
-                                                      uint32_t entry, uint64_t idx_base) {
-    constexpr int TILE = NT * ITEMS;
-    static_assert(TILE % P0_TILE == 0 && (F1 % NT == 0 || NT % F1 == 0), "whole tiles of the histogram pass; whole bins per thread in the per-tile scan");
-    constexpr int BPT = F1 >= NT ? F1 / NT : 1;  // bins per thread in the scan (threads beyond the bins idle there)
-    __shared__ uint4 s_xyzi[TILE];        // the tile's tuples, sorted by bin: x, y, z, idx
-    __shared__ uint2 s_attr[TILE];        //                                    w0, w1
-    __shared__ uint16_t s_bin[TILE];      // its bin
-    __shared__ uint32_t s_cnt[F1], s_base[F1], s_delta[F1], s_cur[F1], s_wsum[NT / 64];
-    __shared__ uint32_t s_total;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int t = threadIdx.x; t < F1; t += NT) {
-        s_cur[t] = binoff[t] + cnt_excl[(size_t)blockIdx.x * F1 + t];
-        s_cnt[t] = 0;
-    }
-    __syncthreads();
-    const uint64_t begin = (uint64_t)blockIdx.x * per_block;
-    const uint64_t end = begin + per_block < c.n ? begin + per_block : c.n;
-    P0In<KIND> cur[ITEMS], nxt[ITEMS];
-#pragma unroll
-    for (int j = 0; j < ITEMS; j++) {
-        const uint64_t i = begin + (uint64_t)j * NT + threadIdx.x;
-        cur[j] = p0_load<KIND, STREAM>(c, i < end ? i : end - 1);
-    }
-#pragma unroll
-    for (int j = 0; j < ITEMS; j++) {  // (arrived: inside the loop nothing is pending at its head, see below)
-        if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
-        else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
-    }
-    for (uint64_t base = begin; base < end; base += TILE) {
-        const uint64_t nbase = base + TILE;
-        if (nbase < end) {  // the next tile's inputs are on their way while this one is sorted
-#pragma unroll
-            for (int j = 0; j < ITEMS; j++) {
-                const uint64_t i = nbase + (uint64_t)j * NT + threadIdx.x;
-                nxt[j] = p0_load<KIND, STREAM>(c, i < end ? i : end - 1);
-            }
-        }
-        // gfx950 counts loads and stores in ONE in-order counter (vmcnt): a wait for a load also waits for every store issued
-        // before it, and the compiler cannot count the stores of the copy-out loop — so a load must never be waited for
-        // right behind the copy-out.  Per tile: the attributes of this tile's matches are asked for here (nothing is
-        // computed on them until the staging, two barriers later); the next tile's positions were asked for above and are
-        // waited for BEFORE this tile's stores are issued.
-        bool passes[ITEMS];
-        uint32_t metas[ITEMS], ranks[ITEMS], rg[ITEMS], bb[ITEMS], cl[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; j++) {
-            const uint64_t i = base + (uint64_t)j * NT + threadIdx.x;
-            passes[j] = i < end && p0_pass<KIND>(c, pr, cur[j]);
-            rg[j] = 0, bb[j] = 0, cl[j] = KIND == PCQ_PRED_CLASS ? cur[j].cls : 0;
-            if (!passes[j]) continue;
-            if (KIND == PCQ_PRED_CLASS) cur[j].rp = ld_xyz(c, i);
-            if (c.rgb) {  // last.rs:145-153
-                const uint8_t *q = c.rgb + i * c.rgb_stride;
-                rg[j] = ld_u16(q) | (ld_u16(q + 2) << 16);
-                bb[j] = ld_u16(q + 4);
-            }
-            if (KIND != PCQ_PRED_CLASS && c.cls) cl[j] = c.cls[i * c.cls_stride];  // last.rs:138-142
-        }
-#pragma unroll
-        for (int j = 0; j < ITEMS; j++) {
-            if (!passes[j]) continue;
-            const uint64_t h = point_hash<KIND>(c, g, cur[j].rp);
-            const uint32_t bin = bin_of(h);
-            metas[j] = bin;
-            ranks[j] = atomicAdd(&s_cnt[bin], 1u);
-        }
-        __syncthreads();
-        {  // exclusive scan of the tile's counts over the bins (thread t = bins t * BPT ...); the workgroup's cursors move on
-            uint32_t v[BPT], mine = 0;
-#pragma unroll
-            for (int q = 0; q < BPT; q++) v[q] = threadIdx.x * BPT + q < F1 ? s_cnt[threadIdx.x * BPT + q] : 0, mine += v[q];
-            uint32_t incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t up = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += up;
-            }
-            if (lane == 63) s_wsum[wave] = incl;
-            __syncthreads();
-            uint32_t before = incl - mine, total = 0;
-            for (int w = 0; w < NT / 64; w++) {
-                before += w < wave ? s_wsum[w] : 0;
-                total += s_wsum[w];
-            }
-#pragma unroll
-            for (int q = 0; q < BPT; q++) {
-                const int bin = threadIdx.x * BPT + q;
-                if (bin >= F1) continue;
-                s_base[bin] = before;
-                s_delta[bin] = s_cur[bin] - before;
-                s_cur[bin] += v[q];
-                s_cnt[bin] = 0;
-                before += v[q];
-            }
-            if (threadIdx.x == 0) s_total = total;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < ITEMS; j++) {
-            if (!passes[j]) continue;
-            const uint64_t i = base + (uint64_t)j * NT + threadIdx.x;
-            const uint32_t at = s_base[metas[j]] + ranks[j];
-            s_xyzi[at] = make_uint4((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y, (uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
-            s_attr[at] = make_uint2(cl[j] | (entry << 8) | (rg[j] << 16), (rg[j] >> 16) | (bb[j] << 16));
-            s_bin[at] = (uint16_t)metas[j];
-        }
-#pragma unroll
-        for (int j = 0; j < ITEMS; j++) {  // the next tile's inputs have arrived (asked for a whole tile ago) — before the stores below
-            cur[j] = nxt[j];
-            if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
-            else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
-        }
-        __syncthreads();
-        const uint32_t total = s_total;
-        for (uint32_t t = threadIdx.x; t < total; t += NT) {
-            const uint4 a = s_xyzi[t];
-            const uint2 b = s_attr[t];
-            uint32_t pos = s_delta[s_bin[t]] + t;
-            if (NTS == 2) pos = (uint32_t)(base + t);  // (lab, WRONG results: the tile leaves in one piece — what do the scattered runs cost?)
-            if (NTS == 3) {  // (lab, WRONG results: groups of 16 tuples = three whole 128-byte lines, each group at a random place)
-                uint32_t grp = (uint32_t)((base + t) >> 4) * 2654435761u;
-                grp ^= grp >> 15;
-                pos = (grp % (uint32_t)(c.n >> 4)) * 16u + (t & 15u);
-            }
-            uint8_t *q = reinterpret_cast<uint8_t *>(out) + (uint64_t)pos * sizeof(GridTuple);
-            u32x4_a8 va = {a.x, a.y, a.z, a.w};
-            if (NTS == 1) {  // (lab: streaming stores)
-                u32x2 vb = {b.x, b.y};
-                __builtin_nontemporal_store(va, reinterpret_cast<u32x4_a8 *>(q));
-                __builtin_nontemporal_store(vb, reinterpret_cast<u32x2 *>(q + 16));
-            } else {
-                *reinterpret_cast<u32x4_a8 *>(q) = va;
-                *reinterpret_cast<uint2 *>(q + 16) = b;
-            }
-        }
-        __syncthreads();  // the stage and the bases are rewritten by the next tile
-    }
-}
-
-#ifdef PCQ_LAB
-// (lab) The scatter with whole-line stores: per bin a carry of up to 15 eight-byte words stays in LDS across the tiles, so
-// that every store to a bin's piece is a whole, aligned 128-byte line (except the piece's first and last) — the runs of the
-// shipped kernel reach the L2 as partial lines that the next tile has to complete (profiles/r02_grid_progress.txt).
-// A tuple is three words; the stream of a (workgroup, bin) piece is carry words followed by the tile's new tuples.
-constexpr int SL_NT = 1024, SL_ITEMS = 3, SL_TILE = SL_NT * SL_ITEMS;  // 72 KB of staged words + 64 KB of carries
-constexpr int SL_MAXLINES = (SL_TILE * 3 + 15 * F1) / 16 + 1;
-template <int KIND>
-__global__ __launch_bounds__(SL_NT, 4) void k_p0_scatter_lines(DevCols c, DevPred pr, DevGrid g, uint64_t per_block, const uint32_t *__restrict__ cnt_excl,
-                                                               const uint32_t *__restrict__ binoff, GridTuple *__restrict__ out, uint32_t entry,
-                                                               uint64_t idx_base) {
-    __shared__ uint2 s_words[SL_TILE * 3];   // the tile's tuples, sorted by bin, as 8-byte words
-    __shared__ uint2 s_carry[F1 * 16];       // per bin: words not yet written (the bin's global cursor is line-aligned in front of them)
-    __shared__ uint4 s_info[F1];             // per bin and tile: {first line among the tile's lines, stage word index - word index,
-                                             //                    global line - tile line, carry words | phantom words << 8}
-    __shared__ uint32_t s_gline[F1], s_cw[F1], s_skip[F1];  // per bin: global line of the carry's first word, carry words (incl. phantom), phantom words
-    __shared__ uint32_t s_cnt[F1], s_base[F1], s_v[F1];
-    __shared__ uint16_t s_linebin[SL_MAXLINES];
-    __shared__ unsigned long long s_wsum[SL_NT / 64];
-    __shared__ uint32_t s_total_lines;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    uint2 *out_words = reinterpret_cast<uint2 *>(out);
-    for (int t = threadIdx.x; t < F1; t += SL_NT) {
-        const uint64_t w0 = 3ull * (binoff[t] + cnt_excl[(size_t)blockIdx.x * F1 + t]);  // the piece's first word
-        s_gline[t] = (uint32_t)(w0 >> 4);
-        s_cw[t] = s_skip[t] = (uint32_t)(w0 & 15);  // the words in front of the piece on its first line belong to the previous workgroup
-        s_cnt[t] = 0;
-    }
-    __syncthreads();
-    const uint64_t begin = (uint64_t)blockIdx.x * per_block;
-    const uint64_t end = begin + per_block < c.n ? begin + per_block : c.n;
-    P0In<KIND> cur[SL_ITEMS], nxt[SL_ITEMS];
-#pragma unroll
-    for (int j = 0; j < SL_ITEMS; j++) {
-        const uint64_t i = begin + (uint64_t)j * SL_NT + threadIdx.x;
-        cur[j] = p0_load<KIND, true>(c, i < end ? i : end - 1);
-    }
-#pragma unroll
-    for (int j = 0; j < SL_ITEMS; j++) {
-        if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
-        else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
-    }
-    for (uint64_t base = begin; base < end; base += SL_TILE) {
-        const uint64_t nbase = base + SL_TILE;
-        if (nbase < end) {
-#pragma unroll
-            for (int j = 0; j < SL_ITEMS; j++) {
-                const uint64_t i = nbase + (uint64_t)j * SL_NT + threadIdx.x;
-                nxt[j] = p0_load<KIND, true>(c, i < end ? i : end - 1);
-            }
-        }
-        bool passes[SL_ITEMS];
-        uint32_t bins[SL_ITEMS], ranks[SL_ITEMS], rg[SL_ITEMS], bb[SL_ITEMS], cl[SL_ITEMS];
-#pragma unroll
-        for (int j = 0; j < SL_ITEMS; j++) {
-            const uint64_t i = base + (uint64_t)j * SL_NT + threadIdx.x;
-            passes[j] = i < end && p0_pass<KIND>(c, pr, cur[j]);
-            rg[j] = 0, bb[j] = 0, cl[j] = KIND == PCQ_PRED_CLASS ? cur[j].cls : 0;
-            if (!passes[j]) continue;
-            if (KIND == PCQ_PRED_CLASS) cur[j].rp = ld_xyz(c, i);
-            if (c.rgb) {
-                const uint8_t *q = c.rgb + i * c.rgb_stride;
-                rg[j] = ld_u16(q) | (ld_u16(q + 2) << 16);
-                bb[j] = ld_u16(q + 4);
-            }
-            if (KIND != PCQ_PRED_CLASS && c.cls) cl[j] = c.cls[i * c.cls_stride];
-        }
-#pragma unroll
-        for (int j = 0; j < SL_ITEMS; j++) {
-            if (!passes[j]) continue;
-            bins[j] = bin_of(point_hash<KIND>(c, g, cur[j].rp));
-            ranks[j] = atomicAdd(&s_cnt[bins[j]], 1u);
-        }
-        __syncthreads();
-        {  // per bin (thread t < 512): the tile's tuples and the lines its stream now fills; both prefix sums in one scan
-            const bool active = threadIdx.x < F1;
-            const uint32_t v = active ? s_cnt[threadIdx.x] : 0, cw = active ? s_cw[threadIdx.x] : 0;
-            const uint32_t tot = cw + 3 * v, nl = active ? tot >> 4 : 0;
-            const unsigned long long mine = ((unsigned long long)nl << 32) | v;
-            unsigned long long incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned long long up = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += up;
-            }
-            if (lane == 63) s_wsum[wave] = incl;
-            __syncthreads();
-            unsigned long long before = incl - mine, total = 0;
-            for (int w = 0; w < SL_NT / 64; w++) {
-                before += w < wave ? s_wsum[w] : 0;
-                total += s_wsum[w];
-            }
-            if (active) {
-                const uint32_t tbase = (uint32_t)before, lstart = (uint32_t)(before >> 32);
-                s_base[threadIdx.x] = tbase;
-                s_v[threadIdx.x] = v;
-                s_info[threadIdx.x] = make_uint4(lstart, 3 * tbase - cw, s_gline[threadIdx.x] - lstart, cw | (s_skip[threadIdx.x] << 8));
-                for (uint32_t i = 0; i < nl; i++) s_linebin[lstart + i] = (uint16_t)threadIdx.x;
-                s_cnt[threadIdx.x] = 0;
-            }
-            if (threadIdx.x == 0) s_total_lines = (uint32_t)(total >> 32);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < SL_ITEMS; j++) {
-            if (!passes[j]) continue;
-            const uint64_t i = base + (uint64_t)j * SL_NT + threadIdx.x;
-            const uint32_t at = 3 * (s_base[bins[j]] + ranks[j]);
-            s_words[at] = make_uint2((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y);
-            s_words[at + 1] = make_uint2((uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
-            s_words[at + 2] = make_uint2(cl[j] | (entry << 8) | (rg[j] << 16), (rg[j] >> 16) | (bb[j] << 16));
-        }
-#pragma unroll
-        for (int j = 0; j < SL_ITEMS; j++) {  // the next tile's inputs have arrived — before the stores below
-            cur[j] = nxt[j];
-            if (KIND == PCQ_PRED_CLASS) asm volatile("" ::"v"(cur[j].cls));
-            else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
-        }
-        __syncthreads();
-        {  // the whole lines: 16 lanes per line, one word each
-            const uint32_t total_lines = s_total_lines, j = threadIdx.x & 15;
-            for (uint32_t L = threadIdx.x >> 4; L < total_lines; L += SL_NT / 16) {
-                const uint32_t bin = s_linebin[L];
-                const uint4 inf = s_info[bin];
-                const uint32_t li = L - inf.x, w = 16 * li + j, cw = inf.w & 0xff, skip = inf.w >> 8;
-                if (li == 0 && j < skip) continue;  // (the previous workgroup's words on the piece's first line)
-                const uint2 v = w < cw ? s_carry[bin * 16 + w] : s_words[inf.y + w];
-                out_words[(uint64_t)(inf.z + L) * 16 + j] = v;
-            }
-        }
-        __syncthreads();
-        {  // what is left of each stream becomes the bin's carry (two threads per bin)
-            const uint32_t bin = threadIdx.x >> 1, h = threadIdx.x & 1;
-            const uint32_t cw = s_cw[bin], tot = cw + 3 * s_v[bin], nl = tot >> 4, rem = tot & 15, off = s_info[bin].y;
-            if (nl) {
-                for (uint32_t i = h; i < rem; i += 2) s_carry[bin * 16 + i] = s_words[off + 16 * nl + i];
-            } else {
-                for (uint32_t i = cw + h; i < tot; i += 2) s_carry[bin * 16 + i] = s_words[off + i];
-            }
-            __syncthreads();  // (both halves of a pair have read s_cw)
-            if (h == 0) {
-                s_cw[bin] = rem;
-                s_gline[bin] += nl;
-                if (nl) s_skip[bin] = 0;
-            }
-        }
-        __syncthreads();
-    }
-    for (int t = threadIdx.x; t < F1; t += SL_NT) {  // the last, partial line of every piece
-        const uint32_t cw = s_cw[t], skip = s_skip[t];
-        for (uint32_t w = skip; w < cw; w++) out_words[(uint64_t)s_gline[t] * 16 + w] = s_carry[t * 16 + w];
-    }
-}
-
-#endif
-
-// ---------------------------------------------------------------------------------------------------------------
-// fold preparation
-// ---------------------------------------------------------------------------------------------------------------
-// tot[p] = tuples of partition p over all segments.
-__global__ __launch_bounds__(BLOCK) void k_part_totals(const GridSeg *__restrict__ segs, int nsegs, uint32_t nparts, uint32_t *__restrict__ tot) {
-    const uint32_t p = blockIdx.x * BLOCK + threadIdx.x;
-    if (p >= nparts) return;
-    uint32_t t = 0;
-    for (int r = 0; r < nsegs; r++) {
-        const GridSeg sg = segs[r];
-        t += seg_count(sg, p, sg.off[p]);
-    }
-    tot[p] = t;
 }
 
 // Room for the winners of partition p: never more than its inputs, never more than the LDS table holds.
@@ -868,28 +877,35 @@ __global__ __launch_bounds__(1024) void k_scan_pieces(const uint64_t *__restrict
     }
 }
 
-// Distinct cells among the tuples of the first PROBE_BINS level-1 bins (a global hash set; one thread per tuple).
-__global__ __launch_bounds__(BLOCK) void k_probe_distinct(const GridSeg *__restrict__ segs, EntryRef entries, DevGrid g,
-                                                          uint64_t *__restrict__ set, uint64_t mask, unsigned long long *__restrict__ distinct) {
-    const GridSeg sg = segs[blockIdx.y];
-    const uint32_t lo = sg.off[0], hi = sg.off[PROBE_BINS];
+// Distinct cells among the tuples of the first PROBE_BINS level-1 bins (a global hash set; one thread per fragment).
+__global__ __launch_bounds__(BLOCK) void k_probe_distinct(BinSrc S, EntryRef entries, DevGrid g, uint64_t *__restrict__ set, uint64_t mask,
+                                                          unsigned long long *__restrict__ distinct) {
     uint32_t mine = 0;
-    for (uint32_t i = lo + blockIdx.x * BLOCK + threadIdx.x; i < hi; i += gridDim.x * BLOCK) {
-        const GridTuple t = ld_tuple(sg.tuples + i);
-        const uint64_t key = eval_tuple(g, entries, t).key;
-        uint64_t h = hash64(key) & mask;
-        for (;;) {
-            const uint64_t k = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k == key) break;
-            if (k == PCQ_EMPTY_KEY) {
-                const uint64_t prev = atomicCAS((unsigned long long *)&set[h], (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key);
-                if (prev == PCQ_EMPTY_KEY) {
-                    mine++;
-                    break;
+    const uint32_t nfrag = S.T * PROBE_BINS;
+    for (uint32_t q = blockIdx.x * BLOCK + threadIdx.x; q < nfrag; q += gridDim.x * BLOCK) {
+        const uint32_t bin = q / S.T, f = q % S.T;
+        const uint32_t lo = ldg(S.preT + (size_t)bin * S.Tp1 + f), hi = ldg(S.preT + (size_t)bin * S.Tp1 + f + 1);
+        if (lo == hi) continue;
+        const uint64_t a = frag_addr(S, bin, f);
+        const bool wide = a & 1;
+        const uint8_t *p = reinterpret_cast<const uint8_t *>(a & ~1ull);
+        for (uint32_t i = 0; i < hi - lo; i++) {
+            const GridTuple t = ld_tuple(p + (uint64_t)i * tuple_bytes(wide), wide);
+            const uint64_t key = eval_tuple(g, entries, t).key;
+            uint64_t h = hash64(key) & mask;
+            for (;;) {
+                const uint64_t k = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k == key) break;
+                if (k == PCQ_EMPTY_KEY) {
+                    const uint64_t prev = atomicCAS((unsigned long long *)&set[h], (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key);
+                    if (prev == PCQ_EMPTY_KEY) {
+                        mine++;
+                        break;
+                    }
+                    if (prev == key) break;
                 }
-                if (prev == key) break;
+                h = (h + 1) & mask;
             }
-            h = (h + 1) & mask;
         }
     }
 #pragma unroll
@@ -899,16 +915,16 @@ __global__ __launch_bounds__(BLOCK) void k_probe_distinct(const GridSeg *__restr
 
 // ---------------------------------------------------------------------------------------------------------------
 // second partition level: one workgroup per level-1 bin cuts the bin's tuples (and, when the fan-out changes, the
-// earlier winners of the bin) into f2 partitions by the next bits of hash(key).  Histogram in LDS, then scatter.
+// earlier winners of the bin) into f2 partitions by the next bits of hash(key).
 // ---------------------------------------------------------------------------------------------------------------
 struct Level2Params {
-    const GridSeg *segs;
-    int nsegs;
+    BinSrc src;
     EntryRef entries;
     DevGrid g;
     uint32_t f2;
-    const uint32_t *binbase;  // [F1 + 1] tuples in front of each bin (prefix over all segments); nullptr: tuples are not moved
-    GridTuple *out;
+    const uint32_t *binbase;  // [F1 + 1] tuples in front of each bin; nullptr: tuples are not moved
+    uint8_t *out;
+    uint32_t wide;            // the output's tuples are 24 bytes (some run carries colour)
     uint32_t *off2;           // [F1 * f2 + 1]
     uint32_t *cnt2;           // k_level2: [F1 * f2] tuples per sub-partition; cap = the room each of them has
     uint32_t cap;
@@ -927,30 +943,17 @@ struct Level2Params {
 
 // The exact form: a histogram pass over the bin's tuples, then the scatter, sub-partitions back to back (off2 only).  Both
 // passes compute the tuple's cell.  For more than 1024 sub-partitions per bin, and when k_level2's regions did not hold.
-__device__ __forceinline__ uint32_t tuple_sel16(const Level2Params &P, const GridSeg &sg, uint32_t i) {
-    return sel16_of(cell_hash(eval_tuple(P.g, P.entries, ld_tuple(sg.tuples + i)).key));
-}
 __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
     __shared__ uint32_t s_hist[F2_MAX], s_cur[F2_MAX], s_ohist[F2_MAX], s_ocur[F2_MAX];
+    __shared__ uint32_t s_pre[L2_FB + 1];
+    __shared__ uint64_t s_addr[L2_FB];
     const uint32_t bin = blockIdx.x, f2 = P.f2;
     for (uint32_t t = threadIdx.x; t < F2_MAX; t += L2_NT) s_hist[t] = 0, s_ohist[t] = 0;
     __syncthreads();
     if (P.binbase)
-        for (int r = 0; r < P.nsegs; r++) {
-            const GridSeg sg = P.segs[r];
-            const uint32_t lo = ldg(sg.off + bin), hi = ldg(sg.off + bin + 1);
-            for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += L2_NT * L2_UNROLL) {  // the loads of four steps are issued together
-                uint32_t sel[L2_UNROLL];
-#pragma unroll
-                for (int u = 0; u < L2_UNROLL; u++) {
-                    const uint32_t i = i0 + u * L2_NT;
-                    sel[u] = tuple_sel16(P, sg, i < hi ? i : hi - 1);
-                }
-#pragma unroll
-                for (int u = 0; u < L2_UNROLL; u++)
-                    if (i0 + u * L2_NT < hi) atomicAdd(&s_hist[sub_from_sel16(sel[u], f2)], 1u);
-            }
-        }
+        bin_for_each<L2_NT, L2_FB, L2_UNROLL>(P.src, bin, s_pre, s_addr, [&](const GridTuple &t) {
+            atomicAdd(&s_hist[sub_of(cell_hash(eval_tuple(P.g, P.entries, t).key), f2)], 1u);
+        });
     if (P.okeys)
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
             const uint64_t base = P.obase[q];
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
             for (uint32_t i = threadIdx.x; i < n; i += L2_NT) atomicAdd(&s_ohist[sub_of(cell_hash(P.okeys[base + i]), f2)], 1u);
         }
     __syncthreads();
-    if (threadIdx.x == 0) {  // f2 <= 256: a serial prefix is a few hundred LDS reads
+    if (threadIdx.x == 0) {  // a serial prefix is a few hundred to a few thousand LDS reads
         uint32_t run = P.binbase ? P.binbase[bin] : 0, orun = P.okeys ? P.obinbase[bin] : 0;
         for (uint32_t s = 0; s < f2; s++) {
             if (P.binbase) P.off2[bin * f2 + s] = run;
@@ -974,27 +977,13 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
         }
     }
     __syncthreads();
-    if (P.binbase)
-        for (int r = 0; r < P.nsegs; r++) {
-            const GridSeg sg = P.segs[r];
-            const uint32_t lo = ldg(sg.off + bin), hi = ldg(sg.off + bin + 1);
-            for (uint32_t i0 = lo + threadIdx.x; i0 < hi; i0 += L2_NT * L2_UNROLL) {
-                GridTuple t[L2_UNROLL];
-                uint32_t sel[L2_UNROLL];
-#pragma unroll
-                for (int u = 0; u < L2_UNROLL; u++) {
-                    const uint32_t i = i0 + u * L2_NT;
-                    t[u] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
-                    sel[u] = tuple_sel16(P, sg, i < hi ? i : hi - 1);
-                }
-#pragma unroll
-                for (int u = 0; u < L2_UNROLL; u++) {
-                    if (i0 + u * L2_NT >= hi) continue;
-                    const uint32_t pos = atomicAdd(&s_cur[sub_from_sel16(sel[u], f2)], 1u);
-                    st_tuple(P.out + pos, t[u]);
-                }
-            }
-        }
+    if (P.binbase) {
+        const bool wide = P.wide;
+        bin_for_each<L2_NT, L2_FB, L2_UNROLL>(P.src, bin, s_pre, s_addr, [&](const GridTuple &t) {
+            const uint32_t pos = atomicAdd(&s_cur[sub_of(cell_hash(eval_tuple(P.g, P.entries, t).key), f2)], 1u);
+            st_tuple(P.out + (uint64_t)pos * tuple_bytes(wide), t, wide);
+        });
+    }
     if (P.okeys)
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
             const uint64_t base = P.obase[q];
@@ -1011,14 +1000,14 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
         }
 }
 
-// The staged form (f2 <= 1024), ONE pass over the bin's tuples: a tile of 1536 tuples is sorted by sub-partition in LDS and
-// leaves as runs (the direct form's scattered 24-byte stores reached HBM as 6.4 GB for 3.9 GB of tuples).  There is no
-// histogram pass in front: sub-partition p owns the fixed region out[p * cap .. (p + 1) * cap), cap = 1.3 x the mean
-// partition + 64 — the cell keys are hashed, a partition's tuple count is the mean +- a few per cent unless single cells
-// hold hundreds of points — and reports off2[p] = p * cap, cnt2[p] = its tuples.  A partition that outgrows its region
-// raises stats[5]: the host then takes the exact form (k_level2_direct), which counts first.
-// (An earlier shape had pass 0 store every tuple's selector bits so that a histogram pass here could read 2 bytes per
-// tuple: those 2-byte stores cost pass 0 0.2-0.7 ms per 163 M points, more than the pass they fed.)
+// The staged form (f2 <= 1024), ONE pass over the bin's tuples: a tile of 4096 tuples is sorted by sub-partition in LDS and
+// leaves as runs (the direct form's scattered stores reached HBM as 6.4 GB for 3.9 GB of tuples).  There is no histogram
+// pass in front: sub-partition p owns the fixed region out[p * cap .. (p + 1) * cap), cap = 1.3 x the mean partition + 64
+// — the cell keys are hashed, a partition's tuple count is the mean +- a few per cent unless single cells hold hundreds
+// of points — and reports off2[p] = p * cap, cnt2[p] = its tuples.  A partition that outgrows its region raises stats[5]:
+// the host then takes the exact form (k_level2_direct), which counts first.
+// The bin arrives through the fragment reader: a window of 2048 fragments (about five tiles' worth of tuples) in LDS,
+// whole tiles out of it — the next window starts at the fragment the last whole tile ended in.
 __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
     constexpr int BPT = L2_STAGED_F2 / L2S_NT;  // sub-partitions per thread in the per-tile scan
     static_assert(BPT >= 1 && BPT * L2S_NT == L2_STAGED_F2, "whole sub-partitions per thread");
@@ -1027,6 +1016,8 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
     __shared__ uint4 s_xyzi[L2S_TILE];   // the tile's tuples, sorted by sub-partition: x, y, z, idx
     __shared__ uint2 s_attr[L2S_TILE];   //                                                 w0, w1
     __shared__ uint32_t s_tpos[L2S_TILE];
+    __shared__ uint32_t s_pre[L2S_FB + 1];
+    __shared__ uint64_t s_addr[L2S_FB];
     __shared__ uint32_t s_wsum[L2S_NT / 64], s_total, s_overflow;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t bin = blockIdx.x, f2 = P.f2, cap = P.cap;
@@ -1051,101 +1042,119 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
     }
     __syncthreads();
     if (P.out) {
+        const BinSrc &S = P.src;
+        const bool wide_out = P.wide;
+        const uint32_t ts_out = tuple_bytes(wide_out);
         const uint64_t region0 = (uint64_t)bin * f2 * cap;  // this bin's sub-partition s: out[region0 + s * cap ...)
-        for (int r = 0; r < P.nsegs; r++) {
-            const GridSeg sg = P.segs[r];
-            const uint32_t lo = ldg(sg.off + bin), hi = ldg(sg.off + bin + 1);
-            if (lo >= hi) continue;
-            GridTuple t[L2S_ITEMS], tn[L2S_ITEMS];
+        const uint32_t total_in = uni32(ldg(S.preT + (size_t)bin * S.Tp1 + S.T));
+        uint32_t f_lo = 0, j0 = 0;
+        while (j0 < total_in) {  // one window of the bin's fragment list per round (the same for every thread)
+            const uint32_t nfr = S.T - f_lo < (uint32_t)L2S_FB ? S.T - f_lo : (uint32_t)L2S_FB;
+            frag_window_fill<L2S_NT>(S, bin, f_lo, nfr, s_pre, s_addr);
+            __syncthreads();
+            const uint32_t wend = s_pre[nfr];
+            // whole tiles out of the window; what is left starts the next window — unless the window ends the bin or holds
+            // less than a tile (a sparse bin), then everything
+            uint32_t hi = wend;
+            if (wend != total_in && wend - j0 >= (uint32_t)L2S_TILE) hi = j0 + (wend - j0) / L2S_TILE * L2S_TILE;
+            if (hi > j0) {
+                GridTuple t[L2S_ITEMS], tn[L2S_ITEMS];
 #pragma unroll
-            for (int j = 0; j < L2S_ITEMS; j++) {
-                const uint32_t i = lo + j * L2S_NT + threadIdx.x;
-                t[j] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
-            }
+                for (int j = 0; j < L2S_ITEMS; j++) {
+                    const uint32_t i = j0 + j * L2S_NT + threadIdx.x;
+                    t[j] = frag_ld_tuple(s_pre, s_addr, nfr, i < hi ? i : hi - 1);
+                }
 #pragma unroll
-            for (int j = 0; j < L2S_ITEMS; j++)  // (arrived: see k_p0_scatter on the one counter for loads and stores)
-                asm volatile("" ::"v"(t[j].x), "v"(t[j].w0));
-            for (uint32_t base = lo; base < hi; base += L2S_TILE) {
-                if (base + L2S_TILE < hi) {  // the next tile is on its way while this one is sorted
+                for (int j = 0; j < L2S_ITEMS; j++)  // (arrived: see k_p0_part on the one counter for loads and stores)
+                    asm volatile("" ::"v"(t[j].x), "v"(t[j].w0), "v"(t[j].w1));
+                for (uint32_t base = j0; base < hi; base += L2S_TILE) {
+                    if (base + L2S_TILE < hi) {  // the next tile is on its way while this one is sorted
+#pragma unroll
+                        for (int j = 0; j < L2S_ITEMS; j++) {
+                            const uint32_t i = base + L2S_TILE + j * L2S_NT + threadIdx.x;
+                            tn[j] = frag_ld_tuple(s_pre, s_addr, nfr, i < hi ? i : hi - 1);
+                        }
+                    }
+                    uint32_t subs[L2S_ITEMS], ranks[L2S_ITEMS];
+                    bool valid[L2S_ITEMS];
 #pragma unroll
                     for (int j = 0; j < L2S_ITEMS; j++) {
-                        const uint32_t i = base + L2S_TILE + j * L2S_NT + threadIdx.x;
-                        tn[j] = ld_tuple(sg.tuples + (i < hi ? i : hi - 1));
+                        valid[j] = base + j * L2S_NT + threadIdx.x < hi;
+                        subs[j] = sub_of(cell_hash(eval_tuple(P.g, P.entries, t[j]).key), f2);
+                        ranks[j] = 0;
+                        if (valid[j]) ranks[j] = atomicAdd(&s_cnt[subs[j]], 1u);
                     }
-                }
-                uint32_t subs[L2S_ITEMS], ranks[L2S_ITEMS];
-                bool valid[L2S_ITEMS];
-#pragma unroll
-                for (int j = 0; j < L2S_ITEMS; j++) {
-                    valid[j] = base + j * L2S_NT + threadIdx.x < hi;
-                    subs[j] = sub_of(cell_hash(eval_tuple(P.g, P.entries, t[j]).key), f2);
-                    if (valid[j]) ranks[j] = atomicAdd(&s_cnt[subs[j]], 1u);
-                }
-                __syncthreads();
-                {  // exclusive scan of the tile's counts over the sub-partitions (BPT per thread)
-                    const uint32_t s0 = threadIdx.x * BPT;
-                    uint32_t v[BPT], mine = 0;
-#pragma unroll
-                    for (int q = 0; q < BPT; q++) v[q] = s_cnt[s0 + q], mine += v[q];
-                    uint32_t incl = mine;
-#pragma unroll
-                    for (int off = 1; off < 64; off <<= 1) {
-                        const uint32_t up = __shfl_up(incl, off, 64);
-                        if (lane >= off) incl += up;
-                    }
-                    if (lane == 63) s_wsum[wave] = incl;
                     __syncthreads();
-                    uint32_t before = incl - mine, total = 0;
-                    for (int w = 0; w < L2S_NT / 64; w++) {
-                        before += w < wave ? s_wsum[w] : 0;
-                        total += s_wsum[w];
+                    {  // exclusive scan of the tile's counts over the sub-partitions (BPT per thread)
+                        const uint32_t s0 = threadIdx.x * BPT;
+                        uint32_t v[BPT], mine = 0;
+#pragma unroll
+                        for (int q = 0; q < BPT; q++) v[q] = s_cnt[s0 + q], mine += v[q];
+                        uint32_t incl = mine;
+#pragma unroll
+                        for (int off = 1; off < 64; off <<= 1) {
+                            const uint32_t up = __shfl_up(incl, off, 64);
+                            if (lane >= off) incl += up;
+                        }
+                        if (lane == 63) s_wsum[wave] = incl;
+                        __syncthreads();
+                        uint32_t before = incl - mine, total = 0;
+                        for (int w = 0; w < L2S_NT / 64; w++) {
+                            before += w < wave ? s_wsum[w] : 0;
+                            total += s_wsum[w];
+                        }
+#pragma unroll
+                        for (int q = 0; q < BPT; q++) {
+                            s_base[s0 + q] = before;
+                            s_cnt[s0 + q] = 0;
+                            before += v[q];
+                        }
+                        if (threadIdx.x == 0) s_total = total;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < L2S_ITEMS; j++) {
+                        if (!valid[j]) continue;
+                        const uint32_t at = s_base[subs[j]] + ranks[j];
+                        s_xyzi[at] = make_uint4((uint32_t)t[j].x, (uint32_t)t[j].y, (uint32_t)t[j].z, t[j].idx);
+                        s_attr[at] = make_uint2(t[j].w0, t[j].w1);
+                        const uint32_t within = s_cur[subs[j]] + ranks[j];  // place in the sub-partition's region
+                        s_tpos[at] = within < cap ? subs[j] * cap + within : 0xffffffffu;
                     }
 #pragma unroll
-                    for (int q = 0; q < BPT; q++) {
-                        s_base[s0 + q] = before;
-                        s_cnt[s0 + q] = 0;
-                        before += v[q];
+                    for (int j = 0; j < L2S_ITEMS; j++) {  // the next tile has arrived — before this tile's stores are issued
+                        t[j] = tn[j];
+                        asm volatile("" ::"v"(t[j].x), "v"(t[j].w0), "v"(t[j].w1));
                     }
-                    if (threadIdx.x == 0) s_total = total;
-                }
-                __syncthreads();
+                    __syncthreads();
+                    {  // the cursors move on (a thread's sub-partitions: their tile counts are s_base differences)
+                        const uint32_t s0 = threadIdx.x * BPT, total = s_total;
 #pragma unroll
-                for (int j = 0; j < L2S_ITEMS; j++) {
-                    if (!valid[j]) continue;
-                    const uint32_t at = s_base[subs[j]] + ranks[j];
-                    s_xyzi[at] = make_uint4((uint32_t)t[j].x, (uint32_t)t[j].y, (uint32_t)t[j].z, t[j].idx);
-                    s_attr[at] = make_uint2(t[j].w0, t[j].w1);
-                    const uint32_t within = s_cur[subs[j]] + ranks[j];  // place in the sub-partition's region
-                    s_tpos[at] = within < cap ? subs[j] * cap + within : 0xffffffffu;
-                }
-#pragma unroll
-                for (int j = 0; j < L2S_ITEMS; j++) {  // the next tile has arrived — before this tile's stores are issued
-                    t[j] = tn[j];
-                    asm volatile("" ::"v"(t[j].x), "v"(t[j].w0));
-                }
-                __syncthreads();
-                {  // the cursors move on (a thread's sub-partitions: their tile counts are s_base differences)
-                    const uint32_t s0 = threadIdx.x * BPT, total = s_total;
-#pragma unroll
-                    for (int q = 0; q < BPT; q++) {
-                        const uint32_t lo_b = s_base[s0 + q], hi_b = s0 + q + 1 < L2_STAGED_F2 ? s_base[s0 + q + 1] : total;
-                        s_cur[s0 + q] += hi_b - lo_b;
-                        if (s_cur[s0 + q] > cap) s_overflow = 1;
+                        for (int q = 0; q < BPT; q++) {
+                            const uint32_t lo_b = s_base[s0 + q], hi_b = s0 + q + 1 < L2_STAGED_F2 ? s_base[s0 + q + 1] : total;
+                            s_cur[s0 + q] += hi_b - lo_b;
+                            if (s_cur[s0 + q] > cap) s_overflow = 1;
+                        }
+                        for (uint32_t k = threadIdx.x; k < total; k += L2S_NT) {
+                            const uint32_t tp = s_tpos[k];
+                            if (tp == 0xffffffffu) continue;  // beyond the region: the fold's result will not be used
+                            const uint4 a = s_xyzi[k];
+                            const uint2 b = s_attr[k];
+                            uint8_t *q = P.out + (region0 + tp) * ts_out;
+                            u32x4_a4 va = {a.x, a.y, a.z, a.w};
+                            *(PCQ_GLOBAL u32x4_a4 *)q = va;
+                            *(PCQ_GLOBAL uint32_t *)(q + 16) = b.x;
+                            if (wide_out) *(PCQ_GLOBAL uint32_t *)(q + 20) = b.y;
+                        }
                     }
-                    for (uint32_t k = threadIdx.x; k < total; k += L2S_NT) {
-                        const uint32_t tp = s_tpos[k];
-                        if (tp == 0xffffffffu) continue;  // beyond the region: the fold's result will not be used
-                        const uint4 a = s_xyzi[k];
-                        const uint2 b = s_attr[k];
-                        uint8_t *q = reinterpret_cast<uint8_t *>(P.out) + (region0 + tp) * sizeof(GridTuple);
-                        u32x4_a8 va = {a.x, a.y, a.z, a.w};
-                        *(PCQ_GLOBAL u32x4_a8 *)q = va;
-                        u32x2 vb = {b.x, b.y};
-                        *(PCQ_GLOBAL u32x2 *)(q + 16) = vb;
-                    }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
+            // the next window: at the fragment tuple `hi` of the bin lies in
+            if (hi == wend) f_lo += nfr;
+            else f_lo += frag_find(s_pre, nfr, hi);
+            j0 = hi;
+            __syncthreads();  // the window is rewritten
         }
         for (uint32_t sp = threadIdx.x; sp < f2; sp += L2S_NT) {
             const uint32_t n = s_cur[sp];
@@ -1192,9 +1201,8 @@ __global__ __launch_bounds__(BLOCK) void k_old_per_bin(const uint32_t *__restric
 // the fold: one workgroup per partition, open-addressing table in LDS
 // ---------------------------------------------------------------------------------------------------------------
 struct FoldParams {
-    const GridSeg *segs;
-    int nsegs;
-    GridSeg seg0;                  // segs[0] again, in the kernel arguments: one dependent load fewer when nsegs == 1
+    BinSrc src;                    // BINS: partition p = level-1 bin p of pass 0's output
+    GridSeg seg;                   // otherwise: partition p of the second level's output
     EntryRef entries;
     GridRef g;
     // earlier winners by partition (okeys == nullptr: none)
@@ -1208,7 +1216,7 @@ struct FoldParams {
     const uint64_t *wbase;
     uint32_t *wcount;
     uint32_t *palias;              // [P] 1: the partition holds aliased keys
-    uint32_t *pay_scratch;         // BIG: the parked payloads, 5 words per slot and partition
+    uint32_t *pay_scratch;         // the parked payloads, 5 words per slot and resident workgroup
     unsigned long long *stats;     // [0] winners, [1] partitions that overflowed the LDS table, [2] partitions with aliased keys,
                                    // [3] partitions k_fold_dense left to k_fold
     uint32_t *defer_list;          // k_fold_dense: the partitions it leaves; k_fold: fold these (stats[3] of them) instead of 0..nparts
@@ -1231,45 +1239,102 @@ __device__ __forceinline__ int lds_find_or_insert(uint64_t *s_key, uint64_t key,
     return -1;
 }
 
+// One chunk of a partition's tuples into the table (the general path of k_fold): tuple k * NT + thread of the chunk is tu[k].
+//   phase 1  cells and their minimum distance: atomicMin on the f64 bits after a plain read — a tuple above the minimum it
+//            sees is out (the minimum only falls), which is nearly all of a coarse grid's
+//   phase 2  among the tuples at the minimum, the earliest in file order
+//   phase 3  a winner from this chunk parks its payload
+// No barrier behind phase 3: the next chunk's phase 1 can only make its test fail for a slot whose winner is about to be
+// replaced, and every thread passes the next barrier before anyone parks again.
+template <int NSLOT, int NT, int FOLD_K, int LIMIT>
+__device__ __forceinline__ void fold_chunk(const FoldParams &P, const GridTuple (&tu)[FOLD_K], uint32_t cnt, uint64_t *s_key, uint64_t *s_dist,
+                                           uint64_t *s_ord, uint32_t *s_aliasbits, uint32_t *s_oldbits, uint32_t *s_ncell, uint32_t *s_over,
+                                           uint32_t *pay) {
+    uint64_t dbits[FOLD_K];
+    int slot[FOLD_K];
+#pragma unroll
+    for (int k = 0; k < FOLD_K; k++) {
+        const uint32_t i = k * NT + threadIdx.x;
+        slot[k] = -1;
+        dbits[k] = 0;
+        if (i >= cnt) continue;
+        const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
+        dbits[k] = ev.dbits;
+        const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, cell_hash(ev.key), s_ncell);
+        if (s < 0) {
+            *s_over = 1;
+            continue;
+        }
+        slot[k] = s;
+        if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
+        const uint64_t seen = __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a stale value is only too large)
+        if (ev.dbits < seen) {
+            const uint64_t old = atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
+            if (ev.dbits < old) s_ord[s] = ~0ull;  // a new minimum: whoever held the cell is out (racing writers store the same value)
+        } else if (ev.dbits > seen) {
+            slot[k] = -1;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < FOLD_K; k++) {
+        if (slot[k] < 0) continue;
+        if (dbits[k] == s_dist[slot[k]]) atomicMin((unsigned long long *)&s_ord[slot[k]], (unsigned long long)ord_of(tu[k]));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < FOLD_K; k++) {
+        const int s = slot[k];
+        if (s < 0) continue;
+        if (dbits[k] == s_dist[s] && s_ord[s] == ord_of(tu[k])) {
+            pay[s * 5] = (uint32_t)tu[k].x, pay[s * 5 + 1] = (uint32_t)tu[k].y, pay[s * 5 + 2] = (uint32_t)tu[k].z;
+            pay[s * 5 + 3] = tu[k].w0, pay[s * 5 + 4] = tu[k].w1;
+            atomicAnd(&s_oldbits[s >> 5], ~(1u << (s & 31)));
+        }
+    }
+}
+
 // Workgroups are persistent: each folds the partitions blockIdx.x, blockIdx.x + gridDim.x, ... (or the partitions
-// k_fold_dense left on its list); the offsets of the next partition are loaded while the current one is folded.  Tuples are
-// loaded chunk by chunk: a register prefetch of the next chunk (CPF, lab) measured 1.72 -> 1.68 ms for the big shape at the
-// price of 40 spilled registers, and LOCKED (lab) is the big fold with a lock bit per slot instead of the phases.
-template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool PAY_LDS, bool DIRECT, bool CPF, bool LOCKED, int MIN_WAVES>
+// k_fold_dense left on its list).  BINS (the big shape): the partition is a level-1 bin read through the fragment window;
+// the window of the next chunk is asked for (into registers) while the current chunk is folded.  Otherwise the partition
+// is a piece of the second level's output, and its range is loaded while the partition before it is folded.
+template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool BINS, bool DIRECT, int MIN_WAVES>
 __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t nparts) {
     constexpr int SPT = (NSLOT + NT - 1) / NT;   // slots per thread in the compaction
     constexpr int CHUNK = NT * FOLD_K;
+    constexpr int FB = BINS ? BIG_FB : 1;
+    static_assert(!BINS || NT > BIG_FB, "one window entry per thread");
     __shared__ uint64_t s_key[NSLOT];
     __shared__ uint64_t s_dist[NSLOT];   // f64 bits of the best squared distance (monotone for d >= 0)
     __shared__ uint64_t s_ord[NSLOT];    // file order of the winner: 0 = an earlier fold's winner, ~0 = none yet
-    __shared__ uint32_t s_pay_lds[PAY_LDS ? NSLOT * 5 : 1];  // winner's x, y, z, w0, w1 — or, for an earlier winner, its index (two words)
     __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32], s_oldbits[(NSLOT + 31) / 32];
-    __shared__ uint32_t s_lock[LOCKED ? (NSLOT + 31) / 32 : 1];  // LOCKED: one bit per slot, held while a tuple replaces the slot's winner
+    __shared__ uint32_t s_pre[FB + 1];
+    __shared__ uint64_t s_addr[FB];
     __shared__ uint32_t s_ncell, s_over, s_wsum[NT / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const GridSeg sg0 = P.seg0;
-    if (LOCKED) {
-        for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_lock[t] = 0;  // (every holder releases: cleared once)
-    }
+    const GridSeg sg = P.seg;
+    const bool seg_wide = sg.wide;
+    const uint32_t seg_ts = tuple_bytes(seg_wide);
 
-    // pipeline state: the first segment's range and the output base of the current and the next partition,
-    // and the first chunk of the current partition's tuples
+    // pipeline state (second-level partitions): the range and the output base of the current and the next partition
     uint32_t cur_lo = 0, cur_cnt = 0, nxt_lo = 0, nxt_cnt = 0;
     uint64_t cur_out = 0, nxt_out = 0;
     if (P.defer_list) nparts = (uint32_t)P.stats[3];  // only what k_fold_dense left
     uint32_t it = blockIdx.x, p = 0, p_next = 0;
     if (it < nparts) {
         p_next = P.defer_list ? P.defer_list[it] : it;
-        cur_lo = sg0.off[p_next], cur_cnt = seg_count(sg0, p_next, cur_lo), cur_out = P.wbase[p_next];
+        if (!BINS) cur_lo = sg.off[p_next], cur_cnt = sg.cnt ? sg.cnt[p_next] : sg.off[p_next + 1] - cur_lo;
+        cur_out = P.wbase[p_next];
     }
     for (; it < nparts; it += gridDim.x) {
         p = p_next;
         const uint32_t pn = it + gridDim.x;
         if (pn < nparts) {
             p_next = P.defer_list ? P.defer_list[pn] : pn;
-            nxt_lo = sg0.off[p_next], nxt_cnt = seg_count(sg0, p_next, nxt_lo), nxt_out = P.wbase[p_next];
+            if (!BINS) nxt_lo = sg.off[p_next], nxt_cnt = sg.cnt ? sg.cnt[p_next] : sg.off[p_next + 1] - nxt_lo;
+            nxt_out = P.wbase[p_next];
         }
-        uint32_t *pay = PAY_LDS ? s_pay_lds : P.pay_scratch + (size_t)blockIdx.x * NSLOT * 5;  // HBM scratch of this workgroup
+        uint32_t *pay = P.pay_scratch + (size_t)blockIdx.x * NSLOT * 5;  // HBM scratch of this workgroup
         const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
         const uint64_t old_base = P.okeys ? P.obase[p] : 0;
         const uint64_t out_base = cur_out;
@@ -1304,10 +1369,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
         }
         if (n_old) __syncthreads();
 
-        // The common partition of a dense grid: one segment, at most one chunk of tuples, no earlier winners.  Every thread
+        // The common partition of a dense grid: at most one chunk of tuples, no earlier winners.  Every thread
         // still holds its tuples when the winners are known, so the winner of a cell writes its record straight from
-        // registers — no payload parked in LDS, no sweep over the table's slots.
-        if (DIRECT && P.nsegs == 1 && n_old == 0 && cur_cnt <= CHUNK) {
+        // registers — no payload parked, no sweep over the table's slots.
+        if (!BINS && DIRECT && n_old == 0 && cur_cnt <= (uint32_t)CHUNK) {
             const uint32_t cnt = cur_cnt;
             GridTuple tu[FOLD_K];
             uint64_t dbits[FOLD_K];
@@ -1315,12 +1380,13 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
 #pragma unroll
             for (int k = 0; k < FOLD_K; k++) {
                 const uint32_t i = k * NT + threadIdx.x;
-                tu[k] = ld_tuple(sg0.tuples + cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0)));
+                tu[k] = ld_tuple(sg.tuples + (uint64_t)(cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0))) * seg_ts, seg_wide);
             }
 #pragma unroll
             for (int k = 0; k < FOLD_K; k++) {  // phase 1: cells and their minimum distance
                 const uint32_t i = k * NT + threadIdx.x;
                 slot[k] = -1;
+                dbits[k] = 0;
                 if (i >= cnt) continue;
                 const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
                 dbits[k] = ev.dbits;
@@ -1393,128 +1459,63 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                 }
             }
         } else {
-            for (int r = 0; r < P.nsegs; r++) {
-                const GridSeg sg = r == 0 ? sg0 : P.segs[r];
-                const uint32_t lo = r == 0 ? cur_lo : ldg(sg.off + p), cnt = r == 0 ? cur_cnt : seg_count(sg, p, lo);
-                if (cnt == 0) continue;
-                GridTuple tn[CPF ? FOLD_K : 1];  // CPF: the next chunk's tuples, in flight while the current chunk is folded
-                if (CPF) {
+            // the partition's tuples chunk by chunk: `cnt` tuples per round, tuple i of the round through tuple_of(i)
+            uint32_t total_in = 0, f_lo = 0, j0 = 0, nfr = 0;
+            uint32_t reg_pre = 0;
+            uint64_t reg_addr = 0;
+            if (BINS) {
+                const BinSrc &S = P.src;
+                total_in = uni32(ldg(S.preT + (size_t)p * S.Tp1 + S.T));
+                nfr = S.T < (uint32_t)FB ? S.T : (uint32_t)FB;
+                if (threadIdx.x <= nfr) reg_pre = ldg(S.preT + (size_t)p * S.Tp1 + threadIdx.x);
+                if (threadIdx.x < nfr) reg_addr = frag_addr(S, p, threadIdx.x);
+            } else {
+                total_in = cur_cnt;
+            }
+            while (j0 < total_in) {  // (the same for every thread)
+                uint32_t cnt, j1;
+                if (BINS) {
+                    const BinSrc &S = P.src;
+                    if (threadIdx.x <= nfr) s_pre[threadIdx.x] = reg_pre;
+                    if (threadIdx.x < nfr) s_addr[threadIdx.x] = reg_addr;
+                    __syncthreads();
+                    const uint32_t wend = uni32(s_pre[nfr]);
+                    cnt = wend - j0 < (uint32_t)CHUNK ? wend - j0 : (uint32_t)CHUNK;
+                    j1 = j0 + cnt;
+                    // the next round's window starts at the fragment tuple j1 lies in; asked for now, stored when the round is over
+                    const uint32_t f_next = j1 == wend ? f_lo + nfr : f_lo + uni32(frag_find(s_pre, nfr, j1));
+                    const uint32_t nfr_next = S.T - f_next < (uint32_t)FB ? S.T - f_next : (uint32_t)FB;
+                    if (j1 < total_in) {
+                        if (threadIdx.x <= nfr_next) reg_pre = ldg(S.preT + (size_t)p * S.Tp1 + f_next + threadIdx.x);
+                        if (threadIdx.x < nfr_next) reg_addr = frag_addr(S, p, f_next + threadIdx.x);
+                    }
+                    if (cnt == 0) {  // a window of empty fragments
+                        f_lo = f_next, nfr = nfr_next;
+                        __syncthreads();  // (everyone has read the window before it is rewritten)
+                        continue;
+                    }
+                    GridTuple tu[FOLD_K];
 #pragma unroll
                     for (int k = 0; k < FOLD_K; k++) {
                         const uint32_t i = k * NT + threadIdx.x;
-                        tn[CPF ? k : 0] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
+                        tu[k] = frag_ld_tuple(s_pre, s_addr, nfr, j0 + (i < cnt ? i : cnt - 1));
                     }
-                }
-                for (uint32_t c0 = 0; c0 < cnt; c0 += CHUNK) {
+                    f_lo = f_next, nfr = nfr_next;
+                    fold_chunk<NSLOT, NT, FOLD_K, LIMIT>(P, tu, cnt, s_key, s_dist, s_ord, s_aliasbits, s_oldbits, &s_ncell, &s_over, pay);
+                } else {
+                    cnt = total_in - j0 < (uint32_t)CHUNK ? total_in - j0 : (uint32_t)CHUNK;
+                    j1 = j0 + cnt;
                     GridTuple tu[FOLD_K];
-                    uint64_t dbits[FOLD_K];
-                    int slot[FOLD_K];
-                    if (CPF) {
-#pragma unroll
-                        for (int k = 0; k < FOLD_K; k++) tu[k] = tn[CPF ? k : 0];
-                        if (c0 + CHUNK < cnt) {
-#pragma unroll
-                            for (int k = 0; k < FOLD_K; k++) {
-                                const uint32_t i = c0 + CHUNK + k * NT + threadIdx.x;
-                                tn[CPF ? k : 0] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < FOLD_K; k++) {
-                            const uint32_t i = c0 + k * NT + threadIdx.x;
-                            tu[k] = ld_tuple(sg.tuples + lo + (i < cnt ? i : cnt - 1));
-                        }
-                    }
-                    // phase 1: cells and their minimum distance
 #pragma unroll
                     for (int k = 0; k < FOLD_K; k++) {
-                        const uint32_t i = c0 + k * NT + threadIdx.x;
-                        slot[k] = -1;
-                        if (i >= cnt) continue;
-                        const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
-                        dbits[k] = ev.dbits;
-                        const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, cell_hash(ev.key), &s_ncell);
-                        if (s < 0) {
-                            s_over = 1;
-                            continue;
-                        }
-                        slot[k] = s;
-                        if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
-                        // most tuples of a coarse grid cannot lower the minimum: a plain read first (a stale value is only too large)
-                        const uint64_t seen = __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (LOCKED) {
-                            // No phases and no barriers between the chunks: a tuple that can still win (at or below the minimum
-                            // it sees) takes the slot's lock bit, compares (distance, file order) with what the slot holds and,
-                            // if it is earlier, becomes the slot's winner — payload included — before it lets go.  The 64 lanes
-                            // of a wave retry together; whoever gets a bit finishes and releases it in the same round, so lanes
-                            // (and waves) that want the same slot pass one after the other.
-                            const uint64_t ord = ord_of(tu[k]);
-                            const uint32_t bit = 1u << (s & 31);
-                            bool pending = ev.dbits <= seen;
-                            // The loop condition is the same for the whole wave (a vote), and the holder releases inside the
-                            // round it acquired in: a loop that each lane leaves on its own can be compiled into "spin until
-                            // acquired, then the critical section behind the loop", which never ends when two lanes of one wave
-                            // want the same slot.  A bound on the rounds turns anything unforeseen into an error, not a hang.
-                            for (uint32_t round = 0; __any(pending); round++) {
-                                bool got = false;
-                                if (pending) {
-                                    const uint32_t held = __hip_atomic_fetch_or(&s_lock[s >> 5], bit, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    got = !(held & bit);
-                                }
-                                if (got) {
-                                    const uint64_t cd = __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    const uint64_t co = __hip_atomic_load(&s_ord[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    if (ev.dbits < cd || (ev.dbits == cd && ord < co)) {
-                                        __hip_atomic_store(&s_dist[s], ev.dbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                        __hip_atomic_store(&s_ord[s], ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                        pay[s * 5] = (uint32_t)tu[k].x, pay[s * 5 + 1] = (uint32_t)tu[k].y, pay[s * 5 + 2] = (uint32_t)tu[k].z;
-                                        pay[s * 5 + 3] = tu[k].w0, pay[s * 5 + 4] = tu[k].w1;
-                                        atomicAnd(&s_oldbits[s >> 5], ~bit);
-                                        // (payload parked in HBM: the next holder's stores must land after these — acknowledged first)
-                                        if (!PAY_LDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                                    }
-                                    __hip_atomic_fetch_and(&s_lock[s >> 5], ~bit, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    pending = false;
-                                }
-                                if (round > (1u << 24)) {  // (a holder's critical section is microseconds)
-                                    if (pending) atomicAdd(&P.stats[6], 1ull);
-                                    pending = false;
-                                }
-                            }
-                            slot[k] = -1;
-                        } else if (ev.dbits < seen) {
-                            const uint64_t old = atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
-                            if (ev.dbits < old) s_ord[s] = ~0ull;  // a new minimum: whoever held the cell is out (racing writers store the same value)
-                        } else if (ev.dbits > seen) {
-                            slot[k] = -1;  // the minimum only falls: this tuple is out of phases 2 and 3 (nearly all of a coarse grid's are)
-                        }
+                        const uint32_t i = k * NT + threadIdx.x;
+                        tu[k] = ld_tuple(sg.tuples + (uint64_t)(cur_lo + j0 + (i < cnt ? i : cnt - 1)) * seg_ts, seg_wide);
                     }
-                    if (LOCKED) continue;  // (everything happened under the locks)
-                    __syncthreads();
-                    // phase 2: among the tuples at the minimum, the earliest in file order
-#pragma unroll
-                    for (int k = 0; k < FOLD_K; k++) {
-                        if (slot[k] < 0) continue;
-                        if (dbits[k] == s_dist[slot[k]]) atomicMin((unsigned long long *)&s_ord[slot[k]], (unsigned long long)ord_of(tu[k]));
-                    }
-                    __syncthreads();
-                    // phase 3: a winner from this chunk parks its payload
-#pragma unroll
-                    for (int k = 0; k < FOLD_K; k++) {
-                        const int s = slot[k];
-                        if (s < 0) continue;
-                        if (dbits[k] == s_dist[s] && s_ord[s] == ord_of(tu[k])) {
-                            pay[s * 5] = (uint32_t)tu[k].x, pay[s * 5 + 1] = (uint32_t)tu[k].y, pay[s * 5 + 2] = (uint32_t)tu[k].z;
-                            pay[s * 5 + 3] = tu[k].w0, pay[s * 5 + 4] = tu[k].w1;
-                            atomicAnd(&s_oldbits[s >> 5], ~(1u << (s & 31)));
-                        }
-                    }
-                    // no barrier here: the next chunk's phase 1 can only make this test fail for a slot whose winner is
-                    // about to be replaced, and every thread passes the barrier behind it before anyone parks again
+                    fold_chunk<NSLOT, NT, FOLD_K, LIMIT>(P, tu, cnt, s_key, s_dist, s_ord, s_aliasbits, s_oldbits, &s_ncell, &s_over, pay);
                 }
+                j0 = j1;
             }
-            if (!PAY_LDS) __threadfence();  // the parked payloads are read back by other threads of the workgroup
+            __threadfence();  // the parked payloads are read back by other threads of the workgroup
             __syncthreads();
             if (s_over) {  // more cells than the table holds: the host repeats the fold with more partitions
                 if (threadIdx.x == 0) {
@@ -1565,8 +1566,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                     } else {
                         uint32_t w[5];
 #pragma unroll
-                        for (int q = 0; q < 5; q++)
-                            w[q] = PAY_LDS ? pay[s * 5 + q] : __hip_atomic_load(&pay[s * 5 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int q = 0; q < 5; q++) w[q] = __hip_atomic_load(&pay[s * 5 + q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (old) {
                             const uint64_t oi = (uint64_t)w[0] | ((uint64_t)w[1] << 32);
                             const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + oi * 32);
@@ -1623,7 +1623,8 @@ __device__ __forceinline__ uint32_t lds_insert_dense(uint64_t *s_key, uint64_t k
 }
 
 struct DenseParams {
-    const GridTuple *tuples;       // the second level's output: partition p = tuples[off[p] .. off[p] + cnt[p])
+    const uint8_t *tuples;         // the second level's output: partition p = tuples off[p] .. off[p] + cnt[p]
+    uint32_t wide;                 // of 24 bytes (20 otherwise)
     const uint32_t *off;           // (cnt == nullptr: .. off[p + 1])
     const uint32_t *cnt;
     EntryRef entries;
@@ -1635,7 +1636,6 @@ struct DenseParams {
     uint32_t *palias;
     unsigned long long *stats;
     uint32_t *defer_list;
-    uint32_t lab_flags;            // libpcq_lab.so experiments (grid_variant >> 4); 0 in the product
 };
 template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool PREFETCH, int MIN_WAVES>
 __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uint32_t nparts) {
@@ -1646,7 +1646,9 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32];
     __shared__ uint32_t s_ncell, s_wsum[NT / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const GridTuple *tuples = P.tuples;
+    const uint8_t *tuples = P.tuples;
+    const bool wide = P.wide;
+    const uint32_t ts = tuple_bytes(wide);
     const uint32_t *off = P.off;
     for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
     for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
@@ -1657,8 +1659,6 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     uint64_t cur_out = 0, nxt_out = 0;
     uint32_t p = blockIdx.x;
     // (the partition's range and output base are the same for the whole workgroup: scalar registers)
-    auto uni32 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    auto uni64 = [&](uint64_t v) { return (uint64_t)uni32((uint32_t)v) | ((uint64_t)uni32((uint32_t)(v >> 32)) << 32); };
     const uint32_t *cntp = P.cnt;
     if (p < nparts) cur_lo = uni32(off[p]), cur_cnt = cntp ? uni32(cntp[p]) : uni32(off[p + 1]) - cur_lo, cur_out = uni64(P.wbase[p]);
     GridTuple tn[PREFETCH ? FOLD_K : 1];  // PREFETCH: the tuples of the partition after the current one, in flight while it is folded
@@ -1666,7 +1666,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
 #pragma unroll
         for (int k = 0; k < FOLD_K; k++) {
             const uint32_t i = k * NT + threadIdx.x;
-            tn[PREFETCH ? k : 0] = ld_tuple(tuples + cur_lo + (i < cur_cnt ? i : (cur_cnt ? cur_cnt - 1 : 0)));
+            tn[PREFETCH ? k : 0] = ld_tuple(tuples + (uint64_t)(cur_lo + (i < cur_cnt ? i : (cur_cnt ? cur_cnt - 1 : 0))) * ts, wide);
         }
     }
     for (; p < nparts; p += gridDim.x) {
@@ -1681,7 +1681,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
 #pragma unroll
                 for (int k = 0; k < FOLD_K; k++) {
                     const uint32_t i = k * NT + threadIdx.x;
-                    tn[PREFETCH ? k : 0] = ld_tuple(tuples + nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0)));
+                    tn[PREFETCH ? k : 0] = ld_tuple(tuples + (uint64_t)(nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0))) * ts, wide);
                 }
             }
         }
@@ -1696,7 +1696,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
 #pragma unroll
             for (int k = 0; k < FOLD_K; k++) {
                 const uint32_t i = k * NT + threadIdx.x;
-                tu[k] = ld_tuple(tuples + cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0)));
+                tu[k] = ld_tuple(tuples + (uint64_t)(cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0))) * ts, wide);
             }
         }
         uint32_t inexact = 0;  // bit k: tuple k is next to a cell boundary (or outside the short computation's range)
@@ -1809,7 +1809,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
                 int32_t x = tu[k].x, y = tu[k].y, z = tu[k].z;
                 uint32_t w0 = tu[k].w0;
                 asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w0));
-                if (!(P.lab_flags & 1)) st_record(dst, P.entries.get((w0 >> 8) & 0xff), x, y, z, w0, tu[k].w1, R_HAS);
+                st_record(dst, P.entries.get((w0 >> 8) & 0xff), x, y, z, w0, tu[k].w1, R_HAS);
             }
             s_key[sl] = PCQ_EMPTY_KEY, s_dist[sl] = ~0ull, s_ord[sl] = ~0ull;
             o++;
@@ -1824,13 +1824,17 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     if (threadIdx.x == 0 && winners) atomicAdd(&P.stats[0], winners);
 }
 
+
 // ---------------------------------------------------------------------------------------------------------------
 // aliased keys: exact sequential replay (grid_sampling.rs:72-103), rare
 // ---------------------------------------------------------------------------------------------------------------
 // The tuples of this fold that belong to aliased keys: counted (EMIT = false) or appended to `list` (EMIT = true).
-template <bool EMIT>
+// BINS: the partitions are pass 0's bins (no second level), otherwise pieces of the second level's output.
+template <bool EMIT, bool BINS>
 __global__ __launch_bounds__(L2_NT) void k_alias_gather(FoldParams P, AliasItem *__restrict__ list, unsigned long long *__restrict__ cursor) {
     __shared__ uint64_t s_akeys[BIG_LIMIT];
+    __shared__ uint32_t s_pre[L2_FB + 1];
+    __shared__ uint64_t s_addr[L2_FB];
     __shared__ uint32_t s_n;
     const uint32_t p = blockIdx.x;
     if (!P.palias[p]) return;
@@ -1843,24 +1847,27 @@ __global__ __launch_bounds__(L2_NT) void k_alias_gather(FoldParams P, AliasItem 
     __syncthreads();
     const uint32_t na = s_n;
     uint32_t mine = 0;
-    for (int r = 0; r < P.nsegs; r++) {
-        const GridSeg sg = P.segs[r];
-        const uint32_t lo = sg.off[p], hi = lo + seg_count(sg, p, lo);
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += L2_NT) {
-            const GridTuple t = ld_tuple(sg.tuples + i);
-            const uint64_t key = eval_tuple(P.g, P.entries, t).key;
-            bool hit = false;
-            for (uint32_t q = 0; q < na && !hit; q++) hit = s_akeys[q] == key;
-            if (!hit) continue;
-            if (EMIT) {
-                AliasItem it;
-                it.key = key, it.ord = ord_of(t);
-                it.x = t.x, it.y = t.y, it.z = t.z, it.w0 = t.w0, it.w1 = t.w1, it._pad = 0;
-                list[atomicAdd(cursor, 1ull)] = it;
-            } else {
-                mine++;
-            }
+    auto visit = [&](const GridTuple &t) {
+        const uint64_t key = eval_tuple(P.g, P.entries, t).key;
+        bool hit = false;
+        for (uint32_t q = 0; q < na && !hit; q++) hit = s_akeys[q] == key;
+        if (!hit) return;
+        if (EMIT) {
+            AliasItem it;
+            it.key = key, it.ord = ord_of(t);
+            it.x = t.x, it.y = t.y, it.z = t.z, it.w0 = t.w0, it.w1 = t.w1, it._pad = 0;
+            list[atomicAdd(cursor, 1ull)] = it;
+        } else {
+            mine++;
         }
+    };
+    if (BINS) {
+        bin_for_each<L2_NT, L2_FB, 1>(P.src, p, s_pre, s_addr, visit);
+    } else {
+        const GridSeg sg = P.seg;
+        const bool wide = sg.wide;
+        const uint32_t lo = sg.off[p], hi = lo + (sg.cnt ? sg.cnt[p] : sg.off[p + 1] - lo);
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += L2_NT) visit(ld_tuple(sg.tuples + (uint64_t)i * tuple_bytes(wide), wide));
     }
     if (!EMIT && mine) atomicAdd(cursor, (unsigned long long)mine);
 }
@@ -1968,15 +1975,17 @@ __global__ __launch_bounds__(BLOCK) void k_drain(const uint64_t *__restrict__ wk
     }
 }
 
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-struct GridRun {
-    GridTuple *tuples;
-    uint64_t cap;      // tuples the run has room for (= points scanned)
-    uint32_t *binoff;  // device, F1 + 1
+struct GridRun {       // the output of one pass-0 launch
+    uint8_t *tuples;   // ntiles blocks of P0_TILE tuples
+    uint16_t *dir;     // ntiles directory rows
+    uint32_t ntiles;
+    uint32_t wide;     // 24-byte tuples (the scan had a colour column)
 };
 
 struct GridState {
@@ -1985,11 +1994,12 @@ struct GridState {
     std::vector<GridEntryDev> entries;
     std::vector<uint64_t> entry_base;  // first file-order index of each entry
     uint64_t entry_end = 0;            // index behind the last point scanned into the last entry
-    std::vector<void *> slabs;         // pool blocks holding the tuples
+    std::vector<void *> slabs;         // pool blocks holding the blocks and directory rows
     uint8_t *slab_cur = nullptr;
     size_t slab_left = 0;
-    uint64_t pending_cap = 0;
-    uint32_t *binoff_store = nullptr;  // MAX_RUNS x (F1 + 1)
+    uint64_t pending_cap = 0;          // points scanned into the pending runs (= the most tuples they can hold)
+    uint64_t pending_tiles = 0;
+    bool any_wide = false;
     // folded winners, grouped by partition
     uint64_t *wkeys = nullptr;
     uint8_t *wrecs = nullptr;
@@ -2005,6 +2015,8 @@ static void grid_free_pending(pcq_ctx *ctx, GridState *gs) {
     gs->slab_cur = nullptr;
     gs->slab_left = 0;
     gs->pending_cap = 0;
+    gs->pending_tiles = 0;
+    gs->any_wide = false;
     gs->runs.clear();
     gs->entries.clear();
     gs->entry_base.clear();
@@ -2025,7 +2037,6 @@ void pcq_grid_release(pcq_collector *c) {
     if (!c->gs) return;
     grid_free_pending(c->ctx, c->gs);
     grid_free_winners(c->ctx, c->gs);
-    pcq_pool_free(c->ctx, c->gs->binoff_store);
     delete c->gs;
     c->gs = nullptr;
 }
@@ -2049,11 +2060,19 @@ struct Scratch {
     }
     void keep(void *p) { blocks.erase(std::remove(blocks.begin(), blocks.end(), p), blocks.end()); }
 };
+// Declared BEHIND a Scratch: whichever way the scope is left, the stream has drained before the Scratch hands its blocks
+// back to the pool ("a block may be freed only when the work that used it has completed").
+struct StreamDrainOnExit {
+    hipStream_t s;
+    explicit StreamDrainOnExit(hipStream_t stream) : s(stream) {}
+    ~StreamDrainOnExit() { (void)hipStreamSynchronize(s); }
+};
 
 static int grid_fold(pcq_ctx *ctx, pcq_collector *c);
 
-static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, GridTuple **out) {
-    const size_t bytes = (size_t)tuples * sizeof(GridTuple);
+// `bytes` of the pending slabs, 256-byte aligned
+static int grid_room(pcq_ctx *ctx, GridState *gs, size_t bytes, void **out) {
+    bytes = (bytes + 255) & ~(size_t)255;
     if (bytes > gs->slab_left) {
         size_t slab = 256ull << 20;
         if (slab < bytes) slab = bytes;
@@ -2064,10 +2083,9 @@ static int grid_tuple_room(pcq_ctx *ctx, GridState *gs, uint64_t tuples, GridTup
         gs->slab_cur = (uint8_t *)p;
         gs->slab_left = slab;
     }
-    *out = (GridTuple *)gs->slab_cur;
-    const size_t used = (bytes + 255) & ~(size_t)255;
-    gs->slab_cur += used < gs->slab_left ? used : gs->slab_left;
-    gs->slab_left -= used < gs->slab_left ? used : gs->slab_left;
+    *out = gs->slab_cur;
+    gs->slab_cur += bytes;
+    gs->slab_left -= bytes;
     return PCQ_OK;
 }
 
@@ -2075,7 +2093,8 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
     if (cols_in.n == 0) return PCQ_OK;
     if (!c->gs) c->gs = new GridState();
     GridState *gs = c->gs;
-    const uint64_t budget = ctx->grid_pending_budget > 0 ? (uint64_t)ctx->grid_pending_budget : (384ull << 20);  // tuples: 9 GB
+    uint64_t budget = ctx->grid_pending_budget > 0 ? (uint64_t)ctx->grid_pending_budget : (384ull << 20);  // points: 7.7 - 9.2 GB of tuples
+    if (budget > PENDING_MAX) budget = PENDING_MAX;  // (a fold's tuple counts and offsets are 32-bit)
     for (uint64_t first = 0; first < cols_in.n; first += RUN_POINTS) {
         DevCols cols = cols_in;
         cols.n = cols_in.n - first < RUN_POINTS ? cols_in.n - first : RUN_POINTS;
@@ -2083,21 +2102,39 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         cols.xyz = cols_in.xyz ? cols_in.xyz + first * cols_in.xyz_stride : nullptr;
         cols.cls = cols_in.cls ? cols_in.cls + first * cols_in.cls_stride : nullptr;
         cols.rgb = cols_in.rgb ? cols_in.rgb + first * cols_in.rgb_stride : nullptr;
+        const uint32_t ntiles = (uint32_t)((cols.n + P0_TILE - 1) / P0_TILE);
+        const bool wide = cols.rgb != nullptr;
+        const size_t tuple_room = (size_t)ntiles * P0_TILE * tuple_bytes(wide) + 64, dir_room = (size_t)ntiles * DIR_STRIDE * sizeof(uint16_t);
         // the entry: scans of one file share it (same scale / offset, indices within 32 bits of its base)
-        bool fresh = gs->entries.empty();
-        if (!fresh) {
+        auto needs_entry = [&]() {
+            if (gs->entries.empty()) return true;
             const GridEntryDev &e = gs->entries.back();
-            fresh = memcmp(e.scale, cols.scale, sizeof e.scale) != 0 || memcmp(e.offset, cols.offset, sizeof e.offset) != 0 ||
-                    cols.first_index < gs->entry_end || cols.first_index + cols.n - gs->entry_base.back() > 0xffffffffull;
-        }
-        if ((fresh && gs->entries.size() == 255) || gs->runs.size() == (size_t)MAX_RUNS ||
-            (gs->pending_cap && gs->pending_cap + cols.n > budget)) {
+            return memcmp(e.scale, cols.scale, sizeof e.scale) != 0 || memcmp(e.offset, cols.offset, sizeof e.offset) != 0 ||
+                   cols.first_index < gs->entry_end || cols.first_index + cols.n - gs->entry_base.back() > 0xffffffffull;
+        };
+        if ((needs_entry() && gs->entries.size() == 255) || gs->runs.size() == (size_t)MAX_RUNS || (gs->pending_cap && gs->pending_cap + cols.n > budget)) {
             c->last_stream = s;
             const int frc = grid_fold(ctx, c);
             if (frc) return frc;
-            fresh = true;
         }
-        if (fresh) {
+        GridRun run{};
+        run.ntiles = ntiles, run.wide = wide;
+        auto alloc_run = [&]() {
+            void *pt = nullptr, *pd = nullptr;
+            int arc = grid_room(ctx, gs, tuple_room, &pt);
+            if (!arc) arc = grid_room(ctx, gs, dir_room, &pd);
+            run.tuples = (uint8_t *)pt, run.dir = (uint16_t *)pd;
+            return arc;
+        };
+        int rc = alloc_run();
+        if (rc == PCQ_ERR_NOMEM && !gs->runs.empty()) {  // no room next to what is pending: fold that first (its slabs go back to the pool)
+            c->last_stream = s;
+            const int frc = grid_fold(ctx, c);
+            if (frc) return frc;
+            rc = alloc_run();
+        }
+        if (rc) return rc;
+        if (needs_entry()) {
             GridEntryDev e;
             for (int a = 0; a < 3; a++) e.scale[a] = cols.scale[a], e.offset[a] = cols.offset[a];
             gs->entries.push_back(e);
@@ -2106,60 +2143,22 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         gs->entry_end = cols.first_index + cols.n;
         const uint32_t entry = (uint32_t)gs->entries.size() - 1;
         const uint64_t idx_base = cols.first_index - gs->entry_base.back();
-
-        if (!gs->binoff_store) {
-            void *p = nullptr;
-            const int rc = pcq_pool_alloc(ctx, (size_t)MAX_RUNS * (F1 + 1) * sizeof(uint32_t), &p);
-            if (rc) return rc;
-            gs->binoff_store = (uint32_t *)p;
-        }
-        if (!ctx->d_grid_cnt) PCQ_HIP(hipMalloc((void **)&ctx->d_grid_cnt, (size_t)(P0_MAX_BLOCKS + 1) * F1 * sizeof(uint32_t)));
-        GridRun run;
-        run.cap = cols.n;
-        run.binoff = gs->binoff_store + gs->runs.size() * (F1 + 1);
-        int rc = grid_tuple_room(ctx, gs, cols.n, &run.tuples);
-        if (rc) return rc;
         gs->pending_cap += cols.n;
+        gs->pending_tiles += ntiles;
+        gs->any_wide |= wide;
 
-        uint64_t nblocks = (cols.n + P0_TILE - 1) / P0_TILE;
-        uint64_t maxb = (uint64_t)ctx->num_cus;  // one scatter workgroup per CU is resident (LDS); each owns one piece of every bin
-#ifdef PCQ_LAB
-        if (ctx->grid_variant & (512 | 1024)) maxb = (uint64_t)ctx->num_cus * 2;  // the 2560-point tile shapes: two per CU
-#endif
-        if (maxb > P0_MAX_BLOCKS) maxb = P0_MAX_BLOCKS;
-        if (nblocks > maxb) nblocks = maxb;
-        uint64_t per_block = (cols.n + nblocks - 1) / nblocks;
-        const uint64_t tile_round = SC_NT * SC_ITEMS;  // whole tiles of the scatter (= two of the histogram pass)
-        per_block = (per_block + tile_round - 1) / tile_round * tile_round;
-        nblocks = (cols.n + per_block - 1) / per_block;
-        uint32_t *cnt = ctx->d_grid_cnt, *total = ctx->d_grid_cnt + (size_t)P0_MAX_BLOCKS * F1;
         const DevGrid &g = c->grid;
-        const dim3 gb((unsigned)nblocks), tb(SC_NT);  // the same workgroups (ranges of points) in the histogram pass and the scatter
-        if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL((k_p0_hist<PCQ_PRED_BOUNDS, SC_NT>), gb, tb, 0, s, cols, pred, g, per_block, cnt);
-        else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL((k_p0_hist<PCQ_PRED_CLASS, SC_NT>), gb, tb, 0, s, cols, pred, g, per_block, cnt);
-        else hipLaunchKernelGGL((k_p0_hist<PCQ_PRED_BOUNDS_F64, SC_NT>), gb, tb, 0, s, cols, pred, g, per_block, cnt);
-        hipLaunchKernelGGL(k_p0_scan_blocks, dim3(F1 / WAVES), dim3(BLOCK), 0, s, cnt, (int)nblocks, total);
-        hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, total, run.binoff, (uint32_t)F1);
-#define PCQ_P0_SCATTER(KIND, STREAM, NT, ITEMS) \
-    hipLaunchKernelGGL((k_p0_scatter<KIND, STREAM, NT, ITEMS>), gb, dim3(NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base)
-#ifdef PCQ_LAB
-        if ((ctx->grid_variant & 32) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, false, SC_NT, SC_ITEMS);  // plain loads of the positions
-        else if ((ctx->grid_variant & 2048) && pred.kind == PCQ_PRED_BOUNDS)  // streaming stores of the tuples
-            hipLaunchKernelGGL((k_p0_scatter<PCQ_PRED_BOUNDS, true, SC_NT, SC_ITEMS, 1>), gb, dim3(SC_NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
-        else if ((ctx->grid_variant & 16384) && pred.kind == PCQ_PRED_BOUNDS)  // whole-line stores with a carry per bin
-            hipLaunchKernelGGL(k_p0_scatter_lines<PCQ_PRED_BOUNDS>, gb, dim3(SL_NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
-        else if ((ctx->grid_variant & 8192) && pred.kind == PCQ_PRED_BOUNDS)  // WRONG results: whole lines at random places (timing experiment only)
-            hipLaunchKernelGGL((k_p0_scatter<PCQ_PRED_BOUNDS, true, SC_NT, SC_ITEMS, 3>), gb, dim3(SC_NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
-        else if ((ctx->grid_variant & 4096) && pred.kind == PCQ_PRED_BOUNDS)  // WRONG results: tiles written in one piece (timing experiment only)
-            hipLaunchKernelGGL((k_p0_scatter<PCQ_PRED_BOUNDS, true, SC_NT, SC_ITEMS, 2>), gb, dim3(SC_NT), 0, s, cols, pred, g, per_block, cnt, run.binoff, run.tuples, entry, idx_base);
-        else if ((ctx->grid_variant & 512) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, true, 256, 10);  // 2560-point tiles on 256 threads
-        else if ((ctx->grid_variant & 1024) && pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, true, 512, 5);  // 2560-point tiles on 512 threads
-        else
-#endif
-        if (pred.kind == PCQ_PRED_BOUNDS) PCQ_P0_SCATTER(PCQ_PRED_BOUNDS, true, SC_NT, SC_ITEMS);
-        else if (pred.kind == PCQ_PRED_CLASS) PCQ_P0_SCATTER(PCQ_PRED_CLASS, true, SC_NT, SC_ITEMS);
-        else PCQ_P0_SCATTER(PCQ_PRED_BOUNDS_F64, true, SC_NT, SC_ITEMS);
-#undef PCQ_P0_SCATTER
+        const unsigned nblocks = ntiles < (uint32_t)ctx->num_cus ? ntiles : (unsigned)ctx->num_cus;  // one workgroup per CU is resident (LDS)
+        const int agg = ctx->grid_agg;
+#define PCQ_P0(KIND)                                                                                                                        \
+    do {                                                                                                                                    \
+        if (wide) hipLaunchKernelGGL((k_p0_part<KIND, true>), dim3(nblocks), dim3(P0_NT), 0, s, cols, pred, g, ntiles, run.tuples, run.dir, entry, idx_base, agg);  \
+        else hipLaunchKernelGGL((k_p0_part<KIND, false>), dim3(nblocks), dim3(P0_NT), 0, s, cols, pred, g, ntiles, run.tuples, run.dir, entry, idx_base, agg);     \
+    } while (0)
+        if (pred.kind == PCQ_PRED_BOUNDS) PCQ_P0(PCQ_PRED_BOUNDS);
+        else if (pred.kind == PCQ_PRED_CLASS) PCQ_P0(PCQ_PRED_CLASS);
+        else PCQ_P0(PCQ_PRED_BOUNDS_F64);
+#undef PCQ_P0
         PCQ_HIP(hipGetLastError());
         gs->runs.push_back(run);
     }
@@ -2173,23 +2172,38 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     hipStream_t s = ctx->stream;
     if (c->last_stream && c->last_stream != s) PCQ_HIP(hipStreamSynchronize(c->last_stream));
     Scratch tmp(ctx);
+    StreamDrainOnExit drain_before_tmp(s);
     const int nruns = (int)gs->runs.size();
     const DevGrid &g = c->grid;
+    if (gs->pending_cap >= (1ull << 32)) return pcq_fail(PCQ_ERR_UNSUPPORTED, "grid collector: more than 2^32 pending tuples in one fold");
 
-    // run directory + entries
-    std::vector<GridSeg> hsegs(nruns);
-    for (int r = 0; r < nruns; r++) hsegs[r] = GridSeg{gs->runs[r].tuples, gs->runs[r].binoff, nullptr};
-    GridSeg *d_segs = nullptr;
+    // run directory, entries, the per-bin fragment lists
+    const uint32_t T = (uint32_t)gs->pending_tiles, Tp = (T + 63) & ~63u, Tp1 = (T + 1 + 63) & ~63u;
+    std::vector<DevRun> hruns(nruns);
+    {
+        uint32_t tile0 = 0;
+        for (int r = 0; r < nruns; r++) {
+            hruns[r] = DevRun{gs->runs[r].tuples, gs->runs[r].dir, tile0, gs->runs[r].ntiles, gs->runs[r].wide, 0};
+            tile0 += gs->runs[r].ntiles;
+        }
+    }
+    const bool any_wide = gs->any_wide;
+    DevRun *d_runs = nullptr;
     GridEntryDev *d_entries = nullptr;
-    uint32_t *d_bintot = nullptr, *d_binbase = nullptr;
+    uint32_t *d_bintot = nullptr, *d_binbase = nullptr, *d_preT = nullptr;
+    uint16_t *d_startT = nullptr;
+    uint64_t *d_tile_addr = nullptr;
     unsigned long long *d_stats = nullptr;
-    int rc = tmp.get(nruns + 1, &d_segs);
+    DevGrid *d_grid = nullptr;
+    int rc = tmp.get(nruns, &d_runs);
     if (!rc) rc = tmp.get(256, &d_entries);
     if (!rc) rc = tmp.get(F1, &d_bintot);
     if (!rc) rc = tmp.get(F1 + 1, &d_binbase);
     if (!rc) rc = tmp.get(8, &d_stats);
-    DevGrid *d_grid = nullptr;
     if (!rc) rc = tmp.get(1, &d_grid);
+    if (!rc) rc = tmp.get((size_t)F1 * Tp, &d_startT);
+    if (!rc) rc = tmp.get((size_t)F1 * Tp1, &d_preT);
+    if (!rc) rc = tmp.get(T, &d_tile_addr);
     if (rc) return rc;
     PCQ_HIP(hipMemcpyAsync(d_grid, &g, sizeof g, hipMemcpyHostToDevice, s));
     GridRef gref{};
@@ -2199,18 +2213,22 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         gref.f.mask[a] = (uint32_t)g.mask[a], gref.f.shift[a] = g.shift[a];
     }
     gref.f.cell_size = g.cell_size;
-    PCQ_HIP(hipMemcpyAsync(d_segs, hsegs.data(), nruns * sizeof(GridSeg), hipMemcpyHostToDevice, s));
+    PCQ_HIP(hipMemcpyAsync(d_runs, hruns.data(), nruns * sizeof(DevRun), hipMemcpyHostToDevice, s));
     PCQ_HIP(hipMemcpyAsync(d_entries, gs->entries.data(), gs->entries.size() * sizeof(GridEntryDev), hipMemcpyHostToDevice, s));
     EntryRef eref;
     eref.table = d_entries;
     eref.e0 = gs->entries[0];
-    hipLaunchKernelGGL(k_part_totals, dim3(F1 / BLOCK), dim3(BLOCK), 0, s, d_segs, nruns, (uint32_t)F1, d_bintot);
+    hipLaunchKernelGGL(k_dir_transpose, dim3((T + 63) / 64), dim3(BLOCK), 0, s, d_runs, nruns, T, Tp, Tp1, d_startT, d_preT, d_tile_addr);
+    hipLaunchKernelGGL(k_bin_prefix, dim3(F1), dim3(1024), 0, s, d_preT, T, Tp1, d_bintot);
     hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, d_bintot, d_binbase, (uint32_t)F1);
+    PCQ_HIP(hipGetLastError());
+    BinSrc src{d_preT, d_startT, d_tile_addr, T, Tp1, Tp};
     uint32_t h_probe[2] = {0, 0};  // tuples in the probe bins, tuples in all
     PCQ_HIP(hipMemcpyAsync(&h_probe[0], d_binbase + PROBE_BINS, 4, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipMemcpyAsync(&h_probe[1], d_binbase + F1, 4, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipStreamSynchronize(s));  // also: the pageable sources above have been read
     const uint64_t m = h_probe[1], w_old = gs->wtotal;
+    ctx->grid_last_tuples = (int64_t)m;
     if (m == 0) {
         grid_free_pending(ctx, gs);
         return PCQ_OK;
@@ -2230,10 +2248,9 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         if (rc) return rc;
         PCQ_HIP(hipMemsetAsync(d_set, 0xff, cap * 8, s));
         PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
-        unsigned per_seg = (unsigned)((h_probe[0] / (unsigned)nruns + BLOCK - 1) / BLOCK);
-        if (per_seg < 1) per_seg = 1;
-        if (per_seg > 4096) per_seg = 4096;
-        hipLaunchKernelGGL(k_probe_distinct, dim3(per_seg, (unsigned)nruns), dim3(BLOCK), 0, s, d_segs, eref, g, d_set, cap - 1, d_stats);
+        unsigned probe_blocks = (unsigned)(((uint64_t)T * PROBE_BINS + BLOCK - 1) / BLOCK);
+        if (probe_blocks > 4096) probe_blocks = 4096;
+        hipLaunchKernelGGL(k_probe_distinct, dim3(probe_blocks), dim3(BLOCK), 0, s, src, eref, g, d_set, cap - 1, d_stats);
         unsigned long long distinct = 0;
         PCQ_HIP(hipMemcpyAsync(&distinct, d_stats, 8, hipMemcpyDeviceToHost, s));
         PCQ_HIP(hipStreamSynchronize(s));
@@ -2248,9 +2265,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     for (int attempt = 0;; attempt++) {
         const uint32_t nparts = (uint32_t)F1 * f2;
         Scratch att(ctx);
-        const GridSeg *fold_segs = d_segs;
-        GridSeg fold_seg0 = hsegs[0];
-        int fold_nsegs = nruns;
+        StreamDrainOnExit drain_before_att(s);
+        GridSeg seg2{};  // the second level's output (f2 > 1)
         const uint32_t *d_tot = d_bintot;
         const uint64_t *obase = gs->wbase;
         const uint32_t *ocount = gs->wcount;
@@ -2259,14 +2275,14 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         const bool recut_old = w_old && gs->f2 != f2;
         if (f2 > 1 || recut_old) {
             Level2Params L{};
-            L.segs = d_segs, L.nsegs = nruns, L.entries = eref, L.g = g, L.f2 = f2, L.stats = d_stats;
-            GridTuple *d_t2 = nullptr;
+            L.src = src, L.entries = eref, L.g = g, L.f2 = f2, L.stats = d_stats, L.wide = any_wide;
+            uint8_t *d_t2 = nullptr;
             uint32_t *d_off2 = nullptr, *d_cnt2 = nullptr;
             // one pass into regions with slack (k_level2), unless that failed for this fold or does not apply
             const uint64_t cap = (uint64_t)std::ceil((double)m / nparts * 1.3) + 64;
             const bool staged = f2 <= (uint32_t)L2_STAGED_F2 && !level2_exact && cap * nparts < (1ull << 32);
             if (f2 > 1) {
-                rc = att.get(staged ? (size_t)(cap * nparts) : (size_t)m, &d_t2);
+                rc = att.get((staged ? (size_t)(cap * nparts) : (size_t)m) * tuple_bytes(any_wide) + 64, &d_t2);
                 if (!rc) rc = att.get((size_t)nparts + 1, &d_off2);
                 if (!rc && staged) rc = att.get((size_t)nparts, &d_cnt2);
                 if (rc) return rc;
@@ -2294,25 +2310,24 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
             else hipLaunchKernelGGL(k_level2_direct, dim3(F1), dim3(L2_NT), 0, s, L);
             PCQ_HIP(hipGetLastError());
             if (f2 > 1) {
-                GridSeg one{d_t2, d_off2, staged ? d_cnt2 : nullptr};
-                GridSeg *d_one = nullptr;
+                seg2 = GridSeg{d_t2, d_off2, staged ? d_cnt2 : nullptr, any_wide ? 1u : 0u};
                 uint32_t *d_tot2 = nullptr;
-                rc = att.get(1, &d_one);
-                if (!rc) rc = att.get(nparts, &d_tot2);
+                rc = att.get(nparts, &d_tot2);
                 if (rc) return rc;
-                unsigned long long outgrown = 0;
-                PCQ_HIP(hipMemcpyAsync(d_one, &one, sizeof one, hipMemcpyHostToDevice, s));
-                PCQ_HIP(hipMemcpyAsync(&outgrown, d_stats + 5, 8, hipMemcpyDeviceToHost, s));
-                PCQ_HIP(hipStreamSynchronize(s));  // `one` is on this stack frame
-                if (staged && outgrown) {  // a sub-partition outgrew its region (cells with very many points): count first, then cut
-                    level2_exact = true;
-                    ctx->grid_level2_exact++;
-                    attempt--;
-                    continue;
+                if (staged) {
+                    unsigned long long outgrown = 0;
+                    PCQ_HIP(hipMemcpyAsync(&outgrown, d_stats + 5, 8, hipMemcpyDeviceToHost, s));
+                    PCQ_HIP(hipStreamSynchronize(s));
+                    if (outgrown) {  // a sub-partition outgrew its region (cells with very many points): count first, then cut
+                        level2_exact = true;
+                        ctx->grid_level2_exact++;
+                        attempt--;
+                        continue;
+                    }
                 }
                 ctx->grid_level2++;
-                hipLaunchKernelGGL(k_part_totals, dim3((nparts + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_one, 1, nparts, d_tot2);
-                fold_segs = d_one, fold_seg0 = one, fold_nsegs = 1, d_tot = d_tot2;
+                hipLaunchKernelGGL(k_part_totals, dim3((nparts + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, seg2, nparts, d_tot2);
+                d_tot = d_tot2;
             }
             if (recut_old) {
                 hipLaunchKernelGGL(k_unpack_old_dir, dim3((nparts + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_ooff2, nparts, d_obase2, d_ocount2);
@@ -2328,7 +2343,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         uint64_t *n_wkeys = nullptr, *n_wbase = nullptr, *d_room = nullptr, *d_pieces = nullptr, *d_piece_pre = nullptr;
         uint8_t *n_wrecs = nullptr;
         uint32_t *n_wcount = nullptr, *d_palias = nullptr, *d_pay = nullptr, *d_defer = nullptr;
-        const bool dense = !big && fold_nsegs == 1 && !w_old;  // k_fold_dense first, k_fold for what it leaves
+        const bool dense = !big && !w_old;  // k_fold_dense first, k_fold for what it leaves
         const uint32_t npieces = (nparts + SCAN_PIECE - 1) / SCAN_PIECE;
         rc = att.get(wcap, &n_wkeys);
         if (!rc) rc = att.get(wcap * 32, &n_wrecs);
@@ -2349,7 +2364,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         PCQ_HIP(hipMemsetAsync(d_palias, 0, (size_t)nparts * 4, s));
         PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
         FoldParams F{};
-        F.segs = fold_segs, F.nsegs = fold_nsegs, F.seg0 = fold_seg0, F.entries = eref, F.g = gref;
+        F.src = src, F.seg = seg2, F.entries = eref, F.g = gref;
         if (w_old) F.okeys = okeys, F.orecs = orecs, F.obase = obase, F.ocount = ocount;
         F.wkeys = n_wkeys, F.wrecs = n_wrecs, F.wbase = n_wbase, F.wcount = n_wcount, F.palias = d_palias, F.pay_scratch = d_pay, F.stats = d_stats;
         {
@@ -2358,32 +2373,17 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
             if (dense) {
                 F.defer_list = d_defer;
                 DenseParams D{};
-                D.tuples = fold_seg0.tuples, D.off = fold_seg0.off, D.cnt = fold_seg0.cnt, D.entries = eref, D.g = gref;
+                D.tuples = seg2.tuples, D.wide = seg2.wide, D.off = seg2.off, D.cnt = seg2.cnt, D.entries = eref, D.g = gref;
                 D.wkeys = n_wkeys, D.wrecs = n_wrecs, D.wbase = n_wbase, D.wcount = n_wcount, D.palias = d_palias, D.stats = d_stats, D.defer_list = d_defer;
-#ifdef PCQ_LAB
-                D.lab_flags = (uint32_t)ctx->grid_variant >> 4;  // 16: no winner records (what do their stores cost?)
-                if (ctx->grid_variant & 8)  // two workgroups per CU, the next partition's tuples prefetched into registers
-                    hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, true, 4>), dim3(resident / 3 * 2), dim3(DENSE_NT), 0, s, D, nparts);
-                else
-#endif
                 hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, false, 6>), dim3(resident), dim3(DENSE_NT), 0, s, D, nparts);
             }
-#ifdef PCQ_LAB
-            // the big fold with a lock bit per slot instead of the three phases per chunk: 1.58 vs 1.75 ms on the uniform synthetic
-            // file — not shipped: every tuple that improves a cell parks its payload under the lock with a store round trip, so a
-            // file sorted towards a cell centre (one coarse cell, points along a drive) serialises on one slot
-            if (big && (ctx->grid_variant & 128)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, true, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
-            else if (big && (ctx->grid_variant & 256)) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, true, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);  // phases + chunk prefetch
-            else
-#endif
-            if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, false, false, false, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
-            else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, true, false, false, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
+            if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, true, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
+            else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, true, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
         }
         PCQ_HIP(hipGetLastError());
         unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         PCQ_HIP(hipMemcpyAsync(st, d_stats, sizeof st, hipMemcpyDeviceToHost, s));
         PCQ_HIP(hipStreamSynchronize(s));
-        if (st[6]) return pcq_fail(PCQ_ERR_HIP, "grid fold: a slot lock was not released (internal error)");
         if (st[1]) {  // a partition held more cells than the LDS table: more partitions
             if (f2 >= F2_MAX || attempt > 8) return pcq_fail(PCQ_ERR_UNSUPPORTED, "grid collector: a partition does not fit the LDS table at the largest fan-out");
             ctx->grid_refolds++;
@@ -2392,7 +2392,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         }
         if (st[2]) {  // aliased keys: gather their tuples, sort by (key, file order), replay
             PCQ_HIP(hipMemsetAsync(d_stats + 4, 0, 8, s));
-            hipLaunchKernelGGL(k_alias_gather<false>, dim3(nparts), dim3(L2_NT), 0, s, F, (AliasItem *)nullptr, d_stats + 4);
+            if (big) hipLaunchKernelGGL((k_alias_gather<false, true>), dim3(nparts), dim3(L2_NT), 0, s, F, (AliasItem *)nullptr, d_stats + 4);
+            else hipLaunchKernelGGL((k_alias_gather<false, false>), dim3(nparts), dim3(L2_NT), 0, s, F, (AliasItem *)nullptr, d_stats + 4);
             unsigned long long na = 0;
             PCQ_HIP(hipMemcpyAsync(&na, d_stats + 4, 8, hipMemcpyDeviceToHost, s));
             PCQ_HIP(hipStreamSynchronize(s));
@@ -2402,7 +2403,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 if (!rc) rc = att.get(na, &d_sorted);
                 if (rc) return rc;
                 PCQ_HIP(hipMemsetAsync(d_stats + 4, 0, 8, s));
-                hipLaunchKernelGGL(k_alias_gather<true>, dim3(nparts), dim3(L2_NT), 0, s, F, d_list, d_stats + 4);
+                if (big) hipLaunchKernelGGL((k_alias_gather<true, true>), dim3(nparts), dim3(L2_NT), 0, s, F, d_list, d_stats + 4);
+                else hipLaunchKernelGGL((k_alias_gather<true, false>), dim3(nparts), dim3(L2_NT), 0, s, F, d_list, d_stats + 4);
                 if (na <= ALIAS_QUADRATIC) {
                     hipLaunchKernelGGL(k_alias_rank, dim3((unsigned)((na + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, d_list, (uint64_t)na, d_sorted);
                 } else {  // massive aliasing: a real sort (alias_sort.hip)
@@ -2426,6 +2428,10 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     grid_free_pending(ctx, gs);
     return PCQ_OK;
 }
+
+// Folds what is pending now (the host layer calls it when a file is done, so that a collector kept for later holds its
+// winners — a few bytes per cell — instead of a tuple per scanned point).
+int pcq_grid_flush(pcq_collector *c) { return c->gs ? grid_fold(c->ctx, c) : PCQ_OK; }
 
 int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_t cap, uint64_t *out_n) {
     pcq_ctx *ctx = c->ctx;

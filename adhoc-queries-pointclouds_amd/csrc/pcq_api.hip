@@ -156,7 +156,6 @@ extern "C" int pcq_shutdown(pcq_ctx *ctx) {
     delete ctx->copy_pool;
     ctx->copy_pool = nullptr;
     pcq_pool_clear(ctx);
-    if (ctx->d_grid_cnt) (void)hipFree(ctx->d_grid_cnt);
     if (ctx->d_partials) (void)hipFree(ctx->d_partials);
     if (ctx->d_scalars) (void)hipFree(ctx->d_scalars);
     if (ctx->h_scalars) (void)hipHostFree(ctx->h_scalars);
@@ -286,8 +285,6 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
         ctx->grid_blocks_per_cu = (int)value;
 #ifdef PCQ_LAB
         ctx->batch_blocks_per_cu = (int)value;
-    } else if (!strcmp(key, "grid_variant")) {
-        ctx->grid_variant = (int)value;
     } else if (!strcmp(key, "k1_variant")) {
         if (value < 0 || value > 14) return pcq_fail(PCQ_ERR_ARG, "k1_variant must be 0..14");
         ctx->k1_variant = (int)value;
@@ -315,8 +312,12 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "allreduce_single_rank")) {
         ctx->allreduce_single_rank = value != 0;
     } else if (!strcmp(key, "grid_pending_budget")) {
-        if (value < 0) return pcq_fail(PCQ_ERR_ARG, "grid_pending_budget must be >= 0");
+        // (points scanned into a grid collector before it folds; a fold's tuple counts and offsets are 32-bit, grid.hip clamps to that)
+        if (value < 0 || value > (int64_t)1 << 40) return pcq_fail(PCQ_ERR_ARG, "grid_pending_budget must be 0..2^40");
         ctx->grid_pending_budget = value;
+    } else if (!strcmp(key, "grid_agg")) {
+        if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "grid_agg must be 0 (adaptive), 1 (always) or 2 (never)");
+        ctx->grid_agg = (int)value;
     } else if (!strcmp(key, "grid_f2")) {
         if (value < 0 || value > 4096) return pcq_fail(PCQ_ERR_ARG, "grid_f2 must be 0..4096");
         ctx->grid_f2 = (int)value;
@@ -363,6 +364,8 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     else if (!strcmp(key, "grid_pending_budget")) *value = ctx->grid_pending_budget;
     else if (!strcmp(key, "allreduce_single_rank")) *value = ctx->allreduce_single_rank;
     else if (!strcmp(key, "grid_f2")) *value = ctx->grid_f2;
+    else if (!strcmp(key, "grid_agg")) *value = ctx->grid_agg;
+    else if (!strcmp(key, "grid_last_tuples")) *value = ctx->grid_last_tuples;
     else if (!strcmp(key, "grid_folds")) *value = ctx->grid_folds;
     else if (!strcmp(key, "grid_level2")) *value = ctx->grid_level2;
     else if (!strcmp(key, "grid_refolds")) *value = ctx->grid_refolds;
@@ -601,6 +604,8 @@ extern "C" int pcq_collector_reset(pcq_collector *c) {
     if (!c) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_reset: null collector");
     hipStream_t s = c->ctx->stream;
     c->next_index = 0;
+    // scans enqueued on a caller's stream may still be reading and moving the counters
+    if (c->kind != COLL_GRID && c->last_stream && c->last_stream != s) PCQ_HIP(hipStreamSynchronize(c->last_stream));
     if (c->kind == COLL_COUNT) PCQ_HIP(hipMemsetAsync(c->d_count, 0, 8, s));
     if (c->kind == COLL_BUFFER) {
         PCQ_HIP(hipMemsetAsync(c->d_count, 0, 16, s));
@@ -616,6 +621,16 @@ extern "C" int pcq_collector_reset(pcq_collector *c) {
 }
 
 extern "C" int pcq_collector_has_points(const pcq_collector *c) { return c && c->kind != COLL_COUNT; }
+
+extern "C" int pcq_collector_flush(pcq_collector *c) {
+    PCQ_ON_DEVICE_OF_COLLECTOR(c);
+    if (!c) return pcq_fail(PCQ_ERR_ARG, "pcq_collector_flush: null collector");
+    pcq_ctx *ctx = c->ctx;
+    if (c->last_stream && c->last_stream != ctx->stream) PCQ_HIP(hipStreamSynchronize(c->last_stream));
+    if (c->kind == COLL_GRID) return pcq_grid_flush(c);  // (synchronises)
+    PCQ_HIP(hipStreamSynchronize(ctx->stream));
+    return PCQ_OK;
+}
 
 extern "C" int pcq_collector_point_count(pcq_collector *c, uint64_t *out) {
     PCQ_ON_DEVICE_OF_COLLECTOR(c);

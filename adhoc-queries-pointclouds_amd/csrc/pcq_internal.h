@@ -150,7 +150,6 @@ struct pcq_ctx {
     // over a second (profiles/r01_grid_timeline.txt) — per-file grids (main.rs:156) reuse the blocks of the file before
     std::vector<PoolBlock> pool;
     uint64_t pool_limit = 96ull << 30;  // free bytes the pool may keep
-    uint32_t *d_grid_cnt = nullptr;     // grid pass 0: per-(block, bin) tuple counts of the run in flight (grid.hip)
     // diagnostics of the grid collector (pcq_get_option): folds run, folds that needed a second partition level,
     // folds repeated because a partition overflowed its LDS table, the last fold's second-level fan-out
     int64_t grid_folds = 0, grid_level2 = 0, grid_refolds = 0, grid_last_f2 = 0;
@@ -159,6 +158,9 @@ struct pcq_ctx {
     int allreduce_single_rank = 0;      // option: pcq_allreduce_sum_u64 with ONE rank still goes through RCCL (communicator of one
                                         // device, ncclAllReduce) — exercises the run-time binding on a single-GPU box
     int grid_f2 = 0;                    // option (tests): second-level fan-out a fold starts from (0 = from the measured estimate)
+    int grid_agg = 0;                   // option: pass 0 folds a tile's duplicate cells before they travel — 0 = while it pays (per workgroup),
+                                        // 1 = every tile, 2 = never; the results are the same, the tuples moved are not
+    int64_t grid_last_tuples = 0;       // diagnostics: tuples the last fold found pending (after pass 0's own fold)
     // options
     int grid_blocks_per_cu = 2;   // persistent blocks per CU of the generic (strided) count kernels and the chunk index
 #ifdef PCQ_LAB                    // libpcq_lab.so only: the kernel shapes of csrc/lab/scan_count_lab.hip
@@ -171,7 +173,6 @@ struct pcq_ctx {
     int class_batch_loads = 4;
     int class_batch_waves_per_cu = 4;
     int class_batch_pipe = 1;
-    int grid_variant = 0;         // experimental shapes of the grid collector's kernels, one bit each: include/pcq_lab.h
 #endif
     int numa_node = -1;               // NUMA node the GPU hangs off (sysfs), -1 if unknown
     cpu_set_t node_cpus;              // its CPUs (empty if unknown)
@@ -229,6 +230,7 @@ int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pre
 int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const DevPred &pred, hipStream_t s);
 void pcq_grid_release(pcq_collector *c);
 int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_t cap, uint64_t *out_n);
+int pcq_grid_flush(pcq_collector *c);  // folds what is pending now
 // alias_sort.hip: sorted[i] = the i-th of n records (u64 key at +0, u64 order at +8) by (key, order)
 int pcq_sort_by_key_then_order(pcq_ctx *ctx, const void *items, size_t stride, uint64_t n, void *sorted, hipStream_t s);
 // pcq_api.hip: device-memory pool of the context.  A block may be freed only when the work that used it has completed.

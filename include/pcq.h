@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PCQ_ABI_VERSION 3
+#define PCQ_ABI_VERSION 4
 
 typedef enum pcq_status {
     PCQ_OK = 0,
@@ -164,6 +164,12 @@ int pcq_collector_grid_cells(pcq_collector *c, uint64_t *out, uint64_t cap, uint
 int pcq_collector_grid_params(const pcq_collector *c, uint64_t dims[3], uint64_t bits[3]);
 /* Resets the collector to its freshly constructed state (keeps allocations). */
 int pcq_collector_reset(pcq_collector *c);
+/* Brings a collector that is kept for later into its compact form NOW and waits for it: a grid collector folds its
+ * pending matches into per-cell winners (the reference's HashMap never holds more than the winners,
+ * grid_sampling.rs:72-103; the device keeps a tuple per scanned point until it folds) and returns their memory to the
+ * context; count and buffer collectors only wait for their scans.  run_search_parallel calls it when a file is done
+ * (main.rs:153-161 keeps one collector per file until all files are searched).  Results are unchanged. */
+int pcq_collector_flush(pcq_collector *c);
 
 /* ---------------------------------------------------------------------------------------------
  * The scan: evaluates `pred` over `cols` and pushes every match into `c`

@@ -7,19 +7,8 @@
  * "class_batch_waves_per_cu", "class_batch_pipe" — the shapes measured on the way to the shipped kernels
  * (profiles/r01_k1_*.log, r01_k2_sweep.log).
  *
- * "grid_variant" (round 2; profiles/r02_grid_progress.txt, tests/test_gpu_lab_variants.py) selects experimental shapes of the
- * grid collector's kernels, one bit each:
- *      8  dense fold: two workgroups per CU, the next partition's tuples prefetched into registers
- *     16  dense fold without its record stores                                   (WRONG results: timing only)
- *     32  pass 0 scatter: positions loaded without the non-temporal hint
- *    128  big fold: a lock bit per slot instead of the phases and barriers per chunk
- *    256  big fold: phases, with the next chunk's tuples prefetched into registers
- *    512  pass 0 scatter: 2560-point tiles on 256 threads x 10 points (two workgroups per CU)
- *   1024  pass 0 scatter: 2560-point tiles on 512 threads x 5 points (two workgroups per CU; the shipped shape before the 5120-point tiles)
- *   2048  pass 0 scatter: non-temporal stores of the tuples
- *   4096  pass 0 scatter: every tile written in one piece                         (WRONG results: timing only)
- *   8192  pass 0 scatter: groups of 16 tuples = whole lines, at random places     (WRONG results: timing only)
- *  16384  pass 0 scatter: whole-line stores with a carry per bin (k_p0_scatter_lines)
+ * (Round 2's experimental shapes of the grid collector — option "grid_variant" — left with the kernels they varied:
+ * round 3 replaced pass 0 and the way the fold reads it; their measurements are in profiles/r02_grid_progress.txt.)
  */
 #ifndef PCQ_LAB_H
 #define PCQ_LAB_H

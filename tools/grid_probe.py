@@ -1,6 +1,6 @@
 """Developer probe: grid-collector scans of one resident file (for rocprofv3 --kernel-trace).
 usage: grid_probe.py QUERY CELL [POINTS] [REPEATS]; GRID_F2=<n> forces the second-level fan-out;
-GRID_VARIANT=<n>[,<n>...] (with PCQ_LAB=1) picks experimental kernel shapes (pcq_internal.h), one per repeat in turn;
+GRID_AGG=<0|1|2>[,...] sets pass 0's tile fold (0 = while it pays, 1 = every tile, 2 = never), one value per repeat in turn;
 COHERENT=<metres> reorders the file into x/y strips of that width (points sorted along each strip, like scan
 lines) instead of the generator's random order."""
 import importlib, os, sys, time
@@ -34,10 +34,10 @@ with pkg.Context(0) as ctx:
     bmin, bmax = specs.box(q)
     lmin, lmax = pkg.box_to_local(bmin, bmax, list(spec.scale), list(spec.offset))
     ctx.set_option("grid_f2", int(os.environ.get("GRID_F2", "0")))
-    variants = [int(v) for v in os.environ.get("GRID_VARIANT", "").split(",") if v]  # PCQ_LAB=1 only; several: one after the other, same buffers
+    aggs = [int(v) for v in os.environ.get("GRID_AGG", "").split(",") if v]  # several: one after the other, same buffers
     for it in range(int(sys.argv[4]) if len(sys.argv) > 4 else 2):
-        if variants:
-            ctx.set_option("grid_variant", variants[it % len(variants)])
+        if aggs:
+            ctx.set_option("grid_agg", aggs[it % len(aggs)])
         t0 = time.perf_counter()
         g = ctx.grid_collector(bmin, bmax, cell)
         t1 = time.perf_counter()
@@ -49,4 +49,5 @@ with pkg.Context(0) as ctx:
         g.free()
         t4 = time.perf_counter()
         print(q, cell, "cells", k, "new %.1f scan %.1f count %.1f free %.1f ms" % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3),
-              "f2", ctx.get_option("grid_last_f2"), "refolds", ctx.get_option("grid_refolds"), flush=True)
+              "f2", ctx.get_option("grid_last_f2"), "refolds", ctx.get_option("grid_refolds"), "agg", ctx.get_option("grid_agg"),
+              "tuples", ctx.get_option("grid_last_tuples"), flush=True)
