@@ -265,13 +265,14 @@ __device__ __forceinline__ T ldg(const T *p) {
     return *(const PCQ_GLOBAL T *)p;
 }
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));  // a 16-byte access at a 4-byte aligned address
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 // (every tuple buffer ends in 64 spare bytes: the word behind a 20-byte tuple is always readable, so the second colour
 // word costs a select instead of a load in a branch of its own — see k_p0_part on loads in branches)
 __device__ __forceinline__ GridTuple ld_tuple(const uint8_t *p, bool wide) {
     const u32x4_a4 a = *(const PCQ_GLOBAL u32x4_a4 *)p;
-    const uint32_t b = *(const PCQ_GLOBAL uint32_t *)(p + 16), c = *(const PCQ_GLOBAL uint32_t *)(p + 20);
+    const u32x2_a4 b = *(const PCQ_GLOBAL u32x2_a4 *)(p + 16);
     GridTuple t;
-    t.x = (int32_t)a.x, t.y = (int32_t)a.y, t.z = (int32_t)a.z, t.idx = a.w, t.w0 = b, t.w1 = wide ? c : 0u;
+    t.x = (int32_t)a.x, t.y = (int32_t)a.y, t.z = (int32_t)a.z, t.idx = a.w, t.w0 = b.x, t.w1 = wide ? b.y : 0u;
     return t;
 }
 __device__ __forceinline__ void st_tuple(uint8_t *p, const GridTuple &t, bool wide) {
@@ -748,6 +749,33 @@ __global__ __launch_bounds__(1024) void k_bin_prefix(uint32_t *__restrict__ preT
     if (threadIdx.x == 0) {
         row[T] = carry;
         bintot[blockIdx.x] = carry;
+    }
+}
+
+// Short fragments (a scan whose tiles shed most of their tuples, a box that few points match): the reader's window
+// would hold a handful of tuples per round.  Then the bins are first copied together — one thread per fragment, comp =
+// bin 0's tuples, bin 1's, ... — and described to the fold as pass-0 output of F1 "tiles", tile t = bin t's piece:
+// fragment (b, t) is empty unless t == b.  Every consumer reads that through the same window code.
+__global__ __launch_bounds__(BLOCK) void k_bin_compact(BinSrc S, const uint32_t *__restrict__ binbase, uint8_t *__restrict__ comp, uint32_t wide_out) {
+    const uint64_t q = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= (uint64_t)S.T * F1) return;
+    const uint32_t bin = (uint32_t)(q / S.T), f = (uint32_t)(q % S.T);
+    const uint32_t lo = ldg(S.preT + (size_t)bin * S.Tp1 + f), hi = ldg(S.preT + (size_t)bin * S.Tp1 + f + 1);
+    if (lo == hi) return;
+    const uint64_t a = frag_addr(S, bin, f);
+    const bool wide = a & 1;
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(a & ~1ull);
+    uint8_t *dst = comp + (uint64_t)(ldg(binbase + bin) + lo) * tuple_bytes(wide_out);
+    for (uint32_t i = 0; i < hi - lo; i++) st_tuple(dst + (uint64_t)i * tuple_bytes(wide_out), ld_tuple(src + (uint64_t)i * tuple_bytes(wide), wide), wide_out);
+}
+// the directory of the compacted bins: preT[b][t] = (t <= b ? 0 : the bin's tuples), startT = 0, tile_addr[t] = bin t's piece
+__global__ __launch_bounds__(BLOCK) void k_compact_dir(const uint32_t *__restrict__ binbase, const uint8_t *__restrict__ comp, uint32_t wide, uint32_t Tp1,
+                                                       uint32_t Tp, uint32_t *__restrict__ preT, uint16_t *__restrict__ startT, uint64_t *__restrict__ tile_addr) {
+    const uint32_t b = blockIdx.x, cnt = binbase[b + 1] - binbase[b];
+    for (uint32_t t = threadIdx.x; t <= (uint32_t)F1; t += BLOCK) {
+        preT[(size_t)b * Tp1 + t] = t <= b ? 0u : cnt;
+        if (t < (uint32_t)F1) startT[(size_t)b * Tp + t] = 0;
+        if (b == 0 && t < (uint32_t)F1) tile_addr[t] = reinterpret_cast<uint64_t>(comp + (uint64_t)binbase[t] * tuple_bytes(wide)) | (wide ? 1u : 0u);
     }
 }
 
@@ -1482,25 +1510,27 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                     const uint32_t wend = uni32(s_pre[nfr]);
                     cnt = wend - j0 < (uint32_t)CHUNK ? wend - j0 : (uint32_t)CHUNK;
                     j1 = j0 + cnt;
-                    // the next round's window starts at the fragment tuple j1 lies in; asked for now, stored when the round is over
+                    GridTuple tu[FOLD_K];
+                    if (cnt) {
+#pragma unroll
+                        for (int k = 0; k < FOLD_K; k++) {
+                            const uint32_t i = k * NT + threadIdx.x;
+                            tu[k] = frag_ld_tuple(s_pre, s_addr, nfr, j0 + (i < cnt ? i : cnt - 1));
+                        }
+                    }
+                    // the next round's window starts at the fragment tuple j1 lies in; asked for now (behind this round's tuples),
+                    // stored when the round is over
                     const uint32_t f_next = j1 == wend ? f_lo + nfr : f_lo + uni32(frag_find(s_pre, nfr, j1));
                     const uint32_t nfr_next = S.T - f_next < (uint32_t)FB ? S.T - f_next : (uint32_t)FB;
                     if (j1 < total_in) {
                         if (threadIdx.x <= nfr_next) reg_pre = ldg(S.preT + (size_t)p * S.Tp1 + f_next + threadIdx.x);
                         if (threadIdx.x < nfr_next) reg_addr = frag_addr(S, p, f_next + threadIdx.x);
                     }
+                    f_lo = f_next, nfr = nfr_next;
                     if (cnt == 0) {  // a window of empty fragments
-                        f_lo = f_next, nfr = nfr_next;
                         __syncthreads();  // (everyone has read the window before it is rewritten)
                         continue;
                     }
-                    GridTuple tu[FOLD_K];
-#pragma unroll
-                    for (int k = 0; k < FOLD_K; k++) {
-                        const uint32_t i = k * NT + threadIdx.x;
-                        tu[k] = frag_ld_tuple(s_pre, s_addr, nfr, j0 + (i < cnt ? i : cnt - 1));
-                    }
-                    f_lo = f_next, nfr = nfr_next;
                     fold_chunk<NSLOT, NT, FOLD_K, LIMIT>(P, tu, cnt, s_key, s_dist, s_ord, s_aliasbits, s_oldbits, &s_ncell, &s_over, pay);
                 } else {
                     cnt = total_in - j0 < (uint32_t)CHUNK ? total_in - j0 : (uint32_t)CHUNK;
@@ -2222,7 +2252,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     hipLaunchKernelGGL(k_bin_prefix, dim3(F1), dim3(1024), 0, s, d_preT, T, Tp1, d_bintot);
     hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, d_bintot, d_binbase, (uint32_t)F1);
     PCQ_HIP(hipGetLastError());
-    BinSrc src{d_preT, d_startT, d_tile_addr, T, Tp1, Tp};
+    BinSrc src{d_preT, d_startT, d_tile_addr, T, Tp1, Tp};  // (replaced by the compacted bins below when the fragments are short)
     uint32_t h_probe[2] = {0, 0};  // tuples in the probe bins, tuples in all
     PCQ_HIP(hipMemcpyAsync(&h_probe[0], d_binbase + PROBE_BINS, 4, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipMemcpyAsync(&h_probe[1], d_binbase + F1, 4, hipMemcpyDeviceToHost, s));
@@ -2234,6 +2264,24 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         return PCQ_OK;
     }
     ctx->grid_folds++;
+    if (T > 2u * BIG_FB && m < 2ull * T * F1) {  // fragments of less than two tuples on average: copy the bins together first
+        const uint32_t Tc = F1, Tcp = F1, Tcp1 = (F1 + 1 + 63) & ~63u;
+        uint8_t *d_comp = nullptr;
+        uint32_t *d_cpre = nullptr;
+        uint16_t *d_cstart = nullptr;
+        uint64_t *d_caddr = nullptr;
+        rc = tmp.get((size_t)m * tuple_bytes(any_wide) + 64, &d_comp);
+        if (!rc) rc = tmp.get((size_t)F1 * Tcp1, &d_cpre);
+        if (!rc) rc = tmp.get((size_t)F1 * Tcp, &d_cstart);
+        if (!rc) rc = tmp.get(Tc, &d_caddr);
+        if (rc) return rc;
+        const uint64_t nfrag = (uint64_t)T * F1;
+        hipLaunchKernelGGL(k_bin_compact, dim3((unsigned)((nfrag + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, src, d_binbase, d_comp, any_wide ? 1u : 0u);
+        hipLaunchKernelGGL(k_compact_dir, dim3(F1), dim3(BLOCK), 0, s, d_binbase, d_comp, any_wide ? 1u : 0u, Tcp1, Tcp, d_cpre, d_cstart, d_caddr);
+        PCQ_HIP(hipGetLastError());
+        src = BinSrc{d_cpre, d_cstart, d_caddr, Tc, Tcp1, Tcp};
+        ctx->grid_compactions++;
+    }
 
     // how dense is the grid?  estimated cells per level-1 bin -> fold the bins directly, or cut them again first
     uint32_t f2 = 1;

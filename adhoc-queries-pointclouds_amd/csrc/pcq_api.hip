@@ -371,6 +371,7 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     else if (!strcmp(key, "grid_refolds")) *value = ctx->grid_refolds;
     else if (!strcmp(key, "grid_level2_exact")) *value = ctx->grid_level2_exact;
     else if (!strcmp(key, "grid_last_f2")) *value = ctx->grid_last_f2;
+    else if (!strcmp(key, "grid_compactions")) *value = ctx->grid_compactions;
     else return pcq_fail(PCQ_ERR_ARG, "unknown option '%s'", key);
     return PCQ_OK;
 }

@@ -153,6 +153,7 @@ struct pcq_ctx {
     // diagnostics of the grid collector (pcq_get_option): folds run, folds that needed a second partition level,
     // folds repeated because a partition overflowed its LDS table, the last fold's second-level fan-out
     int64_t grid_folds = 0, grid_level2 = 0, grid_refolds = 0, grid_last_f2 = 0;
+    int64_t grid_compactions = 0;       // folds whose bins were copied together first (short fragments)
     int64_t grid_level2_exact = 0;      // second levels repeated in the exact (counting) form: a sub-partition had outgrown its region
     int64_t grid_pending_budget = 0;    // option: tuples a grid collector may hold before it folds (0 = default)
     int allreduce_single_rank = 0;      // option: pcq_allreduce_sum_u64 with ONE rank still goes through RCCL (communicator of one

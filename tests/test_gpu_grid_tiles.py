@@ -158,3 +158,31 @@ def test_grid_flush_folds_now_and_changes_nothing(oracle):
             gg.free()
             f.free()
     og.free()
+
+
+@pytest.mark.parametrize("fmt", [1, 2])
+def test_grid_short_fragments_are_copied_together_first(oracle, fmt):
+    """More than 1024 tiles and fewer than two tuples per (tile, bin) fragment — a box that few points match: the fold
+    copies the bins together before it reads them (grid_compactions), coarse and dense grids alike."""
+    n = 1100 * TILE + 77
+    spec = small_spec(6061 + fmt, n, fmt=fmt)
+    image = oracle.synth_image(spec, transposed=True)
+    hdr = oracle.parse_header(image[:400].tobytes())
+    bmin, bmax = (-30.0, -30.0, -2.0), (30.0, 30.0, 2.0)   # about 7 % of the points
+    lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+    with pkg.Context(0) as ctx:
+        f = DevFile(ctx, image, hdr)
+        try:
+            for cell in (2.0, 0.1):
+                og = oracle.grid_collector(bmin, bmax, cell)
+                assert oracle.search_last_bounds(image, bmin, bmax, og) == 0
+                before = ctx.get_option("grid_compactions")
+                gg = ctx.grid_collector(bmin, bmax, cell)
+                ctx.scan_dev(f.columns(True), pkg.Predicate.bounds(lmin, lmax), gg)
+                check_same(gg, og)
+                assert ctx.get_option("grid_compactions") == before + 1
+                assert (ctx.get_option("grid_last_f2") > 1) == (cell == 0.1)
+                gg.free()
+                og.free()
+        finally:
+            f.free()
