@@ -2264,6 +2264,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         return PCQ_OK;
     }
     ctx->grid_folds++;
+    const BinSrc src_tiles = src;  // (the density probe takes a thread per fragment: it reads the tiles' own lists either way)
     if (T > 2u * BIG_FB && m < 2ull * T * F1) {  // fragments of less than two tuples on average: copy the bins together first
         const uint32_t Tc = F1, Tcp = F1, Tcp1 = (F1 + 1 + 63) & ~63u;
         uint8_t *d_comp = nullptr;
@@ -2298,7 +2299,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
         unsigned probe_blocks = (unsigned)(((uint64_t)T * PROBE_BINS + BLOCK - 1) / BLOCK);
         if (probe_blocks > 4096) probe_blocks = 4096;
-        hipLaunchKernelGGL(k_probe_distinct, dim3(probe_blocks), dim3(BLOCK), 0, s, src, eref, g, d_set, cap - 1, d_stats);
+        hipLaunchKernelGGL(k_probe_distinct, dim3(probe_blocks), dim3(BLOCK), 0, s, src_tiles, eref, g, d_set, cap - 1, d_stats);
         unsigned long long distinct = 0;
         PCQ_HIP(hipMemcpyAsync(&distinct, d_stats, 8, hipMemcpyDeviceToHost, s));
         PCQ_HIP(hipStreamSynchronize(s));

@@ -173,7 +173,8 @@ def test_grid_short_fragments_are_copied_together_first(oracle, fmt):
     with pkg.Context(0) as ctx:
         f = DevFile(ctx, image, hdr)
         try:
-            for cell in (2.0, 0.1):
+            for cell, f2 in ((2.0, 0), (0.1, 7)):   # the big fold reads the copied bins directly; forced: through the second level
+                ctx.set_option("grid_f2", f2)
                 og = oracle.grid_collector(bmin, bmax, cell)
                 assert oracle.search_last_bounds(image, bmin, bmax, og) == 0
                 before = ctx.get_option("grid_compactions")
@@ -181,7 +182,7 @@ def test_grid_short_fragments_are_copied_together_first(oracle, fmt):
                 ctx.scan_dev(f.columns(True), pkg.Predicate.bounds(lmin, lmax), gg)
                 check_same(gg, og)
                 assert ctx.get_option("grid_compactions") == before + 1
-                assert (ctx.get_option("grid_last_f2") > 1) == (cell == 0.1)
+                assert ctx.get_option("grid_last_f2") == (f2 or 1)
                 gg.free()
                 og.free()
         finally:
