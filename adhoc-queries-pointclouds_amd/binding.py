@@ -176,7 +176,8 @@ def load_library() -> C.CDLL:
         "pcq_scan_fd": (C.c_int, [vp, C.c_int, P(Columns), P(Predicate), vp]),
         "pcq_scan_host_nowait": (C.c_int, [vp, P(Columns), P(Predicate), vp]),
         "pcq_scan_dev_count_batch": (C.c_int, [vp, P(Columns), P(Predicate), C.c_size_t, vp, vp]),
-        "pcq_allreduce_sum_u64": (C.c_int, [P(vp), P(vp), C.c_int]),
+        "pcq_allreduce_sum_u64": (C.c_int, [P(vp), P(vp), P(vp), C.c_int]),
+        "pcq_allreduce_prepare": (C.c_int, [P(C.c_int), C.c_int]),
         "pcq_read_fd_to_device": (C.c_int, [vp, C.c_int, u64, u64, vp]),
         "pcq_index_new": (C.c_int, [vp, P(vp)]),
         "pcq_index_free": (C.c_int, [vp]),

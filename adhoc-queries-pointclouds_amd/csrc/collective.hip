@@ -9,7 +9,10 @@
 // Message: 8 bytes per rank — latency-bound; ring/tree choice and the 7 x 153 GB/s links are irrelevant.
 #include <dlfcn.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "pcq_internal.h"
@@ -63,43 +66,106 @@ int load_rccl() {
         if (_r != 0) return pcq_fail(PCQ_ERR_HIP, "%s failed: %s", #expr, g_rccl.GetErrorString(_r));         \
     } while (0)
 
+bool timing() {
+    static const bool on = getenv("PCQ_TIMING") && getenv("PCQ_TIMING")[0] == '1';
+    return on;
+}
+
+// (g_mu held) the intra-node communicator for `devs`; leaves the calling thread on whatever device RCCL left it on
+int ensure_comm(const std::vector<int> &devs) {
+    int rc = load_rccl();
+    if (rc) return rc;
+    if (devs == g_rccl.devices) return PCQ_OK;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (ncclComm_t c : g_rccl.comms) g_rccl.CommDestroy(c);
+    g_rccl.comms.assign(devs.size(), nullptr);
+    g_rccl.devices.clear();
+    PCQ_NCCL(g_rccl.CommInitAll(g_rccl.comms.data(), (int)devs.size(), devs.data()));
+    g_rccl.devices = devs;
+    if (timing())
+        fprintf(stderr, "[pcq] RCCL communicator over %zu device(s) ready after %.1f ms\n", devs.size(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    return PCQ_OK;
+}
+
+// a communicator being built on a helper thread (pcq_allreduce_prepare): joined by whoever needs the lock next
+std::thread g_prepare;
+std::mutex g_prepare_mu;
+void join_prepare() {
+    std::lock_guard<std::mutex> lk(g_prepare_mu);
+    if (g_prepare.joinable()) g_prepare.join();
+}
+
 }  // namespace
 
-extern "C" int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, uint64_t *const *device_counters, int n) {
-    if (!ctxs || !device_counters || n < 1) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: bad arguments");
+// Starts building the communicator for `devices` on a helper thread and returns: ncclCommInitAll takes from tens of
+// milliseconds to more than the whole query on eight GPUs, and nothing in it depends on the scans — the `query` CLI calls
+// this when it knows its device list, the scans run meanwhile, and pcq_allreduce_sum_u64 finds the communicator ready (or
+// waits for it).  Errors surface in the all-reduce, which then builds (and fails) synchronously.
+extern "C" int pcq_allreduce_prepare(const int *devices, int n) {
+    if (!devices || n < 1) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_prepare: bad arguments");
+    std::vector<int> devs(devices, devices + n);
+    join_prepare();
+    std::lock_guard<std::mutex> lk(g_prepare_mu);
+    g_prepare = std::thread([devs]() {
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        {
+            std::lock_guard<std::mutex> g(g_mu);
+            (void)ensure_comm(devs);  // (a failure is reported by the all-reduce that finds no communicator)
+        }
+        if (prev >= 0) (void)hipSetDevice(prev);
+    });
+    return PCQ_OK;
+}
+
+extern "C" int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, const uint64_t *const *send, uint64_t *const *recv, int n) {
+    if (!ctxs || !send || !recv || n < 1) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: bad arguments");
     for (int i = 0; i < n; i++)
-        if (!ctxs[i] || !device_counters[i]) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: null entry %d", i);
+        if (!ctxs[i] || !send[i] || !recv[i]) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: null entry %d", i);
     for (int i = 0; i < n; i++)
         for (int j = 0; j < i; j++)
             if (ctxs[i]->device == ctxs[j]->device)
                 return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: entries %d and %d are both on device %d (one rank per GPU)", j, i, ctxs[i]->device);
+    const int inject = ctxs[0]->allreduce_fail;  // test hook: 1 = fail before anything is touched, 2 = fail after the reduction ran
+    if (inject == 1) return pcq_fail(PCQ_ERR_HIP, "pcq_allreduce_sum_u64: injected failure (before the reduction)");
     if (n == 1 && !ctxs[0]->allreduce_single_rank) {  // a single rank: the sum is the value itself
         PCQ_ON_DEVICE_OF_CTX(ctxs[0]);
+        if (recv[0] != send[0]) PCQ_HIP(hipMemcpyAsync(recv[0], send[0], 8, hipMemcpyDeviceToDevice, ctxs[0]->stream));
         PCQ_HIP(hipStreamSynchronize(ctxs[0]->stream));
+        if (inject == 2) return pcq_fail(PCQ_ERR_HIP, "pcq_allreduce_sum_u64: injected failure (after the reduction)");
         return PCQ_OK;
     }
     DeviceGuard restore(ctxs[0]->device);  // the calls below move the thread from device to device; put it back at the end
+    join_prepare();
     std::lock_guard<std::mutex> lk(g_mu);
-    int rc = load_rccl();
-    if (rc) return rc;
     std::vector<int> devs(n);
     for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;
-    if (devs != g_rccl.devices) {  // (re)build the intra-node communicator for this device list
-        for (ncclComm_t c : g_rccl.comms) g_rccl.CommDestroy(c);
-        g_rccl.comms.assign(n, nullptr);
-        g_rccl.devices.clear();
-        PCQ_NCCL(g_rccl.CommInitAll(g_rccl.comms.data(), n, devs.data()));
-        g_rccl.devices = devs;
-    }
+    int rc = ensure_comm(devs);
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    // Whatever fails between GroupStart and GroupEnd, the group is closed before this function returns: an open group
+    // would swallow the next caller's collectives.
     PCQ_NCCL(g_rccl.GroupStart());
-    for (int i = 0; i < n; i++) {
-        PCQ_HIP(hipSetDevice(devs[i]));
-        PCQ_NCCL(g_rccl.AllReduce(device_counters[i], device_counters[i], 1, kNcclUint64, kNcclSum, g_rccl.comms[i], ctxs[i]->stream));
+    int failed = PCQ_OK;
+    for (int i = 0; i < n && !failed; i++) {
+        hipError_t he = hipSetDevice(devs[i]);
+        if (he != hipSuccess) {
+            failed = pcq_fail(PCQ_ERR_HIP, "hipSetDevice(%d) failed: %s", devs[i], hipGetErrorString(he));
+            break;
+        }
+        const ncclResult_t r = g_rccl.AllReduce(send[i], recv[i], 1, kNcclUint64, kNcclSum, g_rccl.comms[i], ctxs[i]->stream);
+        if (r != 0) failed = pcq_fail(PCQ_ERR_HIP, "ncclAllReduce (rank %d) failed: %s", i, g_rccl.GetErrorString(r));
     }
-    PCQ_NCCL(g_rccl.GroupEnd());
+    const ncclResult_t ge = g_rccl.GroupEnd();
+    if (failed) return failed;
+    if (ge != 0) return pcq_fail(PCQ_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(ge));
     for (int i = 0; i < n; i++) {
         PCQ_HIP(hipSetDevice(devs[i]));
         PCQ_HIP(hipStreamSynchronize(ctxs[i]->stream));
     }
+    if (timing())
+        fprintf(stderr, "[pcq] all-reduce of %d count(s) took %.2f ms\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (inject == 2) return pcq_fail(PCQ_ERR_HIP, "pcq_allreduce_sum_u64: injected failure (after the reduction)");
     return PCQ_OK;
 }

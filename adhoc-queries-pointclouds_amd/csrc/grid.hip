@@ -91,13 +91,15 @@ constexpr uint8_t R_HAS = 1;    // byte 31 of a winner record: the record holds 
 constexpr uint8_t R_ALIAS = 2;  // the key has seen a point whose unmasked cell differs from the masked one (sticky)
 
 // One matched point on its way to the fold, as the kernels hold it.  `idx` is the file-order index relative to its
-// entry's base index.  In memory: 20 bytes {x, y, z, idx, w0}, or 24 with w1 when the scan had a colour column
+// entry's base index.  In memory: 20 bytes {x, y, z, idx, w0 (sel in the red half)}, or 24 with w1 when the scan had a colour column
 // (synthetic ca13 is format 1: no colour — a sixth less to move through every partition level).
 struct GridTuple {
     int32_t x, y, z;
     uint32_t idx;
     uint32_t w0;  // classification | entry << 8 | red << 16
     uint32_t w1;  // green | blue << 16
+    uint32_t sel; // 20-byte tuples only: the 16 hash bits that pick the second-level partition (sel16_of), which pass 0 —
+                  // it has the hash at hand — leaves in the red half of w0 (a tuple without colour has no red); ~0 otherwise
 };
 __host__ __device__ __forceinline__ uint32_t tuple_bytes(bool wide) { return wide ? 24u : 20u; }
 
@@ -272,13 +274,14 @@ __device__ __forceinline__ GridTuple ld_tuple(const uint8_t *p, bool wide) {
     const u32x4_a4 a = *(const PCQ_GLOBAL u32x4_a4 *)p;
     const u32x2_a4 b = *(const PCQ_GLOBAL u32x2_a4 *)(p + 16);
     GridTuple t;
-    t.x = (int32_t)a.x, t.y = (int32_t)a.y, t.z = (int32_t)a.z, t.idx = a.w, t.w0 = b.x, t.w1 = wide ? b.y : 0u;
+    t.x = (int32_t)a.x, t.y = (int32_t)a.y, t.z = (int32_t)a.z, t.idx = a.w;
+    t.w0 = wide ? b.x : b.x & 0xffffu, t.w1 = wide ? b.y : 0u, t.sel = wide ? ~0u : b.x >> 16;
     return t;
 }
 __device__ __forceinline__ void st_tuple(uint8_t *p, const GridTuple &t, bool wide) {
     u32x4_a4 a = {(uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx};
     *(PCQ_GLOBAL u32x4_a4 *)p = a;
-    *(PCQ_GLOBAL uint32_t *)(p + 16) = t.w0;
+    *(PCQ_GLOBAL uint32_t *)(p + 16) = wide ? t.w0 : t.w0 | (t.sel << 16);  // (20-byte output: every input was 20 bytes, sel is there)
     if (wide) *(PCQ_GLOBAL uint32_t *)(p + 20) = t.w1;
 }
 __device__ __forceinline__ uint32_t uni32(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
@@ -348,6 +351,12 @@ template <typename G>
 __device__ __forceinline__ TupleEval eval_tuple(const G &g, const EntryRef &entries, const GridTuple &t) {
     const GridEntryDev e = entries.get((t.w0 >> 8) & 0xff);
     return eval_world(g, world(t.x, e.scale[0], e.offset[0]), world(t.y, e.scale[1], e.offset[1]), world(t.z, e.scale[2], e.offset[2]));
+}
+// the second-level partition of a tuple: from the bits pass 0 left in it, or — a tuple with colour — from its cell again
+template <typename G>
+__device__ __forceinline__ uint32_t tuple_sub(const G &g, const EntryRef &entries, const GridTuple &t, uint32_t f2) {
+    if (t.sel != ~0u) return sub_from_sel16(t.sel, f2);
+    return sub_of(cell_hash(eval_tuple(g, entries, t).key), f2);
 }
 // file order among tuples: entries are numbered in scan order; 0 is reserved for an earlier fold's winner
 __device__ __forceinline__ uint64_t ord_of(const GridTuple &t) { return ((uint64_t)((t.w0 >> 8) & 0xff) << 32 | t.idx) + 1; }
@@ -571,8 +580,11 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
                 const bool through = ev.alias || ev.dbits >= 0x7ff0000000000000ull;
                 pk[j] = (through ? 0ull : ((ev.dbits >> AGG_POS_BITS) + 1) << AGG_POS_BITS) | place;
                 metas[j] = bin_of(h) | (((uint32_t)(h >> 24) & (AGG_SLOTS - 1)) << F1_BITS);
+                if (!RGB) rg[j] = sel16_of(h) << 16;  // (no colour: the red half of w0 carries the second level's selector)
             } else {
-                metas[j] = bin_of(cell_hash(key_only(g, px, py, pz)));
+                const uint64_t h = cell_hash(key_only(g, px, py, pz));
+                metas[j] = bin_of(h);
+                if (!RGB) rg[j] = sel16_of(h) << 16;
             }
         }
         if (agg) {
@@ -631,7 +643,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
             const uint64_t i = base + (uint64_t)j * NT + tid;
             const uint32_t at = s_base[metas[j] & (F1 - 1)] + ranks[j];
             s_xyzi[at] = make_uint4((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y, (uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
-            s_w0[at] = cl[j] | (entry << 8) | (rg[j] << 16);
+            s_w0[at] = cl[j] | (entry << 8) | (RGB ? rg[j] << 16 : rg[j]);
             if (RGB) s_w1[at] = (rg[j] >> 16) | (bb[j] << 16);
         }
 #pragma unroll
@@ -985,7 +997,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
     __syncthreads();
     if (P.binbase)
         bin_for_each<L2_NT, L2_FB, L2_UNROLL>(P.src, bin, s_pre, s_addr, [&](const GridTuple &t) {
-            atomicAdd(&s_hist[sub_of(cell_hash(eval_tuple(P.g, P.entries, t).key), f2)], 1u);
+            atomicAdd(&s_hist[tuple_sub(P.g, P.entries, t, f2)], 1u);
         });
     if (P.okeys)
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
@@ -1013,7 +1025,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
     if (P.binbase) {
         const bool wide = P.wide;
         bin_for_each<L2_NT, L2_FB, L2_UNROLL>(P.src, bin, s_pre, s_addr, [&](const GridTuple &t) {
-            const uint32_t pos = atomicAdd(&s_cur[sub_of(cell_hash(eval_tuple(P.g, P.entries, t).key), f2)], 1u);
+            const uint32_t pos = atomicAdd(&s_cur[tuple_sub(P.g, P.entries, t, f2)], 1u);
             st_tuple(P.out + (uint64_t)pos * tuple_bytes(wide), t, wide);
         });
     }
@@ -1113,7 +1125,7 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
 #pragma unroll
                     for (int j = 0; j < L2S_ITEMS; j++) {
                         valid[j] = base + j * L2S_NT + threadIdx.x < hi;
-                        subs[j] = sub_of(cell_hash(eval_tuple(P.g, P.entries, t[j]).key), f2);
+                        subs[j] = tuple_sub(P.g, P.entries, t[j], f2);
                         ranks[j] = 0;
                         if (valid[j]) ranks[j] = atomicAdd(&s_cnt[subs[j]], 1u);
                     }
@@ -1492,54 +1504,65 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                 }
             }
         } else {
-            // the partition's tuples chunk by chunk: `cnt` tuples per round, tuple i of the round through tuple_of(i)
-            uint32_t total_in = 0, f_lo = 0, j0 = 0, nfr = 0;
-            uint32_t reg_pre = 0;
-            uint64_t reg_addr = 0;
             if (BINS) {
+                // The bin through the fragment window, one round per chunk, software-pipelined: a round publishes the window
+                // that covers the NEXT chunk (its entries were asked for, into registers, a round earlier), asks for that
+                // chunk's tuples and for the window behind it, and only then folds the chunk whose tuples the round before
+                // asked for — the search and the memory round trip of a chunk (4.8 of 12 us per chunk when they came first) run
+                // under the fold of the chunk before.
                 const BinSrc &S = P.src;
-                total_in = uni32(ldg(S.preT + (size_t)p * S.Tp1 + S.T));
-                nfr = S.T < (uint32_t)FB ? S.T : (uint32_t)FB;
+                const uint32_t total_in = uni32(ldg(S.preT + (size_t)p * S.Tp1 + S.T));
+                uint32_t f_lo = 0, j0 = 0;  // the next chunk to plan starts at tuple j0 of the bin, in fragment f_lo or behind
+                uint32_t nfr = S.T < (uint32_t)FB ? S.T : (uint32_t)FB;
+                uint32_t reg_pre = 0;
+                uint64_t reg_addr = 0;
                 if (threadIdx.x <= nfr) reg_pre = ldg(S.preT + (size_t)p * S.Tp1 + threadIdx.x);
                 if (threadIdx.x < nfr) reg_addr = frag_addr(S, p, threadIdx.x);
-            } else {
-                total_in = cur_cnt;
-            }
-            while (j0 < total_in) {  // (the same for every thread)
-                uint32_t cnt, j1;
-                if (BINS) {
-                    const BinSrc &S = P.src;
-                    if (threadIdx.x <= nfr) s_pre[threadIdx.x] = reg_pre;
-                    if (threadIdx.x < nfr) s_addr[threadIdx.x] = reg_addr;
-                    __syncthreads();
-                    const uint32_t wend = uni32(s_pre[nfr]);
-                    cnt = wend - j0 < (uint32_t)CHUNK ? wend - j0 : (uint32_t)CHUNK;
-                    j1 = j0 + cnt;
-                    GridTuple tu[FOLD_K];
-                    if (cnt) {
+                GridTuple tu[FOLD_K], tn[FOLD_K];
+                uint32_t cnt_n = 0;
 #pragma unroll
-                        for (int k = 0; k < FOLD_K; k++) {
-                            const uint32_t i = k * NT + threadIdx.x;
-                            tu[k] = frag_ld_tuple(s_pre, s_addr, nfr, j0 + (i < cnt ? i : cnt - 1));
+                for (int k = 0; k < FOLD_K; k++) tn[k] = GridTuple{0, 0, 0, 0, 0, 0, 0};
+                for (;;) {  // (every condition below is the same for the whole workgroup)
+#pragma unroll
+                    for (int k = 0; k < FOLD_K; k++) tu[k] = tn[k];
+                    const uint32_t cnt = cnt_n;
+                    const bool more = j0 < total_in;
+                    if (more) {
+                        if (threadIdx.x <= nfr) s_pre[threadIdx.x] = reg_pre;
+                        if (threadIdx.x < nfr) s_addr[threadIdx.x] = reg_addr;
+                    }
+                    __syncthreads();
+                    cnt_n = 0;
+                    if (more) {
+                        const uint32_t wend = uni32(s_pre[nfr]);
+                        cnt_n = wend - j0 < (uint32_t)CHUNK ? wend - j0 : (uint32_t)CHUNK;
+                        const uint32_t j1 = j0 + cnt_n;
+                        if (cnt_n) {
+#pragma unroll
+                            for (int k = 0; k < FOLD_K; k++) {
+                                const uint32_t i = k * NT + threadIdx.x;
+                                tn[k] = frag_ld_tuple(s_pre, s_addr, nfr, j0 + (i < cnt_n ? i : cnt_n - 1));
+                            }
                         }
+                        // the window behind: from the fragment tuple j1 lies in
+                        const uint32_t f_next = j1 == wend ? f_lo + nfr : f_lo + uni32(frag_find(s_pre, nfr, j1));
+                        const uint32_t nfr_next = S.T - f_next < (uint32_t)FB ? S.T - f_next : (uint32_t)FB;
+                        if (j1 < total_in) {
+                            if (threadIdx.x <= nfr_next) reg_pre = ldg(S.preT + (size_t)p * S.Tp1 + f_next + threadIdx.x);
+                            if (threadIdx.x < nfr_next) reg_addr = frag_addr(S, p, f_next + threadIdx.x);
+                        }
+                        f_lo = f_next, nfr = nfr_next, j0 = j1;
                     }
-                    // the next round's window starts at the fragment tuple j1 lies in; asked for now (behind this round's tuples),
-                    // stored when the round is over
-                    const uint32_t f_next = j1 == wend ? f_lo + nfr : f_lo + uni32(frag_find(s_pre, nfr, j1));
-                    const uint32_t nfr_next = S.T - f_next < (uint32_t)FB ? S.T - f_next : (uint32_t)FB;
-                    if (j1 < total_in) {
-                        if (threadIdx.x <= nfr_next) reg_pre = ldg(S.preT + (size_t)p * S.Tp1 + f_next + threadIdx.x);
-                        if (threadIdx.x < nfr_next) reg_addr = frag_addr(S, p, f_next + threadIdx.x);
+                    if (cnt) {
+                        fold_chunk<NSLOT, NT, FOLD_K, LIMIT>(P, tu, cnt, s_key, s_dist, s_ord, s_aliasbits, s_oldbits, &s_ncell, &s_over, pay);
+                    } else {
+                        if (!more) break;
+                        __syncthreads();  // (nothing folded this round: everyone has read the window before the next round rewrites it)
                     }
-                    f_lo = f_next, nfr = nfr_next;
-                    if (cnt == 0) {  // a window of empty fragments
-                        __syncthreads();  // (everyone has read the window before it is rewritten)
-                        continue;
-                    }
-                    fold_chunk<NSLOT, NT, FOLD_K, LIMIT>(P, tu, cnt, s_key, s_dist, s_ord, s_aliasbits, s_oldbits, &s_ncell, &s_over, pay);
-                } else {
-                    cnt = total_in - j0 < (uint32_t)CHUNK ? total_in - j0 : (uint32_t)CHUNK;
-                    j1 = j0 + cnt;
+                }
+            } else {
+                for (uint32_t j0 = 0; j0 < cur_cnt; j0 += CHUNK) {
+                    const uint32_t cnt = cur_cnt - j0 < (uint32_t)CHUNK ? cur_cnt - j0 : (uint32_t)CHUNK;
                     GridTuple tu[FOLD_K];
 #pragma unroll
                     for (int k = 0; k < FOLD_K; k++) {
@@ -1548,9 +1571,12 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                     }
                     fold_chunk<NSLOT, NT, FOLD_K, LIMIT>(P, tu, cnt, s_key, s_dist, s_ord, s_aliasbits, s_oldbits, &s_ncell, &s_over, pay);
                 }
-                j0 = j1;
             }
-            __threadfence();  // the parked payloads are read back by other threads of the workgroup
+            // The parked payloads are read back by other threads of THIS workgroup: a workgroup-scope fence (the stores have
+            // left the wave; all waves of a workgroup share one L1).  The device-scope fence that stood here made every wave
+            // write the L2's dirty lines back (buffer_wbl2) — 16 times per partition and CU, with the winners of all
+            // partitions in flight.
+            __threadfence_block();
             __syncthreads();
             if (s_over) {  // more cells than the table holds: the host repeats the fold with more partitions
                 if (threadIdx.x == 0) {

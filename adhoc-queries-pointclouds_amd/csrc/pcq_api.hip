@@ -311,6 +311,9 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
 #endif
     } else if (!strcmp(key, "allreduce_single_rank")) {
         ctx->allreduce_single_rank = value != 0;
+    } else if (!strcmp(key, "allreduce_fail")) {
+        if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "allreduce_fail must be 0, 1 or 2");
+        ctx->allreduce_fail = (int)value;
     } else if (!strcmp(key, "grid_pending_budget")) {
         // (points scanned into a grid collector before it folds; a fold's tuple counts and offsets are 32-bit, grid.hip clamps to that)
         if (value < 0 || value > (int64_t)1 << 40) return pcq_fail(PCQ_ERR_ARG, "grid_pending_budget must be 0..2^40");
@@ -363,6 +366,7 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     else if (!strcmp(key, "numa_node")) *value = ctx->numa_node;
     else if (!strcmp(key, "grid_pending_budget")) *value = ctx->grid_pending_budget;
     else if (!strcmp(key, "allreduce_single_rank")) *value = ctx->allreduce_single_rank;
+    else if (!strcmp(key, "allreduce_fail")) *value = ctx->allreduce_fail;
     else if (!strcmp(key, "grid_f2")) *value = ctx->grid_f2;
     else if (!strcmp(key, "grid_agg")) *value = ctx->grid_agg;
     else if (!strcmp(key, "grid_last_tuples")) *value = ctx->grid_last_tuples;

@@ -158,6 +158,7 @@ struct pcq_ctx {
     int64_t grid_pending_budget = 0;    // option: tuples a grid collector may hold before it folds (0 = default)
     int allreduce_single_rank = 0;      // option: pcq_allreduce_sum_u64 with ONE rank still goes through RCCL (communicator of one
                                         // device, ncclAllReduce) — exercises the run-time binding on a single-GPU box
+    int allreduce_fail = 0;             // option (tests): pcq_allreduce_sum_u64 fails — 1: before anything is touched, 2: after the reduction has run
     int grid_f2 = 0;                    // option (tests): second-level fan-out a fold starts from (0 = from the measured estimate)
     int grid_agg = 0;                   // option: pass 0 folds a tile's duplicate cells before they travel — 0 = while it pays (per workgroup),
                                         // 1 = every tile, 2 = never; the results are the same, the tuples moved are not

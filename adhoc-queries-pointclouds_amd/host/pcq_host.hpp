@@ -104,6 +104,9 @@ public:
     // ResultCollector::points_ref (Some only for the buffer collector)
     virtual const std::vector<Point> *points_ref();
     virtual Status point_count(size_t *out);
+    // A collector that is kept while other files are searched takes its compact form now (run_search_parallel keeps one per
+    // file until all are done, main.rs:153-161).  Nothing to do except for the grid collector.
+    virtual Status file_done() { return Status::Ok(); }
     bool has_points() const { return pcq_collector_has_points(handle_) != 0; }
     pcq_collector *handle() const { return handle_; }
     pcq_ctx *context() const { return ctx_; }
@@ -133,6 +136,9 @@ class GridSampledCollector : public ResultCollector {  // collect_points.rs:100-
 public:
     static Status create(pcq_ctx *ctx, const AABB &bounds, double cell_size, std::unique_ptr<ResultCollector> *out);
     std::optional<std::vector<Point>> points() override;
+    // folds the file's matches into per-cell winners: what the reference's HashMap holds at this point (grid_sampling.rs:72-103);
+    // unfolded, the device keeps a tuple per scanned point
+    Status file_done() override { return Status::FromLib(pcq_collector_flush(handle_)); }
 };
 
 // ---- search/last.rs, search/las.rs ---------------------------------------------------------------
@@ -146,8 +152,9 @@ struct FilePlan {
     Status status;               // an error the reference raises before its per-point loop
     bool needs_gpu = false;      // false: resolved on the host
     int las_record_size = -1;    // las.rs:73 (printed even for a file that is then skipped)
-    std::unique_ptr<MappedFile> file;
-    pcq_columns cols{};          // column pointers inside the mapping (execute_plan turns them into file offsets)
+    std::string path;            // opened again by execute_plan, for the duration of the scan
+    uint64_t file_size = 0;      // as the prologue saw it
+    pcq_columns cols{};          // the column "pointers" are byte offsets into the file (pcq_scan_fd)
     pcq_predicate pred{};
 };
 FilePlan plan_last_file_by_bounds_optimized(const std::string &path, const AABB &bounds);

@@ -213,6 +213,17 @@ Status FileDumper::dump_points(const Point *points, size_t n) {
     return Status::Ok();
 }
 
+// The fallback of the count merge: the per-GPU counts, read one by one (main.rs:164-180 as a host loop).
+static uint64_t merge_counts_on_host(const std::vector<pcq_ctx *> &ctxs, const std::vector<const uint64_t *> &counts, Status *status) {
+    uint64_t total = 0;
+    for (size_t k = 0; k < ctxs.size() && status->ok(); k++) {
+        uint64_t part = 0;
+        *status = Status::FromLib(pcq_copy_to_host(ctxs[k], &part, counts[k], 8));
+        total += part;
+    }
+    return total;
+}
+
 // ---- drain shared by both drivers (main.rs:135-141 / :164-180) ---------------------------------------------
 static Status drain(ResultCollector &c, PointDumper &dumper, std::optional<size_t> *num_matches) {
     if (c.has_points() && !dumper.wants_points()) {  // same observable behaviour, no device-to-host copy
@@ -273,6 +284,9 @@ Status run_search_sequential(const std::vector<std::string> &files, const Search
 Status run_search_parallel(const std::vector<std::string> &files, const Searcher &searcher, SearchImplementation impl,
                            const CollectorFactoryFn &factory, PointDumper &dumper, const RunOptions &opt, const PrintFn &print) {
     const size_t nfiles = files.size();
+    const bool timing = getenv("PCQ_TIMING") != nullptr;
+    const auto t_run = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run).count(); };
     std::vector<std::optional<FilePlan>> plans(nfiles);
     std::vector<Status> results(nfiles);
     std::vector<SearchLog> logs(nfiles);
@@ -287,7 +301,7 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
             work.push_back(i);  // no host-only prologue for this format: search_file does everything
         }
     }
-    if (getenv("PCQ_TIMING")) fprintf(stderr, "[pcq] %zu of %zu files need the GPU\n", work.size(), nfiles);
+    if (timing) fprintf(stderr, "[pcq] %zu of %zu files need the GPU (host prologue of all files: %.1f ms)\n", work.size(), nfiles, since());
 
     std::vector<std::unique_ptr<ResultCollector>> collectors(nfiles);
     std::vector<int> file_device(nfiles, -1);
@@ -298,6 +312,9 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
     size_t nthreads = devices.size() * (size_t)tpd;
     if (nthreads > work.size()) nthreads = work.size();  // README.md:12
     const bool counting = !opt.collectors_yield_points;
+    // several GPUs, count query: the RCCL communicator is built on a helper thread while the files are scanned
+    // (ncclCommInitAll is of the order of the whole query on eight GPUs; the all-reduce at the end waits for it)
+    if (counting && devices.size() > 1 && !work.empty()) (void)pcq_allreduce_prepare(devices.data(), (int)devices.size());
     // per-GPU device counters (count queries): owned by the first worker of the device
     std::vector<uint64_t *> dev_counter(devices.size(), nullptr);
     std::vector<pcq_ctx *> dev_ctx(devices.size(), nullptr);
@@ -344,7 +361,8 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
                 const auto t_f = std::chrono::steady_clock::now();
                 Status st = factory(ctx, counter, &collectors[i]);  // :156
                 if (st.ok()) st = plans[i] ? execute_plan(*plans[i], *collectors[i]) : searcher.search_file(files[i], impl, *collectors[i], &logs[i]);  // :158
-                plans[i].reset();  // unmaps the file
+                plans[i].reset();
+                if (st.ok()) st = collectors[i]->file_done();  // a grid keeps its winners, not a tuple per scanned point
                 results[i] = st;
                 file_ms[i] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f).count();
                 if (getenv("PCQ_TIMING")) fprintf(stderr, "[pcq] file %zu searched in %.1f ms\n", i, file_ms[i]);
@@ -368,6 +386,7 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return finished == nthreads; });
     }
+    if (timing) fprintf(stderr, "[pcq] all workers done %.1f ms after the search started\n", since());
     Status final_status = Status::Ok();
     for (size_t i = 0; i < nfiles; i++)
         if (logs[i].las_record_size >= 0) print("Point record size: " + std::to_string(logs[i].las_record_size));
@@ -377,25 +396,29 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         if (!dev_status[d].ok()) final_status = dev_status[d];
     std::optional<size_t> matches;
     if (final_status.ok() && counting) {
-        // :164-180 — the sum over the collectors is the sum over the per-GPU counters: one all-reduce
+        // :164-180 — the sum over the collectors is the sum over the per-GPU counters: one all-reduce, OUT OF PLACE (word 0
+        // of a GPU's counter block is its count, word 1 receives the sum): whatever happens to the collective — and
+        // whenever: before it ran, or on rank 3's stream after all ranks had reduced — the per-GPU counts are still
+        // what they were, so the fallback below cannot read a partially reduced value.
         uint64_t total = 0;
         std::vector<pcq_ctx *> ctxs;
-        std::vector<uint64_t *> counters;
+        std::vector<const uint64_t *> sends;
+        std::vector<uint64_t *> recvs;
         for (size_t d = 0; d < devices.size(); d++)
-            if (dev_counter[d]) ctxs.push_back(dev_ctx[d]), counters.push_back(dev_counter[d]);
+            if (dev_counter[d]) ctxs.push_back(dev_ctx[d]), sends.push_back(dev_counter[d]), recvs.push_back(dev_counter[d] + 1);
         if (!ctxs.empty()) {
-            Status ast = Status::FromLib(pcq_allreduce_sum_u64(ctxs.data(), counters.data(), (int)ctxs.size()));
+            if (const char *inj = getenv("PCQ_TEST_ALLREDUCE_FAIL")) {  // tests: make the collective fail ("early" / "late"), through the real RCCL calls
+                (void)pcq_set_option(ctxs[0], "allreduce_single_rank", 1);
+                (void)pcq_set_option(ctxs[0], "allreduce_fail", !strcmp(inj, "late") ? 2 : 1);
+            }
+            Status ast = Status::FromLib(pcq_allreduce_sum_u64(ctxs.data(), sends.data(), recvs.data(), (int)ctxs.size()));
             if (ast.ok()) {
-                final_status = Status::FromLib(pcq_copy_to_host(ctxs[0], &total, counters[0], 8));
+                final_status = Status::FromLib(pcq_copy_to_host(ctxs[0], &total, recvs[0], 8));
             } else {
-                // RCCL missing or unusable must not turn a correct answer into an error: the per-GPU counters are
-                // exact, so they are read one by one and summed here
+                // RCCL missing or unusable must not turn a correct answer into an error: the per-GPU counts are exact, so
+                // they are read one by one and summed here
                 fprintf(stderr, "warning: all-reduce of the per-GPU counts failed (%s); summing on the host\n", ast.message.c_str());
-                for (size_t k = 0; k < ctxs.size() && final_status.ok(); k++) {
-                    uint64_t part = 0;
-                    final_status = Status::FromLib(pcq_copy_to_host(ctxs[k], &part, counters[k], 8));
-                    total += part;
-                }
+                total = merge_counts_on_host(ctxs, sends, &final_status);
             }
         }
         if (nfiles) matches = (size_t)total;  // no collector at all: num_matches stays None (main.rs:164)
@@ -406,12 +429,14 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
             final_status = drain(*collectors[i], dumper, &none);
         }
     }
+    if (timing) fprintf(stderr, "[pcq] results merged / drained %.1f ms after the search started\n", since());
     {
         std::unique_lock<std::mutex> lk(mu);
         release = true;
         cv.notify_all();
     }
     for (auto &th : pool) th.join();
+    if (timing) fprintf(stderr, "[pcq] contexts released %.1f ms after the search started\n", since());
     if (opt.stats)
         for (size_t i = 0; i < nfiles; i++) opt.stats->push_back({files[i], file_device[i], file_ms[i]});
     if (!final_status.ok()) return final_status;

@@ -5,6 +5,11 @@
 // and then hands the column blocks to libpcq.so, which replaces the loop and the collector pushes.
 #include "pcq_host.hpp"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
 #include <cstring>
 
 namespace pcq {
@@ -98,22 +103,25 @@ bool block_ok(const MappedFile &f, uint64_t off, uint64_t bytes) { return off <=
 
 }  // namespace
 
-// The column blocks were located in the mapped file (header parse, offsets: exactly as the reference
-// does); the bytes themselves are streamed by the library with pread from the same file, so `cols`
-// carries file offsets instead of addresses inside the mapping.
+// The column blocks were located in the mapped file (header parse, offsets: exactly as the reference does); the
+// bytes themselves are streamed by the library with pread, so a plan carries FILE OFFSETS instead of addresses inside a
+// mapping — and nothing else of the file: the mapping and the descriptor of the prologue are gone when the plan is
+// returned, and the file is opened again here, for the duration of its scan.  (run_search_parallel plans every file before
+// the first worker starts; a plan that kept its file open put a query over a thousand files past RLIMIT_NOFILE, where the
+// reference — which opens inside the rayon task — has at most one file per thread open.)
 Status execute_plan(FilePlan &plan, ResultCollector &rc) {
     if (!plan.status.ok() || !plan.needs_gpu) return plan.status;
     pcq_columns cols = plan.cols;
     cols.first_index = rc.next_index;
-    const MappedFile &file = *plan.file;
-    auto to_offset = [&](const void *p) -> const void * {
-        return p ? (const void *)(uintptr_t)((const uint8_t *)p - file.data()) : nullptr;
-    };
-    // a NULL column must stay NULL, and offset 0 never is a column (the header lives there)
-    cols.xyz = to_offset(cols.xyz);
-    cols.cls = to_offset(cols.cls);
-    cols.rgb = to_offset(cols.rgb);
-    const int r = pcq_scan_fd(rc.context(), file.fd(), &cols, &plan.pred, rc.handle());
+    const int fd = ::open(plan.path.c_str(), O_RDONLY);
+    if (fd < 0) return Status::Err(PCQ_ERR_IO, plan.path + ": " + strerror(errno));
+    struct stat st;
+    if (fstat(fd, &st) != 0 || (uint64_t)st.st_size < plan.file_size) {  // (truncated between the prologue and the scan)
+        ::close(fd);
+        return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
+    }
+    const int r = pcq_scan_fd(rc.context(), fd, &cols, &plan.pred, rc.handle());
+    ::close(fd);
     rc.next_index += cols.n;
     return Status::FromLib(r);
 }
@@ -124,6 +132,21 @@ FilePlan done(Status st = Status::Ok()) {
     FilePlan p;
     p.status = std::move(st);
     return p;
+}
+// `cols` points into the mapping of `file`: the plan keeps the offsets (a NULL column stays NULL; offset 0 never is a
+// column, the header lives there)
+FilePlan gpu(const std::string &path, const MappedFile &file, pcq_columns cols, const pcq_predicate &pred) {
+    auto to_offset = [&](const void *p) -> const void * { return p ? (const void *)(uintptr_t)((const uint8_t *)p - file.data()) : nullptr; };
+    cols.xyz = to_offset(cols.xyz);
+    cols.cls = to_offset(cols.cls);
+    cols.rgb = to_offset(cols.rgb);
+    FilePlan plan;
+    plan.needs_gpu = true;
+    plan.path = path;
+    plan.file_size = file.size();
+    plan.cols = cols;
+    plan.pred = pred;
+    return plan;
 }
 }  // namespace
 
@@ -166,12 +189,7 @@ FilePlan plan_last_file_by_bounds_optimized(const std::string &path, const AABB 
     cols.rgb_stride = 6;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :156-160
-    FilePlan plan;
-    plan.needs_gpu = true;
-    plan.file = std::move(holder);
-    plan.cols = cols;
-    plan.pred = pred;
-    return plan;
+    return gpu(path, file, cols, pred);
 }
 Status search_last_file_by_bounds_optimized(const std::string &path, const AABB &bounds, ResultCollector &rc) {
     FilePlan plan = plan_last_file_by_bounds_optimized(path, bounds);
@@ -213,12 +231,7 @@ FilePlan plan_last_file_by_classification_optimized(const std::string &path, uin
     cols.rgb_stride = 6;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :283-287
-    FilePlan plan;
-    plan.needs_gpu = true;
-    plan.file = std::move(holder);
-    plan.cols = cols;
-    plan.pred = pred;
-    return plan;
+    return gpu(path, file, cols, pred);
 }
 Status search_last_file_by_classification_optimized(const std::string &path, uint8_t cls, ResultCollector &rc) {
     FilePlan plan = plan_last_file_by_classification_optimized(path, cls);
@@ -259,11 +272,7 @@ FilePlan plan_las_file_by_bounds_optimized(const std::string &path, const AABB &
     cols.xyz_stride = cols.cls_stride = cols.rgb_stride = rl;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :138-142
-    FilePlan plan;
-    plan.needs_gpu = true;
-    plan.file = std::move(holder);
-    plan.cols = cols;
-    plan.pred = pred;
+    FilePlan plan = gpu(path, file, cols, pred);
     plan.las_record_size = rec;
     return plan;
 }
@@ -302,12 +311,7 @@ FilePlan plan_las_file_by_classification_optimized(const std::string &path, uint
     cols.xyz_stride = cols.cls_stride = cols.rgb_stride = rl;
     cols.n = n;
     for (int a = 0; a < 3; a++) cols.scale[a] = h.scale[a], cols.offset[a] = h.offset[a];  // :251-255
-    FilePlan plan;
-    plan.needs_gpu = true;
-    plan.file = std::move(holder);
-    plan.cols = cols;
-    plan.pred = pred;
-    return plan;
+    return gpu(path, file, cols, pred);
 }
 Status search_las_file_by_classification_optimized(const std::string &path, uint8_t cls, ResultCollector &rc) {
     FilePlan plan = plan_las_file_by_classification_optimized(path, cls);

@@ -233,6 +233,14 @@ def main():
     for w in pending:  # every all-reduce of the timed queries has completed before the clock stops
         w.wait()
     pending.clear()
+    if use_dist:
+        # Every rank says what it did BEFORE the closing barrier: a scaling run that hangs or fails there can be read from
+        # the tail of its stderr (which rank never arrived, on which device, after how much work).
+        torch.cuda.synchronize()
+        sys.stderr.write("[bench] rank %d/%d local_rank %d device %s uuid %s: scanned %d points per query, %d queries in %.3f s (own clock)\n" % (
+            rank, world, local_rank, torch.cuda.get_device_name(dev), str(getattr(torch.cuda.get_device_properties(dev), "uuid", "?")),
+            scanned_local, args.steps, time.perf_counter() - t0))
+        sys.stderr.flush()
     barrier()
     elapsed = time.perf_counter() - t0
     # every timed query produced the answer (nothing was skipped or cached: each query wrote its own slot)

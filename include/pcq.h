@@ -226,12 +226,16 @@ int pcq_scan_dev_indexed(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predic
                          pcq_collector *c, void *stream);
 
 /* The one collective of the path (main.rs:164-180) for callers that drive n GPUs from ONE process:
- * device_counters[i] (8 bytes in ctxs[i]'s HBM, e.g. of pcq_collector_new_count_at) all become the sum
- * over i — a single RCCL all-reduce(sum, u64, count = 1) over an intra-node communicator (xGMI).
- * Synchronous.  One rank per GPU (two entries on one device are refused).  n == 1 is a no-op unless option
- * "allreduce_single_rank" is set on ctxs[0] (then the one-rank communicator and the all-reduce really run).
- * RCCL is bound at run time; failure to find it is an error. */
-int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, uint64_t *const *device_counters, int n);
+ * recv[i][0] = the sum over i of send[i][0] (8 bytes each in ctxs[i]'s HBM, e.g. the counter of
+ * pcq_collector_new_count_at) — a single RCCL all-reduce(sum, u64, count = 1) over an intra-node communicator (xGMI).
+ * Synchronous.  recv[i] may be send[i]; callers that want to fall back to summing the per-GPU values themselves when the
+ * collective fails pass a different word, so that send[] is never touched.  One rank per GPU (two entries on one device
+ * are refused).  n == 1 copies send to recv without RCCL unless option "allreduce_single_rank" is set on ctxs[0] (then
+ * the one-rank communicator and the all-reduce really run).  RCCL is bound at run time; failure to find it is an error.
+ * pcq_allreduce_prepare(devices, n) builds the communicator for that device list on a helper thread and returns at once
+ * (ncclCommInitAll overlaps the scans); the all-reduce waits for it. */
+int pcq_allreduce_prepare(const int *devices, int n);
+int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, const uint64_t *const *send, uint64_t *const *recv, int n);
 
 /* Device memory helpers for callers that keep column blocks resident in HBM. */
 int pcq_device_alloc(pcq_ctx *ctx, uint64_t bytes, void **out);

@@ -22,17 +22,35 @@ QUERY = os.path.join(ROOT, "adhoc-queries-pointclouds_amd", "host", "query")
 ORACLE = os.path.join(ROOT, "oracle", "query_oracle")
 
 
-def run(exe, args, repeat=3):
-    best, out = None, None
+ALL_TIMES = {}
+
+
+def run(exe, args, repeat=3, tag=None):
+    best, out, times = None, None, []
     for _ in range(repeat):
         t0 = time.perf_counter()
         r = subprocess.run([exe] + args, capture_output=True, text=True)
         dt = time.perf_counter() - t0
         if r.returncode != 0:
             raise SystemExit(f"{exe} failed: {r.stderr}")
+        times.append(round(dt, 4))
         best = dt if best is None or dt < best else best
         out = [l for l in r.stdout.splitlines() if not l.startswith("Searched")]
+    if tag:
+        ALL_TIMES[tag] = times
     return best, out
+
+
+def phases(exe, args):
+    """One more run with PCQ_TIMING=1: the per-phase lines (plans, context ready, per file, merge) of the CLI's stderr."""
+    r = subprocess.run([exe] + args, capture_output=True, text=True, env=dict(os.environ, PCQ_TIMING="1"))
+    lines = [l for l in r.stderr.splitlines() if l.startswith("[pcq]") or l.startswith("pcq:")]
+    files = [float(l.split(" searched in ")[1].split(" ms")[0]) for l in lines if " searched in " in l]
+    keep = [l for l in lines if " searched in " not in l and "pool block" not in l]
+    if files:
+        keep.append("[pcq] %d files searched, per file min %.1f / median %.1f / max %.1f ms, sum %.1f ms" % (
+            len(files), min(files), sorted(files)[len(files) // 2], max(files), sum(files)))
+    return keep
 
 
 def main():
@@ -53,13 +71,16 @@ def main():
                     ("class_6", ["--class", "6"]), ("bounds_XL_density_100", ["--bounds", xl, "--density", "100"]),
                     ("bounds_XL_density_10", ["--bounds", xl, "--density", "10"])):
         base = ["-i", d, "--optimized", "--parallel"] + q
-        t_gpu, out_gpu = run(QUERY, base + ["--threads-per-gpu", str(args.threads_per_gpu)])
+        t_gpu, out_gpu = run(QUERY, base + ["--threads-per-gpu", str(args.threads_per_gpu)], repeat=5, tag=name)
+        for l in phases(QUERY, base + ["--threads-per-gpu", str(args.threads_per_gpu)]):
+            print("   ", name, l, flush=True)
         t_gpu2, _ = run(QUERY, base + ["--threads-per-gpu", "2"])
         t_gpu8, _ = run(QUERY, base + ["--threads-per-gpu", "4"])
         t_cpu, out_cpu = run(ORACLE, base, repeat=1)
         assert sorted(out_gpu) == sorted(out_cpu), (out_gpu, out_cpu)
         res[name] = {"gpu_cli_s": t_gpu, "gpu_cli_s_2thr": t_gpu2, "gpu_cli_s_4thr": t_gpu8, "oracle_cli_s": t_cpu, "gpu_Mpts_per_s": total_pts / t_gpu / 1e6,
                      "oracle_cli_Mpts_per_s": total_pts / t_cpu / 1e6, "stdout": out_gpu[-1] if out_gpu else ""}
+        res[name]["gpu_cli_all_runs_s"] = ALL_TIMES.get(name)
         print(name, json.dumps(res[name]), flush=True)
     for f in os.listdir(d):
         os.remove(os.path.join(d, f))

@@ -429,6 +429,49 @@ def test_cli_query_resolved_on_the_host_never_wakes_the_gpu(files):
         assert rc_p == rc_o == 0 and sorted(body_p) == sorted(body_o) and "context on device" not in err_p
 
 
+@pytest.mark.parametrize("when", ["early", "late"])
+def test_cli_count_merge_survives_a_failing_allreduce(files, when):
+    """main.rs:164-180 on several GPUs is one RCCL all-reduce of the per-GPU counters.  When the collective fails — before
+    it touched anything, or after the reduction had run on every rank (a late stream error) — the CLI sums the per-GPU
+    counts on the host: the all-reduce is out of place, so those counts are never a partially reduced value, and the
+    printed count is the oracle's either way (with the warning on stderr).  The failure is injected into the real RCCL
+    call path (one-rank communicator; several GPUs are not available to the tests)."""
+    d = os.path.dirname(files[0])
+    for query_args in (["--bounds", "0;-400;-100;200;0;100"], ["--class", "6"]):
+        args = ["-i", d, "--optimized", "--parallel"] + query_args
+        rc_p, body_p, _, err_p = _cli(QUERY, args, env={"PCQ_TEST_ALLREDUCE_FAIL": when})
+        rc_o, body_o, _, _ = _cli(ORACLE_CLI, args)
+        assert rc_p == rc_o == 0, err_p
+        assert sorted(body_p) == sorted(body_o)
+        assert "all-reduce of the per-GPU counts failed" in err_p and "injected failure" in err_p and "summing on the host" in err_p
+        assert ("before the reduction" if when == "early" else "after the reduction") in err_p
+
+
+def test_cli_more_files_than_descriptors(oracle, tmp_path):
+    """run_search_parallel plans every file before the first worker starts; a plan keeps the header's values, not the open
+    file (the reference opens inside the rayon task: at most one file per thread is open at a time).  1100 small LAST files
+    under a descriptor limit of 256: same stdout as the oracle CLI."""
+    import resource
+    n_files, n = 1100, 41
+    d = tmp_path / "many"
+    d.mkdir()
+    for k in range(n_files):
+        spec = specs._spec(70000 + k, n, 1, (0.01, 0.01, 0.01), (0.0, 0.0, 0.0), (-5000, -5000, -1000), (10001, 10001, 2001), zo=None,
+                           classes=[(1, 0.5), (6, 0.5)])
+        oracle.synth_image(spec, transposed=True).tofile(str(d / f"f{k:04d}.last"))
+    args = ["-i", str(d), "--optimized", "--parallel", "--bounds", "-20;-20;-5;20;20;5"]
+
+    def limited():
+        resource.setrlimit(resource.RLIMIT_NOFILE, (256, 256))
+
+    r = subprocess.run([QUERY] + args, capture_output=True, text=True, preexec_fn=limited)
+    rc_o, body_o, _, _ = _cli(ORACLE_CLI, args)
+    assert r.returncode == rc_o == 0, r.stderr[-2000:]
+    body_p = [l for l in r.stdout.splitlines() if not l.startswith("Searched ")]
+    assert sorted(body_p) == sorted(body_o)
+    assert body_p[0] == f"Searching {n_files} files..."
+
+
 def test_package_before_torch_shares_one_hip_runtime(tmp_path):
     """PyTorch ships its own libamdhip64 (same SONAME as ROCm's).  Whichever is imported first, the process must end up
     with ONE runtime: the package maps torch's copy before libpcq.so when torch is installed (binding._one_hip_runtime)."""

@@ -510,38 +510,56 @@ def test_synth_device_generator_is_bit_identical(oracle, gpu_ctx):
 
 def test_allreduce_single_rank_through_the_real_rccl_calls(gpu_ctx):
     """With option "allreduce_single_rank" a ONE-rank all-reduce still binds RCCL at run time (dlopen, the six symbols),
-    builds a communicator of one device and runs ncclAllReduce(sum, ncclUint64 = 5, count 1) on the context's stream:
-    the whole call path of the multi-GPU merge (main.rs:164-180), minus a second GPU.  Two entries on one device are
-    refused (one rank per GPU)."""
+    builds a communicator of one device — here on the helper thread of pcq_allreduce_prepare, as the CLI does — and runs
+    ncclAllReduce(sum, ncclUint64 = 5, count 1) on the context's stream, out of place (word 0 -> word 1): the whole call
+    path of the multi-GPU merge (main.rs:164-180), minus a second GPU.  Two entries on one device are refused (one rank
+    per GPU).  The injected failures (option "allreduce_fail") leave the value that was sent untouched — what the CLI's
+    host-side fallback sums."""
     d = gpu_ctx.alloc(16)
-    gpu_ctx.to_device(d, np.array([98765432109876543], dtype=np.uint64))
+    gpu_ctx.to_device(d, np.array([98765432109876543, 7], dtype=np.uint64))
     ctxs = (C.c_void_p * 2)(gpu_ctx.handle.value, gpu_ctx.handle.value)
-    ptrs = (C.c_void_p * 2)(d, d)
+    send = (C.c_void_p * 2)(d, d)
+    recv = (C.c_void_p * 2)(d + 8, d + 8)
     gpu_ctx.set_option("allreduce_single_rank", 1)
     try:
-        for _ in range(3):  # the communicator is built once and reused
-            assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, ptrs, 1) == 0, gpu_ctx.lib.pcq_last_error()
-        out = np.zeros(1, dtype=np.uint64)
+        devs = (C.c_int * 1)(0)  # the fixture's context is on device 0
+        assert gpu_ctx.lib.pcq_allreduce_prepare(devs, 1) == 0
+        for _ in range(3):  # the communicator is built once (by the helper thread) and reused
+            assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, recv, 1) == 0, gpu_ctx.lib.pcq_last_error()
+        out = np.zeros(2, dtype=np.uint64)
         gpu_ctx.to_host(out, d)
-        assert int(out[0]) == 98765432109876543
-        assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, ptrs, 2) == -8  # PCQ_ERR_ARG: both on device 0
+        assert [int(v) for v in out] == [98765432109876543, 98765432109876543]
+        assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, send, 1) == 0  # in place is allowed
+        assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, recv, 2) == -8  # PCQ_ERR_ARG: both on device 0
         assert b"one rank per GPU" in gpu_ctx.lib.pcq_last_error()
+        for mode, where in ((1, b"before"), (2, b"after")):
+            gpu_ctx.to_device(d + 8, np.array([0], dtype=np.uint64))
+            gpu_ctx.set_option("allreduce_fail", mode)
+            assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, recv, 1) != 0
+            assert b"injected failure" in gpu_ctx.lib.pcq_last_error() and where in gpu_ctx.lib.pcq_last_error()
+            gpu_ctx.set_option("allreduce_fail", 0)
+            gpu_ctx.to_host(out, d)
+            assert int(out[0]) == 98765432109876543                      # what was sent is what the fallback reads
+            assert int(out[1]) == (0 if mode == 1 else 98765432109876543)  # the late failure comes after the reduction ran
+        assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, recv, 1) == 0  # and the next collective is not swallowed
     finally:
+        gpu_ctx.set_option("allreduce_fail", 0)
         gpu_ctx.set_option("allreduce_single_rank", 0)
         gpu_ctx.free(d)
 
 
 def test_allreduce_entry_point_single_rank(gpu_ctx):
-    """pcq_allreduce_sum_u64 with one rank is the identity (the n > 1 RCCL path needs several GPUs)."""
+    """pcq_allreduce_sum_u64 with one rank copies the value (the n > 1 RCCL path needs several GPUs)."""
     d = gpu_ctx.alloc(16)
-    gpu_ctx.to_device(d, np.array([12345678901234567], dtype=np.uint64))
+    gpu_ctx.to_device(d, np.array([12345678901234567, 0], dtype=np.uint64))
     ctxs = (C.c_void_p * 1)(gpu_ctx.handle.value)
-    ptrs = (C.c_void_p * 1)(d)
-    assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, ptrs, 1) == 0
-    out = np.zeros(1, dtype=np.uint64)
+    send = (C.c_void_p * 1)(d)
+    recv = (C.c_void_p * 1)(d + 8)
+    assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, recv, 1) == 0
+    out = np.zeros(2, dtype=np.uint64)
     gpu_ctx.to_host(out, d)
     gpu_ctx.free(d)
-    assert int(out[0]) == 12345678901234567
+    assert [int(v) for v in out] == [12345678901234567, 12345678901234567]
 
 
 def test_class_count_batch_matches_sum_of_files(oracle, gpu_ctx):
