@@ -454,6 +454,23 @@ __device__ __forceinline__ P0In<KIND> p0_load(const DevCols &c, uint64_t i) {
     else in.rp = ld_xyz_stream(c, i);
     return in;
 }
+// The same for point `li` of the tile that starts at point `base` (li clamped to the tile's last point).  PACKED: the
+// columns are LAST blocks — 12-byte positions at a 4-byte aligned address, one class byte per point, 6-byte colours — so
+// that a point's address is the tile's (the same for the whole workgroup, scalar registers) plus a 32-bit offset, instead
+// of a 64-bit multiply-add and an alignment test per point and column.
+template <int KIND, bool PACKED>
+__device__ __forceinline__ P0In<KIND> p0_load_tile(const DevCols &c, uint64_t base, uint32_t li, uint32_t nvalid) {
+    const uint32_t lc = li < nvalid ? li : nvalid - 1;
+    if (!PACKED) return p0_load<KIND>(c, base + lc);
+    P0In<KIND> in;
+    if (KIND == PCQ_PRED_CLASS) {
+        in.cls = *(const PCQ_GLOBAL uint8_t *)(c.cls + base + lc);
+    } else {
+        const i32x3_a4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x3_a4 *>(c.xyz + base * 12) + lc);
+        in.rp.x = v.x, in.rp.y = v.y, in.rp.z = v.z;
+    }
+    return in;
+}
 template <int KIND>
 __device__ __forceinline__ bool p0_pass(const DevCols &c, const DevPred &pr, const P0In<KIND> &in) {
     if (KIND == PCQ_PRED_CLASS) return in.cls == pr.cls;
@@ -500,7 +517,7 @@ __device__ __forceinline__ uint64_t key_only(const DevGrid &g, double px, double
 // them until the staging); the next tile's positions were asked for before that and are waited for BEFORE this tile's
 // stores are issued.  A load in a branch of its own (`c.cls ? c.cls[i] : 0` in an unrolled loop) is a serial round trip
 // per point.
-template <int KIND, bool RGB>
+template <int KIND, bool RGB, bool PACKED>
 __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, DevGrid g, uint32_t ntiles, uint8_t *__restrict__ out,
                                                       uint16_t *__restrict__ dir, uint32_t entry, uint64_t idx_base, int agg_mode) {
     constexpr int NT = P0_NT, ITEMS = P0_ITEMS;
@@ -522,12 +539,14 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
     uint32_t agg_skip = 0, agg_backoff = 1, parity = 0;
     uint32_t tile = blockIdx.x;
     P0In<KIND> cur[ITEMS], nxt[ITEMS];
+    auto tile_points = [&](uint32_t t) {  // points of tile t (the last one may be short)
+        const uint64_t left = c.n - (uint64_t)t * P0_TILE;
+        return left < (uint64_t)P0_TILE ? (uint32_t)left : (uint32_t)P0_TILE;
+    };
     if (tile < ntiles) {
+        const uint32_t nv = tile_points(tile);
 #pragma unroll
-        for (int j = 0; j < ITEMS; j++) {
-            const uint64_t i = (uint64_t)tile * P0_TILE + (uint64_t)j * NT + tid;
-            cur[j] = p0_load<KIND>(c, i < c.n ? i : c.n - 1);
-        }
+        for (int j = 0; j < ITEMS; j++) cur[j] = p0_load_tile<KIND, PACKED>(c, (uint64_t)tile * P0_TILE, (uint32_t)j * NT + tid, nv);
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {  // (arrived: inside the loop nothing is pending at its head)
@@ -537,12 +556,11 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
     for (; tile < ntiles; tile += gridDim.x, parity ^= 1) {
         const uint64_t base = (uint64_t)tile * P0_TILE;
         const uint32_t ntile = tile + gridDim.x;
+        const uint32_t nvalid = tile_points(tile);
         if (ntile < ntiles) {
+            const uint32_t nv = tile_points(ntile);
 #pragma unroll
-            for (int j = 0; j < ITEMS; j++) {
-                const uint64_t i = (uint64_t)ntile * P0_TILE + (uint64_t)j * NT + tid;
-                nxt[j] = p0_load<KIND>(c, i < c.n ? i : c.n - 1);
-            }
+            for (int j = 0; j < ITEMS; j++) nxt[j] = p0_load_tile<KIND, PACKED>(c, (uint64_t)ntile * P0_TILE, (uint32_t)j * NT + tid, nv);
         }
         const bool agg = agg_mode == 1 || (agg_mode == 0 && agg_skip == 0);  // (the same for the whole workgroup)
         bool passes[ITEMS];
@@ -550,18 +568,26 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
         uint64_t pk[ITEMS];
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
-            const uint64_t i = base + (uint64_t)j * NT + tid;
-            passes[j] = i < c.n && p0_pass<KIND>(c, pr, cur[j]);
+            const uint32_t li = (uint32_t)j * NT + tid;
+            const uint64_t i = base + li;
+            passes[j] = li < nvalid && p0_pass<KIND>(c, pr, cur[j]);
             rg[j] = 0, bb[j] = 0, cl[j] = KIND == PCQ_PRED_CLASS ? cur[j].cls : 0;
             pk[j] = 0, metas[j] = 0, ranks[j] = 0;
             if (!passes[j]) continue;
-            if (KIND == PCQ_PRED_CLASS) cur[j].rp = ld_xyz(c, i);
+            if (KIND == PCQ_PRED_CLASS) {
+                if (PACKED) {
+                    const i32x3_a4 v = *((const PCQ_GLOBAL i32x3_a4 *)(c.xyz + base * 12) + li);
+                    cur[j].rp.x = v.x, cur[j].rp.y = v.y, cur[j].rp.z = v.z;
+                } else {
+                    cur[j].rp = ld_xyz(c, i);
+                }
+            }
             if (RGB) {  // last.rs:145-153
-                const uint8_t *q = c.rgb + i * c.rgb_stride;
+                const uint8_t *q = PACKED ? c.rgb + base * 6 + li * 6u : c.rgb + i * c.rgb_stride;
                 rg[j] = ld_u16(q) | (ld_u16(q + 2) << 16);
                 bb[j] = ld_u16(q + 4);
             }
-            if (KIND != PCQ_PRED_CLASS && c.cls) cl[j] = c.cls[i * c.cls_stride];  // last.rs:138-142
+            if (KIND != PCQ_PRED_CLASS && c.cls) cl[j] = PACKED ? *(const PCQ_GLOBAL uint8_t *)(c.cls + base + li) : c.cls[i * c.cls_stride];  // last.rs:138-142
         }
         if (agg)
             for (uint32_t k = tid; k < (uint32_t)AGG_SLOTS; k += NT) s_atab[k] = ~0ull;
@@ -640,9 +666,8 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
             if (!passes[j]) continue;
-            const uint64_t i = base + (uint64_t)j * NT + tid;
             const uint32_t at = s_base[metas[j] & (F1 - 1)] + ranks[j];
-            s_xyzi[at] = make_uint4((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y, (uint32_t)cur[j].rp.z, (uint32_t)(idx_base + i));
+            s_xyzi[at] = make_uint4((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y, (uint32_t)cur[j].rp.z, (uint32_t)(idx_base + base) + (uint32_t)j * NT + tid);
             s_w0[at] = cl[j] | (entry << 8) | (RGB ? rg[j] << 16 : rg[j]);
             if (RGB) s_w1[at] = (rg[j] >> 16) | (bb[j] << 16);
         }
@@ -2219,15 +2244,22 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         const DevGrid &g = c->grid;
         const unsigned nblocks = ntiles < (uint32_t)ctx->num_cus ? ntiles : (unsigned)ctx->num_cus;  // one workgroup per CU is resident (LDS)
         const int agg = ctx->grid_agg;
-#define PCQ_P0(KIND)                                                                                                                        \
-    do {                                                                                                                                    \
-        if (wide) hipLaunchKernelGGL((k_p0_part<KIND, true>), dim3(nblocks), dim3(P0_NT), 0, s, cols, pred, g, ntiles, run.tuples, run.dir, entry, idx_base, agg);  \
-        else hipLaunchKernelGGL((k_p0_part<KIND, false>), dim3(nblocks), dim3(P0_NT), 0, s, cols, pred, g, ntiles, run.tuples, run.dir, entry, idx_base, agg);     \
+        // LAST blocks (12-byte positions at an aligned address, a class byte per point, 6-byte colours): the short index arithmetic
+        const bool packed = cols.xyz_stride == 12 && ((uintptr_t)cols.xyz & 3) == 0 && (!cols.cls || cols.cls_stride == 1) && (!cols.rgb || cols.rgb_stride == 6);
+#define PCQ_P0_LAUNCH(KIND, RGB, PACKED) \
+    hipLaunchKernelGGL((k_p0_part<KIND, RGB, PACKED>), dim3(nblocks), dim3(P0_NT), 0, s, cols, pred, g, ntiles, run.tuples, run.dir, entry, idx_base, agg)
+#define PCQ_P0(KIND)                                            \
+    do {                                                        \
+        if (wide && packed) PCQ_P0_LAUNCH(KIND, true, true);    \
+        else if (wide) PCQ_P0_LAUNCH(KIND, true, false);        \
+        else if (packed) PCQ_P0_LAUNCH(KIND, false, true);      \
+        else PCQ_P0_LAUNCH(KIND, false, false);                 \
     } while (0)
         if (pred.kind == PCQ_PRED_BOUNDS) PCQ_P0(PCQ_PRED_BOUNDS);
         else if (pred.kind == PCQ_PRED_CLASS) PCQ_P0(PCQ_PRED_CLASS);
         else PCQ_P0(PCQ_PRED_BOUNDS_F64);
 #undef PCQ_P0
+#undef PCQ_P0_LAUNCH
         PCQ_HIP(hipGetLastError());
         gs->runs.push_back(run);
     }
