@@ -466,7 +466,7 @@ __device__ __forceinline__ P0In<KIND> p0_load_tile(const DevCols &c, uint64_t ba
     if (KIND == PCQ_PRED_CLASS) {
         in.cls = *(const PCQ_GLOBAL uint8_t *)(c.cls + base + lc);
     } else {
-        const i32x3_a4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x3_a4 *>(c.xyz + base * 12) + lc);
+        const i32x3_a4 v = __builtin_nontemporal_load(reinterpret_cast<const i32x3_a4 *>(c.xyz + base * 12 + lc * 12u));  // (sizeof(i32x3) is 16: bytes, not elements)
         in.rp.x = v.x, in.rp.y = v.y, in.rp.z = v.z;
     }
     return in;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
             if (!passes[j]) continue;
             if (KIND == PCQ_PRED_CLASS) {
                 if (PACKED) {
-                    const i32x3_a4 v = *((const PCQ_GLOBAL i32x3_a4 *)(c.xyz + base * 12) + li);
+                    const i32x3_a4 v = *(const PCQ_GLOBAL i32x3_a4 *)(c.xyz + base * 12 + li * 12u);
                     cur[j].rp.x = v.x, cur[j].rp.y = v.y, cur[j].rp.z = v.z;
                 } else {
                     cur[j].rp = ld_xyz(c, i);
