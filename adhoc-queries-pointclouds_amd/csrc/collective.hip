@@ -41,6 +41,9 @@ std::mutex g_mu;
 
 int load_rccl() {
     if (g_rccl.lib) return PCQ_OK;
+    // RCCL writes its banner and its NCCL_DEBUG output to stdout; the stdout of a query is the reference's (main.rs:289,
+    // :179, :313-316) and nothing else.  Whatever level the environment asks for goes to stderr unless it names a file.
+    setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *n : names) {
         g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);

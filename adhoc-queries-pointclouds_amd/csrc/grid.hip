@@ -64,6 +64,7 @@ constexpr int DIR_WORDS = F1 / 2 + 1;  // the 513 entries as 32-bit words
 constexpr int AGG_SLOTS = 8192;        // pass 0: slots of the tile's duplicate table
 constexpr int AGG_POS_BITS = 13;       // a tuple's place in its tile (< 5120) in the low bits of a table word
 static_assert(P0_TILE <= (1 << AGG_POS_BITS) && P0_TILE <= 65535, "tile places fit the table word and the 16-bit directory");
+static_assert((P0_TILE * 20) % 16 == 0 && (P0_TILE * 24) % 16 == 0, "a tile's block starts 16-byte aligned and holds whole 16-byte words");
 // The fold's shapes.  BIG: one 1024-thread workgroup owns a CU's whole LDS — 6400 slots of {key, distance, file order},
 // the winner's payload parked in HBM scratch — and folds a level-1 bin directly (coarse grids: few cells, many tuples
 // per cell).  SMALL / DENSE: 2048 slots, three workgroups per CU, a whole partition of the second level (about 1000
@@ -526,9 +527,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
     constexpr int AGG_BYTES = P0_TILE * 8 + AGG_SLOTS * 8;
     constexpr int RAW_BYTES = STAGE_BYTES > AGG_BYTES ? STAGE_BYTES : AGG_BYTES;
     __shared__ __attribute__((aligned(16))) uint8_t s_raw[RAW_BYTES];  // the tile's sorted image; before that, the duplicate table
-    uint4 *s_xyzi = reinterpret_cast<uint4 *>(s_raw);                          // x, y, z, idx
-    uint32_t *s_w0 = reinterpret_cast<uint32_t *>(s_raw + P0_TILE * 16);       // w0 [, w1]
-    uint32_t *s_w1 = s_w0 + P0_TILE;
+    uint32_t *s_img = reinterpret_cast<uint32_t *>(s_raw);                     // the block as it will lie in memory: TS bytes per tuple
     uint64_t *s_akey = reinterpret_cast<uint64_t *>(s_raw);                    // the cell key of every place in the tile
     uint64_t *s_atab = s_akey + P0_TILE;                                       // the table
     __shared__ uint32_t s_cnt[F1], s_base[F1 + 1], s_wsum[NT / 64], s_npass[2];
@@ -667,9 +666,11 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
         for (int j = 0; j < ITEMS; j++) {
             if (!passes[j]) continue;
             const uint32_t at = s_base[metas[j] & (F1 - 1)] + ranks[j];
-            s_xyzi[at] = make_uint4((uint32_t)cur[j].rp.x, (uint32_t)cur[j].rp.y, (uint32_t)cur[j].rp.z, (uint32_t)(idx_base + base) + (uint32_t)j * NT + tid);
-            s_w0[at] = cl[j] | (entry << 8) | (RGB ? rg[j] << 16 : rg[j]);
-            if (RGB) s_w1[at] = (rg[j] >> 16) | (bb[j] << 16);
+            uint32_t *q = s_img + at * (TS / 4);  // (5 or 6 words per tuple: an odd stride, or two-way conflicts — the LDS is not what this kernel waits for)
+            q[0] = (uint32_t)cur[j].rp.x, q[1] = (uint32_t)cur[j].rp.y, q[2] = (uint32_t)cur[j].rp.z;
+            q[3] = (uint32_t)(idx_base + base) + (uint32_t)j * NT + tid;
+            q[4] = cl[j] | (entry << 8) | (RGB ? rg[j] << 16 : rg[j]);
+            if (RGB) q[5] = (rg[j] >> 16) | (bb[j] << 16);
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {  // the next tile's inputs have arrived (asked for a whole tile ago) — before the stores below
@@ -679,15 +680,13 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
         }
         if (tid == 0) s_npass[parity ^ 1] = 0;
         __syncthreads();
-        uint8_t *blk = out + (uint64_t)tile * P0_TILE * TS;
-        for (uint32_t t = tid; t < total; t += NT) {  // the block, front to back
-            const uint4 a = s_xyzi[t];
-            uint8_t *q = blk + (uint64_t)t * TS;
-            u32x4_a4 va = {a.x, a.y, a.z, a.w};
-            *(PCQ_GLOBAL u32x4_a4 *)q = va;
-            *(PCQ_GLOBAL uint32_t *)(q + 16) = s_w0[t];
-            if (RGB) *(PCQ_GLOBAL uint32_t *)(q + 20) = s_w1[t];
-        }
+        // The block, front to back, as whole 16-byte words of the image (a block starts 16-byte aligned and has room for whole
+        // words): every store instruction of a wave is 1 KiB without a gap.  (Stored tuple by tuple — 16 + 4 bytes at a stride
+        // of 20 — the same bytes left as twice the instructions with holes for the other one to fill.)
+        uint4 *blk = reinterpret_cast<uint4 *>(out + (uint64_t)tile * P0_TILE * TS);
+        const uint32_t nq = (total * TS + 15) / 16;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        for (uint32_t t = tid; t < nq; t += NT) *(PCQ_GLOBAL u32x4 *)(blk + t) = reinterpret_cast<const u32x4 *>(s_img)[t];
         __syncthreads();  // the image is rewritten by the next tile
         if (agg && agg_mode == 0) {
             if (total * 4 > matched * 3) {  // less than a quarter shed: not worth the table for a while
