@@ -5,7 +5,7 @@
  * the deterministic synthetic data of SURVEY.md §8(d), directly in HBM, so that bench.py can hold
  * the full synthetic ca13 dataset (2608 Mpoints, 31.3 GB of positions) resident without pushing it
  * through PCIe.  The generator is integer-only (counter-based splitmix64 + 64x64 multiply-high) and
- * is bit-identical to the host generator oracle/synth.c (checked by tests/test_synth.py), so the CPU
+ * is bit-identical to the host generator oracle/synth.c (checked by tests/test_gpu_scan.py::test_synth_device_generator_is_bit_identical), so the CPU
  * baseline and the GPU scan the same points.
  */
 #ifndef PCQ_SYNTH_H
