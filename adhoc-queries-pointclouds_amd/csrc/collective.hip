@@ -8,6 +8,7 @@
 // own RCCL (PyTorch ships one) must not get a second copy mixed in through libpcq.so's dependencies.
 // Message: 8 bytes per rank — latency-bound; ring/tree choice and the 7 x 153 GB/s links are irrelevant.
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdlib>
@@ -83,7 +84,21 @@ int ensure_comm(const std::vector<int> &devs) {
     for (ncclComm_t c : g_rccl.comms) g_rccl.CommDestroy(c);
     g_rccl.comms.assign(devs.size(), nullptr);
     g_rccl.devices.clear();
-    PCQ_NCCL(g_rccl.CommInitAll(g_rccl.comms.data(), (int)devs.size(), devs.data()));
+    {
+        // RCCL prints its version banner to stdout when a communicator is created (plain printf, whatever NCCL_DEBUG_FILE
+        // says); the stdout of a query is the reference's and nothing else.  For the duration of the call descriptor 1 is
+        // descriptor 2.  (The CLI prints nothing of its own between "Searching N files..." and the merged result.)
+        fflush(stdout);
+        const int saved = dup(1);
+        if (saved >= 0) (void)dup2(2, 1);
+        const ncclResult_t r = g_rccl.CommInitAll(g_rccl.comms.data(), (int)devs.size(), devs.data());
+        fflush(stdout);
+        if (saved >= 0) {
+            (void)dup2(saved, 1);
+            close(saved);
+        }
+        if (r != 0) return pcq_fail(PCQ_ERR_HIP, "ncclCommInitAll failed: %s", g_rccl.GetErrorString(r));
+    }
     g_rccl.devices = devs;
     if (timing())
         fprintf(stderr, "[pcq] RCCL communicator over %zu device(s) ready after %.1f ms\n", devs.size(),

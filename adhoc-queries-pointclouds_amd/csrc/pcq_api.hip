@@ -28,6 +28,11 @@ int pcq_fail(int code, const char *fmt, ...) {
 }
 
 extern "C" const char *pcq_last_error(void) { return g_err; }
+// a few 64-bit words from device memory into pinned host memory (pcq_copy_to_host)
+__global__ void k_words_to_host(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst_pinned, uint32_t n) {
+    if (threadIdx.x < n) dst_pinned[threadIdx.x] = src[threadIdx.x];
+}
+
 extern "C" int pcq_abi_version(void) { return PCQ_ABI_VERSION; }
 
 // ---------------------------------------------------------------------------------------------
@@ -407,6 +412,16 @@ extern "C" int pcq_copy_to_host(pcq_ctx *ctx, void *dst, const void *src, uint64
     PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx || (!dst && bytes) || (!src && bytes)) return pcq_fail(PCQ_ERR_ARG, "pcq_copy_to_host: null argument");
     if (bytes) {
+        if (bytes <= 64 * sizeof(uint64_t) && bytes % 8 == 0 && ((uintptr_t)src & 7) == 0) {
+            // A few words (a count): a kernel stores them into the context's pinned, device-visible scratch.  The first
+            // device-to-host hipMemcpy of a process sets up the runtime's copy-engine path — 8 ms in the CLI, where this
+            // read is the only one (profiles/r03_cli_e2e.log).
+            hipLaunchKernelGGL(k_words_to_host, dim3(1), dim3(64), 0, ctx->stream, (const uint64_t *)src, ctx->h_scalars, (uint32_t)(bytes / 8));
+            PCQ_HIP(hipGetLastError());
+            PCQ_HIP(hipStreamSynchronize(ctx->stream));
+            memcpy(dst, ctx->h_scalars, bytes);
+            return PCQ_OK;
+        }
         PCQ_HIP(hipStreamSynchronize(ctx->stream));
         PCQ_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     }

@@ -133,11 +133,7 @@ Status parse_las_header(const uint8_t *data, size_t len, bool mask_format, LasHe
 
 // ---- mmap ---------------------------------------------------------------------------------------------
 MappedFile::~MappedFile() {
-    const auto t0 = std::chrono::steady_clock::now();
     if (data_) munmap(const_cast<uint8_t *>(data_), size_);
-    if (data_ && getenv("PCQ_TIMING") && size_ > (64u << 20))
-        fprintf(stderr, "[pcq] unmapped a %.0f MB file in %.1f ms\n", (double)size_ / 1e6,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (fd_ >= 0) close(fd_);
 }
 
