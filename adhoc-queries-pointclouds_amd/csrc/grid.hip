@@ -747,18 +747,34 @@ __device__ __forceinline__ uint32_t dir_entry(const uint32_t *s_rows, uint32_t r
     return (b & 1) ? w >> 16 : w & 0xffffu;
 }
 
-// bintot[b] += the tuples of bin b in the 64 tiles of this workgroup (lane = tile, a wave sums a bin).  bintot starts at zero.
-__global__ __launch_bounds__(BLOCK) void k_tile_bin_totals(const DevRun *__restrict__ runs, int nruns, uint32_t T, uint32_t *__restrict__ bintot) {
+// part[g][b] = the tuples of bin b in the 64 tiles of workgroup g (lane = tile, a wave sums a bin).  No atomics: 500
+// workgroups adding to the same 512 words from eight XCDs took 0.26 ms — same-address atomics across XCDs pass one by one.
+__global__ __launch_bounds__(BLOCK) void k_tile_bin_totals(const DevRun *__restrict__ runs, int nruns, uint32_t T, uint32_t *__restrict__ part) {
     __shared__ uint32_t s_rows[64 * DIR_WORDS];
     __shared__ uint64_t s_rowptr[64], s_blk[64];
+    __shared__ uint32_t s_tot[F1];
     load_dir_rows(runs, nruns, T, blockIdx.x * 64, s_rows, s_rowptr, s_blk);
     const uint32_t r = threadIdx.x & 63;
     for (uint32_t b = threadIdx.x >> 6; b < (uint32_t)F1; b += WAVES) {
         uint32_t c = dir_entry(s_rows, r, b + 1) - dir_entry(s_rows, r, b);
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if (r == 0 && c) atomicAdd(&bintot[b], c);
+        if (r == 0) s_tot[b] = c;
     }
+    __syncthreads();
+    for (uint32_t b = threadIdx.x; b < (uint32_t)F1; b += BLOCK) part[(size_t)blockIdx.x * F1 + b] = s_tot[b];
+}
+// part[g][b] -> the tuples of bin b in the workgroups in front of g (exclusive prefix over g); bintot[b] = the bin's tuples
+__global__ __launch_bounds__(BLOCK) void k_wg_prefix(uint32_t *__restrict__ part, uint32_t ngroups, uint32_t *__restrict__ bintot) {
+    const uint32_t b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= (uint32_t)F1) return;
+    uint32_t run = 0;
+    for (uint32_t g = 0; g < ngroups; g++) {
+        const uint32_t v = part[(size_t)g * F1 + b];
+        part[(size_t)g * F1 + b] = run;
+        run += v;
+    }
+    bintot[b] = run;
 }
 
 // 64 tiles per workgroup: their directory rows through LDS; lane = tile, so that what leaves are whole lines of
@@ -824,29 +840,18 @@ __global__ __launch_bounds__(1024) void k_bin_prefix(uint32_t *__restrict__ preT
 // would hold a handful of tuples per round, and the transposed directory (T x 512 entries) would outweigh the tuples.
 // Then the bins are copied together instead, tile-major — comp = bin 0's tuples, bin 1's, ... (binbase from
 // k_tile_bin_totals) — and described to the fold as pass-0 output of F1 "tiles", tile t = bin t's piece: fragment (b, t)
-// is empty unless t == b.  Every consumer reads that through the same window code.  A workgroup takes 64 tiles: per bin
-// it reserves room for its tuples with one atomic on the bin's cursor (the order of the pieces inside a bin is whatever
-// the atomics make it — the fold does not depend on it), and thread (tile, bin) copies its fragment, reading its tile's
-// block front to back.
+// is empty unless t == b.  Every consumer reads that through the same window code.  A workgroup takes 64 tiles (the same
+// 64 as in k_tile_bin_totals, whose prefix over the workgroups is its place in every bin), and thread (tile, bin) copies
+// its fragment, reading its tile's block front to back.
 __global__ __launch_bounds__(BLOCK) void k_sparse_compact(const DevRun *__restrict__ runs, int nruns, uint32_t T, const uint32_t *__restrict__ binbase,
-                                                          uint32_t *__restrict__ cursor, uint8_t *__restrict__ comp, uint32_t wide_out) {
+                                                          const uint32_t *__restrict__ part, uint8_t *__restrict__ comp, uint32_t wide_out) {
     __shared__ uint32_t s_rows[64 * DIR_WORDS];
     __shared__ uint64_t s_rowptr[64], s_blk[64];
     __shared__ uint32_t s_res[F1];
+    for (uint32_t b = threadIdx.x; b < (uint32_t)F1; b += BLOCK)  // this workgroup's place in every bin (k_wg_prefix)
+        s_res[b] = ldg(binbase + b) + ldg(part + (size_t)blockIdx.x * F1 + b);
     load_dir_rows(runs, nruns, T, blockIdx.x * 64, s_rows, s_rowptr, s_blk);
     const uint32_t r = threadIdx.x & 63;
-    for (uint32_t b = threadIdx.x >> 6; b < (uint32_t)F1; b += WAVES) {  // the workgroup's tuples per bin
-        uint32_t c = dir_entry(s_rows, r, b + 1) - dir_entry(s_rows, r, b);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if (r == 0) s_res[b] = c;
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < (uint32_t)F1; b += BLOCK) {  // their place in the bin
-        const uint32_t c = s_res[b];
-        s_res[b] = ldg(binbase + b) + (c ? atomicAdd(&cursor[b], c) : 0u);
-    }
-    __syncthreads();
     const uint64_t blk = s_blk[r];
     const bool wide = blk & 1;
     const uint8_t *src0 = reinterpret_cast<const uint8_t *>(blk & ~1ull);
@@ -2359,7 +2364,10 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     DevGrid *d_grid = nullptr;
     int rc = tmp.get(nruns, &d_runs);
     if (!rc) rc = tmp.get(256, &d_entries);
-    if (!rc) rc = tmp.get(2 * F1, &d_bintot);  // [F1 .. 2 F1): the bins' cursors of the compaction
+    if (!rc) rc = tmp.get(F1, &d_bintot);
+    const uint32_t ngroups = (T + 63) / 64;  // 64 tiles to a workgroup in the directory kernels
+    uint32_t *d_part = nullptr;              // [ngroups][F1] tuples per (workgroup, bin), then their prefix over the workgroups
+    if (!rc) rc = tmp.get((size_t)ngroups * F1, &d_part);
     if (!rc) rc = tmp.get(F1 + 1, &d_binbase);
     if (!rc) rc = tmp.get(8, &d_stats);
     if (!rc) rc = tmp.get(1, &d_grid);
@@ -2378,8 +2386,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     eref.table = d_entries;
     eref.e0 = gs->entries[0];
     // the bins' sizes first: they decide how the fold reads pass 0's output
-    PCQ_HIP(hipMemsetAsync(d_bintot, 0, 2 * F1 * sizeof(uint32_t), s));
-    hipLaunchKernelGGL(k_tile_bin_totals, dim3((T + 63) / 64), dim3(BLOCK), 0, s, d_runs, nruns, T, d_bintot);
+    hipLaunchKernelGGL(k_tile_bin_totals, dim3(ngroups), dim3(BLOCK), 0, s, d_runs, nruns, T, d_part);
+    hipLaunchKernelGGL(k_wg_prefix, dim3(F1 / BLOCK), dim3(BLOCK), 0, s, d_part, ngroups, d_bintot);
     hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, d_bintot, d_binbase, (uint32_t)F1);
     PCQ_HIP(hipGetLastError());
     uint32_t h_probe[2] = {0, 0};  // tuples in the probe bins, tuples in all
@@ -2406,7 +2414,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         if (!rc) rc = tmp.get((size_t)F1 * Tcp, &d_cstart);
         if (!rc) rc = tmp.get(Tc, &d_caddr);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_sparse_compact, dim3((T + 63) / 64), dim3(BLOCK), 0, s, d_runs, nruns, T, d_binbase, d_bintot + F1, d_comp, any_wide ? 1u : 0u);
+        hipLaunchKernelGGL(k_sparse_compact, dim3(ngroups), dim3(BLOCK), 0, s, d_runs, nruns, T, d_binbase, d_part, d_comp, any_wide ? 1u : 0u);
         hipLaunchKernelGGL(k_compact_dir, dim3(F1), dim3(BLOCK), 0, s, d_binbase, d_comp, any_wide ? 1u : 0u, Tcp1, Tcp, d_cpre, d_cstart, d_caddr);
         PCQ_HIP(hipGetLastError());
         src = BinSrc{d_cpre, d_cstart, d_caddr, Tc, Tcp1, Tcp};
