@@ -712,14 +712,16 @@ struct DevRun {        // one pending pass-0 run
     uint32_t wide, _pad;
 };
 
-// The directory rows of the 64 tiles t0 .. t0 + 64 into LDS (rows behind the last tile: zeros) — 64 rows of 257 words: lane r
-// reads word r * 257 + k, no two lanes in one bank — and s_blk[r] = the tile's block address | 1 when its tuples are 24 bytes.
-// Whole workgroup of BLOCK threads; ends on a barrier.
-__device__ __forceinline__ void load_dir_rows(const DevRun *__restrict__ runs, int nruns, uint32_t T, uint32_t t0, uint32_t *s_rows, uint64_t *s_rowptr,
-                                              uint64_t *s_blk) {
+// 64 tiles per workgroup: their directory rows through LDS; lane = tile, so that what leaves are whole lines of
+// startT[b] / preT[b] (preT gets the fragment's COUNT here; k_bin_prefix turns the counts into the prefix).
+__global__ __launch_bounds__(BLOCK) void k_dir_transpose(const DevRun *__restrict__ runs, int nruns, uint32_t T, uint32_t Tp, uint32_t Tp1,
+                                                         uint16_t *__restrict__ startT, uint32_t *__restrict__ preT, uint64_t *__restrict__ tile_addr) {
+    __shared__ uint32_t s_rows[64 * DIR_WORDS];  // 64 rows of 257 words: lane r reads word r * 257 + k — no two lanes in one bank
+    __shared__ uint64_t s_rowptr[64];
+    const uint32_t t0 = blockIdx.x * 64;
     if (threadIdx.x < 64) {
         const uint32_t t = t0 + threadIdx.x;
-        uint64_t rowptr = 0, blk = 0;
+        uint64_t rowptr = 0;
         if (t < T) {
             int lo = 0, hi = nruns;  // the last run with tile0 <= t
             while (hi - lo > 1) {
@@ -730,9 +732,9 @@ __device__ __forceinline__ void load_dir_rows(const DevRun *__restrict__ runs, i
             const DevRun r = runs[lo];
             const uint32_t local = t - r.tile0;
             rowptr = reinterpret_cast<uint64_t>(r.dir + (size_t)local * DIR_STRIDE);
-            blk = reinterpret_cast<uint64_t>(r.tuples + (uint64_t)local * P0_TILE * tuple_bytes(r.wide)) | (r.wide ? 1u : 0u);
+            tile_addr[t] = reinterpret_cast<uint64_t>(r.tuples + (uint64_t)local * P0_TILE * tuple_bytes(r.wide)) | (r.wide ? 1u : 0u);
         }
-        s_rowptr[threadIdx.x] = rowptr, s_blk[threadIdx.x] = blk;
+        s_rowptr[threadIdx.x] = rowptr;
     }
     __syncthreads();
     for (int r = 0; r < 64; r++) {
@@ -740,56 +742,11 @@ __device__ __forceinline__ void load_dir_rows(const DevRun *__restrict__ runs, i
         for (int w = threadIdx.x; w < DIR_WORDS; w += BLOCK) s_rows[r * DIR_WORDS + w] = row ? ldg(row + w) : 0u;
     }
     __syncthreads();
-}
-// entry b of row r: where bin b starts in tile r's block (b == F1: the block's tuples)
-__device__ __forceinline__ uint32_t dir_entry(const uint32_t *s_rows, uint32_t r, uint32_t b) {
-    const uint32_t w = s_rows[r * DIR_WORDS + (b >> 1)];
-    return (b & 1) ? w >> 16 : w & 0xffffu;
-}
-
-// part[g][b] = the tuples of bin b in the 64 tiles of workgroup g (lane = tile, a wave sums a bin).  No atomics: 500
-// workgroups adding to the same 512 words from eight XCDs took 0.26 ms — same-address atomics across XCDs pass one by one.
-__global__ __launch_bounds__(BLOCK) void k_tile_bin_totals(const DevRun *__restrict__ runs, int nruns, uint32_t T, uint32_t *__restrict__ part) {
-    __shared__ uint32_t s_rows[64 * DIR_WORDS];
-    __shared__ uint64_t s_rowptr[64], s_blk[64];
-    __shared__ uint32_t s_tot[F1];
-    load_dir_rows(runs, nruns, T, blockIdx.x * 64, s_rows, s_rowptr, s_blk);
-    const uint32_t r = threadIdx.x & 63;
-    for (uint32_t b = threadIdx.x >> 6; b < (uint32_t)F1; b += WAVES) {
-        uint32_t c = dir_entry(s_rows, r, b + 1) - dir_entry(s_rows, r, b);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if (r == 0) s_tot[b] = c;
-    }
-    __syncthreads();
-    for (uint32_t b = threadIdx.x; b < (uint32_t)F1; b += BLOCK) part[(size_t)blockIdx.x * F1 + b] = s_tot[b];
-}
-// part[g][b] -> the tuples of bin b in the workgroups in front of g (exclusive prefix over g); bintot[b] = the bin's tuples
-__global__ __launch_bounds__(BLOCK) void k_wg_prefix(uint32_t *__restrict__ part, uint32_t ngroups, uint32_t *__restrict__ bintot) {
-    const uint32_t b = blockIdx.x * BLOCK + threadIdx.x;
-    if (b >= (uint32_t)F1) return;
-    uint32_t run = 0;
-    for (uint32_t g = 0; g < ngroups; g++) {
-        const uint32_t v = part[(size_t)g * F1 + b];
-        part[(size_t)g * F1 + b] = run;
-        run += v;
-    }
-    bintot[b] = run;
-}
-
-// 64 tiles per workgroup: their directory rows through LDS; lane = tile, so that what leaves are whole lines of
-// startT[b] / preT[b] (preT gets the fragment's COUNT here; k_bin_prefix turns the counts into the prefix).
-__global__ __launch_bounds__(BLOCK) void k_dir_transpose(const DevRun *__restrict__ runs, int nruns, uint32_t T, uint32_t Tp, uint32_t Tp1,
-                                                         uint16_t *__restrict__ startT, uint32_t *__restrict__ preT, uint64_t *__restrict__ tile_addr) {
-    __shared__ uint32_t s_rows[64 * DIR_WORDS];
-    __shared__ uint64_t s_rowptr[64], s_blk[64];
-    const uint32_t t0 = blockIdx.x * 64;
-    load_dir_rows(runs, nruns, T, t0, s_rows, s_rowptr, s_blk);
     const uint32_t r = threadIdx.x & 63;
     if (t0 + r >= T) return;
-    if (threadIdx.x < 64) tile_addr[t0 + r] = s_blk[r];
     for (uint32_t b = threadIdx.x >> 6; b < (uint32_t)F1; b += WAVES) {
-        const uint32_t v0 = dir_entry(s_rows, r, b), v1 = dir_entry(s_rows, r, b + 1);
+        const uint32_t w0 = s_rows[r * DIR_WORDS + (b >> 1)], w1 = s_rows[r * DIR_WORDS + ((b + 1) >> 1)];
+        const uint32_t v0 = (b & 1) ? w0 >> 16 : w0 & 0xffffu, v1 = ((b + 1) & 1) ? w1 >> 16 : w1 & 0xffffu;
         startT[(size_t)b * Tp + t0 + r] = (uint16_t)v0;
         preT[(size_t)b * Tp1 + t0 + r] = v1 - v0;
     }
@@ -837,37 +794,20 @@ __global__ __launch_bounds__(1024) void k_bin_prefix(uint32_t *__restrict__ preT
 }
 
 // Short fragments (a scan whose tiles shed most of their tuples, a box that few points match): the reader's window
-// would hold a handful of tuples per round, and the transposed directory (T x 512 entries) would outweigh the tuples.
-// Then the bins are copied together instead, tile-major — comp = bin 0's tuples, bin 1's, ... (binbase from
-// k_tile_bin_totals) — and described to the fold as pass-0 output of F1 "tiles", tile t = bin t's piece: fragment (b, t)
-// is empty unless t == b.  Every consumer reads that through the same window code.  A workgroup takes 64 tiles (the same
-// 64 as in k_tile_bin_totals, whose prefix over the workgroups is its place in every bin), and thread (tile, bin) copies
-// its fragment, reading its tile's block front to back.
-__global__ __launch_bounds__(BLOCK) void k_sparse_compact(const DevRun *__restrict__ runs, int nruns, uint32_t T, const uint32_t *__restrict__ binbase,
-                                                          const uint32_t *__restrict__ part, uint8_t *__restrict__ comp, uint32_t wide_out) {
-    __shared__ uint32_t s_rows[64 * DIR_WORDS];
-    __shared__ uint64_t s_rowptr[64], s_blk[64];
-    __shared__ uint32_t s_res[F1];
-    for (uint32_t b = threadIdx.x; b < (uint32_t)F1; b += BLOCK)  // this workgroup's place in every bin (k_wg_prefix)
-        s_res[b] = ldg(binbase + b) + ldg(part + (size_t)blockIdx.x * F1 + b);
-    load_dir_rows(runs, nruns, T, blockIdx.x * 64, s_rows, s_rowptr, s_blk);
-    const uint32_t r = threadIdx.x & 63;
-    const uint64_t blk = s_blk[r];
-    const bool wide = blk & 1;
-    const uint8_t *src0 = reinterpret_cast<const uint8_t *>(blk & ~1ull);
-    for (uint32_t b = threadIdx.x >> 6; b < (uint32_t)F1; b += WAVES) {
-        const uint32_t v0 = dir_entry(s_rows, r, b), c = dir_entry(s_rows, r, b + 1) - v0;
-        uint32_t incl = c;  // the tiles in front of this one, inside the workgroup
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t up = __shfl_up(incl, o, 64);
-            if (r >= (uint32_t)o) incl += up;
-        }
-        if (c == 0) continue;
-        const uint8_t *src = src0 + (uint64_t)v0 * tuple_bytes(wide);
-        uint8_t *dst = comp + (uint64_t)(s_res[b] + incl - c) * tuple_bytes(wide_out);
-        for (uint32_t i = 0; i < c; i++) st_tuple(dst + (uint64_t)i * tuple_bytes(wide_out), ld_tuple(src + (uint64_t)i * tuple_bytes(wide), wide), wide_out);
-    }
+// would hold a handful of tuples per round.  Then the bins are first copied together — one thread per fragment, comp =
+// bin 0's tuples, bin 1's, ... — and described to the fold as pass-0 output of F1 "tiles", tile t = bin t's piece:
+// fragment (b, t) is empty unless t == b.  Every consumer reads that through the same window code.
+__global__ __launch_bounds__(BLOCK) void k_bin_compact(BinSrc S, const uint32_t *__restrict__ binbase, uint8_t *__restrict__ comp, uint32_t wide_out) {
+    const uint64_t q = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (q >= (uint64_t)S.T * F1) return;
+    const uint32_t bin = (uint32_t)(q / S.T), f = (uint32_t)(q % S.T);
+    const uint32_t lo = ldg(S.preT + (size_t)bin * S.Tp1 + f), hi = ldg(S.preT + (size_t)bin * S.Tp1 + f + 1);
+    if (lo == hi) return;
+    const uint64_t a = frag_addr(S, bin, f);
+    const bool wide = a & 1;
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(a & ~1ull);
+    uint8_t *dst = comp + (uint64_t)(ldg(binbase + bin) + lo) * tuple_bytes(wide_out);
+    for (uint32_t i = 0; i < hi - lo; i++) st_tuple(dst + (uint64_t)i * tuple_bytes(wide_out), ld_tuple(src + (uint64_t)i * tuple_bytes(wide), wide), wide_out);
 }
 // the directory of the compacted bins: preT[b][t] = (t <= b ? 0 : the bin's tuples), startT = 0, tile_addr[t] = bin t's piece
 __global__ __launch_bounds__(BLOCK) void k_compact_dir(const uint32_t *__restrict__ binbase, const uint8_t *__restrict__ comp, uint32_t wide, uint32_t Tp1,
@@ -1006,20 +946,6 @@ __global__ __launch_bounds__(1024) void k_scan_pieces(const uint64_t *__restrict
     }
 }
 
-// 1 when `key` is new to the global hash set (open addressing, linear probing)
-__device__ __forceinline__ uint32_t probe_set_insert(uint64_t *set, uint64_t mask, uint64_t key) {
-    uint64_t h = hash64(key) & mask;
-    for (;;) {
-        const uint64_t k = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (k == key) return 0;
-        if (k == PCQ_EMPTY_KEY) {
-            const uint64_t prev = atomicCAS((unsigned long long *)&set[h], (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key);
-            if (prev == PCQ_EMPTY_KEY) return 1;
-            if (prev == key) return 0;
-        }
-        h = (h + 1) & mask;
-    }
-}
 // Distinct cells among the tuples of the first PROBE_BINS level-1 bins (a global hash set; one thread per fragment).
 __global__ __launch_bounds__(BLOCK) void k_probe_distinct(BinSrc S, EntryRef entries, DevGrid g, uint64_t *__restrict__ set, uint64_t mask,
                                                           unsigned long long *__restrict__ distinct) {
@@ -1032,20 +958,25 @@ __global__ __launch_bounds__(BLOCK) void k_probe_distinct(BinSrc S, EntryRef ent
         const uint64_t a = frag_addr(S, bin, f);
         const bool wide = a & 1;
         const uint8_t *p = reinterpret_cast<const uint8_t *>(a & ~1ull);
-        for (uint32_t i = 0; i < hi - lo; i++)
-            mine += probe_set_insert(set, mask, eval_tuple(g, entries, ld_tuple(p + (uint64_t)i * tuple_bytes(wide), wide)).key);
+        for (uint32_t i = 0; i < hi - lo; i++) {
+            const GridTuple t = ld_tuple(p + (uint64_t)i * tuple_bytes(wide), wide);
+            const uint64_t key = eval_tuple(g, entries, t).key;
+            uint64_t h = hash64(key) & mask;
+            for (;;) {
+                const uint64_t k = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (k == key) break;
+                if (k == PCQ_EMPTY_KEY) {
+                    const uint64_t prev = atomicCAS((unsigned long long *)&set[h], (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key);
+                    if (prev == PCQ_EMPTY_KEY) {
+                        mine++;
+                        break;
+                    }
+                    if (prev == key) break;
+                }
+                h = (h + 1) & mask;
+            }
+        }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(distinct, (unsigned long long)mine);
-}
-// The same over the compacted form: the probe bins are the first binbase[PROBE_BINS] tuples of comp (one thread per tuple).
-__global__ __launch_bounds__(BLOCK) void k_probe_distinct_seg(const uint8_t *__restrict__ comp, uint32_t wide, const uint32_t *__restrict__ binbase, EntryRef entries,
-                                                              DevGrid g, uint64_t *__restrict__ set, uint64_t mask, unsigned long long *__restrict__ distinct) {
-    uint32_t mine = 0;
-    const uint32_t n = ldg(binbase + PROBE_BINS);
-    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK)
-        mine += probe_set_insert(set, mask, eval_tuple(g, entries, ld_tuple(comp + (uint64_t)i * tuple_bytes(wide), wide)).key);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(distinct, (unsigned long long)mine);
@@ -2347,7 +2278,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     if (gs->pending_cap >= (1ull << 32)) return pcq_fail(PCQ_ERR_UNSUPPORTED, "grid collector: more than 2^32 pending tuples in one fold");
 
     // run directory, entries, the per-bin fragment lists
-    const uint32_t T = (uint32_t)gs->pending_tiles;
+    const uint32_t T = (uint32_t)gs->pending_tiles, Tp = (T + 63) & ~63u, Tp1 = (T + 1 + 63) & ~63u;
     std::vector<DevRun> hruns(nruns);
     {
         uint32_t tile0 = 0;
@@ -2359,18 +2290,20 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     const bool any_wide = gs->any_wide;
     DevRun *d_runs = nullptr;
     GridEntryDev *d_entries = nullptr;
-    uint32_t *d_bintot = nullptr, *d_binbase = nullptr;
+    uint32_t *d_bintot = nullptr, *d_binbase = nullptr, *d_preT = nullptr;
+    uint16_t *d_startT = nullptr;
+    uint64_t *d_tile_addr = nullptr;
     unsigned long long *d_stats = nullptr;
     DevGrid *d_grid = nullptr;
     int rc = tmp.get(nruns, &d_runs);
     if (!rc) rc = tmp.get(256, &d_entries);
     if (!rc) rc = tmp.get(F1, &d_bintot);
-    const uint32_t ngroups = (T + 63) / 64;  // 64 tiles to a workgroup in the directory kernels
-    uint32_t *d_part = nullptr;              // [ngroups][F1] tuples per (workgroup, bin), then their prefix over the workgroups
-    if (!rc) rc = tmp.get((size_t)ngroups * F1, &d_part);
     if (!rc) rc = tmp.get(F1 + 1, &d_binbase);
     if (!rc) rc = tmp.get(8, &d_stats);
     if (!rc) rc = tmp.get(1, &d_grid);
+    if (!rc) rc = tmp.get((size_t)F1 * Tp, &d_startT);
+    if (!rc) rc = tmp.get((size_t)F1 * Tp1, &d_preT);
+    if (!rc) rc = tmp.get(T, &d_tile_addr);
     if (rc) return rc;
     PCQ_HIP(hipMemcpyAsync(d_grid, &g, sizeof g, hipMemcpyHostToDevice, s));
     GridRef gref{};
@@ -2385,11 +2318,11 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     EntryRef eref;
     eref.table = d_entries;
     eref.e0 = gs->entries[0];
-    // the bins' sizes first: they decide how the fold reads pass 0's output
-    hipLaunchKernelGGL(k_tile_bin_totals, dim3(ngroups), dim3(BLOCK), 0, s, d_runs, nruns, T, d_part);
-    hipLaunchKernelGGL(k_wg_prefix, dim3(F1 / BLOCK), dim3(BLOCK), 0, s, d_part, ngroups, d_bintot);
+    hipLaunchKernelGGL(k_dir_transpose, dim3((T + 63) / 64), dim3(BLOCK), 0, s, d_runs, nruns, T, Tp, Tp1, d_startT, d_preT, d_tile_addr);
+    hipLaunchKernelGGL(k_bin_prefix, dim3(F1), dim3(1024), 0, s, d_preT, T, Tp1, d_bintot);
     hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, d_bintot, d_binbase, (uint32_t)F1);
     PCQ_HIP(hipGetLastError());
+    BinSrc src{d_preT, d_startT, d_tile_addr, T, Tp1, Tp};  // (replaced by the compacted bins below when the fragments are short)
     uint32_t h_probe[2] = {0, 0};  // tuples in the probe bins, tuples in all
     PCQ_HIP(hipMemcpyAsync(&h_probe[0], d_binbase + PROBE_BINS, 4, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipMemcpyAsync(&h_probe[1], d_binbase + F1, 4, hipMemcpyDeviceToHost, s));
@@ -2401,9 +2334,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         return PCQ_OK;
     }
     ctx->grid_folds++;
-    BinSrc src{};
-    const uint8_t *d_comp_probe = nullptr;  // the compacted form, for the density probe
-    if (T > 2u * BIG_FB && m < 2ull * T * F1) {  // fragments of less than two tuples on average: the bins are copied together
+    const BinSrc src_tiles = src;  // (the density probe takes a thread per fragment: it reads the tiles' own lists either way)
+    if (T > 2u * BIG_FB && m < 2ull * T * F1) {  // fragments of less than two tuples on average: copy the bins together first
         const uint32_t Tc = F1, Tcp = F1, Tcp1 = (F1 + 1 + 63) & ~63u;
         uint8_t *d_comp = nullptr;
         uint32_t *d_cpre = nullptr;
@@ -2414,25 +2346,12 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         if (!rc) rc = tmp.get((size_t)F1 * Tcp, &d_cstart);
         if (!rc) rc = tmp.get(Tc, &d_caddr);
         if (rc) return rc;
-        hipLaunchKernelGGL(k_sparse_compact, dim3(ngroups), dim3(BLOCK), 0, s, d_runs, nruns, T, d_binbase, d_part, d_comp, any_wide ? 1u : 0u);
+        const uint64_t nfrag = (uint64_t)T * F1;
+        hipLaunchKernelGGL(k_bin_compact, dim3((unsigned)((nfrag + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, src, d_binbase, d_comp, any_wide ? 1u : 0u);
         hipLaunchKernelGGL(k_compact_dir, dim3(F1), dim3(BLOCK), 0, s, d_binbase, d_comp, any_wide ? 1u : 0u, Tcp1, Tcp, d_cpre, d_cstart, d_caddr);
         PCQ_HIP(hipGetLastError());
         src = BinSrc{d_cpre, d_cstart, d_caddr, Tc, Tcp1, Tcp};
-        d_comp_probe = d_comp;
         ctx->grid_compactions++;
-    } else {  // the directory rows, transposed into per-bin fragment lists
-        const uint32_t Tp = (T + 63) & ~63u, Tp1 = (T + 1 + 63) & ~63u;
-        uint32_t *d_preT = nullptr;
-        uint16_t *d_startT = nullptr;
-        uint64_t *d_tile_addr = nullptr;
-        rc = tmp.get((size_t)F1 * Tp, &d_startT);
-        if (!rc) rc = tmp.get((size_t)F1 * Tp1, &d_preT);
-        if (!rc) rc = tmp.get(T, &d_tile_addr);
-        if (rc) return rc;
-        hipLaunchKernelGGL(k_dir_transpose, dim3((T + 63) / 64), dim3(BLOCK), 0, s, d_runs, nruns, T, Tp, Tp1, d_startT, d_preT, d_tile_addr);
-        hipLaunchKernelGGL(k_bin_prefix, dim3(F1), dim3(1024), 0, s, d_preT, T, Tp1, d_bintot);
-        PCQ_HIP(hipGetLastError());
-        src = BinSrc{d_preT, d_startT, d_tile_addr, T, Tp1, Tp};
     }
 
     // how dense is the grid?  estimated cells per level-1 bin -> fold the bins directly, or cut them again first
@@ -2448,11 +2367,9 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         if (rc) return rc;
         PCQ_HIP(hipMemsetAsync(d_set, 0xff, cap * 8, s));
         PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
-        unsigned probe_blocks = (unsigned)(((d_comp_probe ? (uint64_t)h_probe[0] : (uint64_t)T * PROBE_BINS) + BLOCK - 1) / BLOCK);
+        unsigned probe_blocks = (unsigned)(((uint64_t)T * PROBE_BINS + BLOCK - 1) / BLOCK);
         if (probe_blocks > 4096) probe_blocks = 4096;
-        if (probe_blocks < 1) probe_blocks = 1;
-        if (d_comp_probe) hipLaunchKernelGGL(k_probe_distinct_seg, dim3(probe_blocks), dim3(BLOCK), 0, s, d_comp_probe, any_wide ? 1u : 0u, d_binbase, eref, g, d_set, cap - 1, d_stats);
-        else hipLaunchKernelGGL(k_probe_distinct, dim3(probe_blocks), dim3(BLOCK), 0, s, src, eref, g, d_set, cap - 1, d_stats);
+        hipLaunchKernelGGL(k_probe_distinct, dim3(probe_blocks), dim3(BLOCK), 0, s, src_tiles, eref, g, d_set, cap - 1, d_stats);
         unsigned long long distinct = 0;
         PCQ_HIP(hipMemcpyAsync(&distinct, d_stats, 8, hipMemcpyDeviceToHost, s));
         PCQ_HIP(hipStreamSynchronize(s));
