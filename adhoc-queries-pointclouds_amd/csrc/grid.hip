@@ -962,19 +962,24 @@ __global__ __launch_bounds__(BLOCK) void k_probe_distinct(BinSrc S, EntryRef ent
             const GridTuple t = ld_tuple(p + (uint64_t)i * tuple_bytes(wide), wide);
             const uint64_t key = eval_tuple(g, entries, t).key;
             uint64_t h = hash64(key) & mask;
-            for (;;) {
+            bool is_new = true;  // (the set is sized from an estimate: after 64 probes in a crowded one a key counts as new — an estimate either way)
+            for (int probes = 0; probes < 64; probes++) {
                 const uint64_t k = __hip_atomic_load(&set[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (k == key) break;
+                if (k == key) {
+                    is_new = false;
+                    break;
+                }
                 if (k == PCQ_EMPTY_KEY) {
                     const uint64_t prev = atomicCAS((unsigned long long *)&set[h], (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key);
-                    if (prev == PCQ_EMPTY_KEY) {
-                        mine++;
+                    if (prev == PCQ_EMPTY_KEY) break;
+                    if (prev == key) {
+                        is_new = false;
                         break;
                     }
-                    if (prev == key) break;
                 }
                 h = (h + 1) & mask;
             }
+            mine += is_new ? 1 : 0;
         }
     }
 #pragma unroll
@@ -2325,10 +2330,31 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, d_bintot, d_binbase, (uint32_t)F1);
     PCQ_HIP(hipGetLastError());
     BinSrc src{d_preT, d_startT, d_tile_addr, T, Tp1, Tp};  // (replaced by the compacted bins below when the fragments are short)
-    uint32_t h_probe[2] = {0, 0};  // tuples in the probe bins, tuples in all
-    PCQ_HIP(hipMemcpyAsync(&h_probe[0], d_binbase + PROBE_BINS, 4, hipMemcpyDeviceToHost, s));
-    PCQ_HIP(hipMemcpyAsync(&h_probe[1], d_binbase + F1, 4, hipMemcpyDeviceToHost, s));
+    // How dense is the grid?  The distinct cells of two bins are counted into a global hash set — asked for here, before the
+    // host knows how many tuples there are, so that ONE synchronisation brings back the tuple count and the estimate (the
+    // set is sized for eight times the mean bin; its probing is bounded).  Not when the bins cannot be large anyway.
+    const double old_per_bin = (double)gs->wtotal / F1;
+    const bool probed = ctx->grid_f2 <= 0 && (double)gs->pending_cap / F1 + old_per_bin > BIG_DIRECT;
+    PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
+    if (probed) {
+        uint64_t cap = 1024;
+        while (cap < 16ull * (gs->pending_cap / F1 + 1) * PROBE_BINS) cap <<= 1;
+        if (cap > (1ull << 26)) cap = 1ull << 26;
+        uint64_t *d_set = nullptr;
+        rc = tmp.get(cap, &d_set);
+        if (rc) return rc;
+        PCQ_HIP(hipMemsetAsync(d_set, 0xff, cap * 8, s));
+        unsigned probe_blocks = (unsigned)(((uint64_t)T * PROBE_BINS + BLOCK - 1) / BLOCK);
+        if (probe_blocks > 4096) probe_blocks = 4096;
+        hipLaunchKernelGGL(k_probe_distinct, dim3(probe_blocks), dim3(BLOCK), 0, s, src, eref, g, d_set, cap - 1, d_stats);
+        PCQ_HIP(hipGetLastError());
+    }
+    uint32_t h_tuples = 0;
+    unsigned long long distinct = 0;
+    PCQ_HIP(hipMemcpyAsync(&h_tuples, d_binbase + F1, 4, hipMemcpyDeviceToHost, s));
+    PCQ_HIP(hipMemcpyAsync(&distinct, d_stats, 8, hipMemcpyDeviceToHost, s));
     PCQ_HIP(hipStreamSynchronize(s));  // also: the pageable sources above have been read
+    const uint32_t h_probe[2] = {0, h_tuples};
     const uint64_t m = h_probe[1], w_old = gs->wtotal;
     ctx->grid_last_tuples = (int64_t)m;
     if (m == 0) {
@@ -2336,7 +2362,6 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         return PCQ_OK;
     }
     ctx->grid_folds++;
-    const BinSrc src_tiles = src;  // (the density probe takes a thread per fragment: it reads the tiles' own lists either way)
     if (T > 2u * BIG_FB && m < 2ull * T * F1) {  // fragments of less than two tuples on average: copy the bins together first
         const uint32_t Tc = F1, Tcp = F1, Tcp1 = (F1 + 1 + 63) & ~63u;
         uint8_t *d_comp = nullptr;
@@ -2356,25 +2381,11 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         ctx->grid_compactions++;
     }
 
-    // how dense is the grid?  estimated cells per level-1 bin -> fold the bins directly, or cut them again first
+    // estimated cells per level-1 bin -> fold the bins directly, or cut them again first
     uint32_t f2 = 1;
-    const double old_per_bin = (double)w_old / F1;
     if (ctx->grid_f2 > 0) {
         f2 = (uint32_t)ctx->grid_f2;
-    } else if ((double)m / F1 + old_per_bin > BIG_DIRECT) {
-        uint64_t cap = 1024;
-        while (cap < 2ull * h_probe[0] + 2) cap <<= 1;
-        uint64_t *d_set = nullptr;
-        rc = tmp.get(cap, &d_set);
-        if (rc) return rc;
-        PCQ_HIP(hipMemsetAsync(d_set, 0xff, cap * 8, s));
-        PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
-        unsigned probe_blocks = (unsigned)(((uint64_t)T * PROBE_BINS + BLOCK - 1) / BLOCK);
-        if (probe_blocks > 4096) probe_blocks = 4096;
-        hipLaunchKernelGGL(k_probe_distinct, dim3(probe_blocks), dim3(BLOCK), 0, s, src_tiles, eref, g, d_set, cap - 1, d_stats);
-        unsigned long long distinct = 0;
-        PCQ_HIP(hipMemcpyAsync(&distinct, d_stats, 8, hipMemcpyDeviceToHost, s));
-        PCQ_HIP(hipStreamSynchronize(s));
+    } else if (probed && (double)m / F1 + old_per_bin > BIG_DIRECT) {
         const double est = (double)distinct / PROBE_BINS + old_per_bin;
         if (est > BIG_DIRECT) {
             f2 = (uint32_t)std::ceil(est / SMALL_TARGET);
@@ -2387,6 +2398,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         const uint32_t nparts = (uint32_t)F1 * f2;
         Scratch att(ctx);
         StreamDrainOnExit drain_before_att(s);
+        bool staged_level2 = false;
         GridSeg seg2{};  // the second level's output (f2 > 1)
         const uint32_t *d_tot = d_bintot;
         const uint64_t *obase = gs->wbase;
@@ -2435,18 +2447,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 uint32_t *d_tot2 = nullptr;
                 rc = att.get(nparts, &d_tot2);
                 if (rc) return rc;
-                if (staged) {
-                    unsigned long long outgrown = 0;
-                    PCQ_HIP(hipMemcpyAsync(&outgrown, d_stats + 5, 8, hipMemcpyDeviceToHost, s));
-                    PCQ_HIP(hipStreamSynchronize(s));
-                    if (outgrown) {  // a sub-partition outgrew its region (cells with very many points): count first, then cut
-                        level2_exact = true;
-                        ctx->grid_level2_exact++;
-                        attempt--;
-                        continue;
-                    }
-                }
-                ctx->grid_level2++;
+                staged_level2 = staged;  // (whether a region was outgrown is read back with the fold's counters: the fold of truncated
+                                         // partitions is wasted then, but the common case saves a synchronisation)
                 hipLaunchKernelGGL(k_part_totals, dim3((nparts + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, seg2, nparts, d_tot2);
                 d_tot = d_tot2;
             }
@@ -2483,7 +2485,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         hipLaunchKernelGGL(k_excl_scan_u64, dim3(1), dim3(1024), 0, s, d_pieces, d_piece_pre, npieces);
         hipLaunchKernelGGL(k_scan_pieces, dim3(npieces), dim3(1024), 0, s, d_room, nparts, d_piece_pre, n_wbase);
         PCQ_HIP(hipMemsetAsync(d_palias, 0, (size_t)nparts * 4, s));
-        PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
+        PCQ_HIP(hipMemsetAsync(d_stats, 0, 40, s));  // [0 .. 5): the fold's counters ([5]: the second level's, still to be read)
+        if (!(f2 > 1 || recut_old)) PCQ_HIP(hipMemsetAsync(d_stats + 5, 0, 24, s));
         FoldParams F{};
         F.src = src, F.seg = seg2, F.entries = eref, F.g = gref;
         if (w_old) F.okeys = okeys, F.orecs = orecs, F.obase = obase, F.ocount = ocount;
@@ -2505,6 +2508,13 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         PCQ_HIP(hipMemcpyAsync(st, d_stats, sizeof st, hipMemcpyDeviceToHost, s));
         PCQ_HIP(hipStreamSynchronize(s));
+        if (staged_level2 && st[5]) {  // a sub-partition outgrew its region (cells with very many points): count first, then cut
+            level2_exact = true;
+            ctx->grid_level2_exact++;
+            attempt--;
+            continue;
+        }
+        if (f2 > 1) ctx->grid_level2++;
         if (st[1]) {  // a partition held more cells than the LDS table: more partitions
             if (f2 >= F2_MAX || attempt > 8) return pcq_fail(PCQ_ERR_UNSUPPORTED, "grid collector: a partition does not fit the LDS table at the largest fan-out");
             ctx->grid_refolds++;
