@@ -135,5 +135,5 @@ if os.path.exists(ks):
             avg, mn, calls = float(r["AverageNs"]) / 1e6, float(r["MinNs"]) / 1e6, int(r["Calls"])
             gb = 12 * 2_608_000_000 / 1e9
             print(f"K1 under rocprofv3 ({os.path.basename(ks)}): {calls} launches, average {avg:.3f} ms, min {mn:.3f} ms -> "
-                  f"{gb / avg:.0f} GB/s = {gb / avg / 8000:.3f} of 8 TB/s (min: {gb / mn / 8000:.3f})")
+                  f"{gb / (avg * 1e-3):.0f} GB/s = {gb / (avg * 1e-3) / 8000:.3f} of 8 TB/s (min: {gb / (mn * 1e-3) / 8000:.3f})")
 print("profiles written for", head)
