@@ -362,8 +362,18 @@ __device__ __forceinline__ uint32_t tuple_sub(const G &g, const EntryRef &entrie
 // file order among tuples: entries are numbered in scan order; 0 is reserved for an earlier fold's winner
 __device__ __forceinline__ uint64_t ord_of(const GridTuple &t) { return ((uint64_t)((t.w0 >> 8) & 0xff) << 32 | t.idx) + 1; }
 
-// The 32-byte winner record: pcq_point (31 bytes) + flag byte.
-__device__ __forceinline__ void st_record(uint8_t *dst32, const GridEntryDev &e, int32_t x, int32_t y, int32_t z, uint32_t w0, uint32_t w1,
+// The winners' records: pcq_point (31 bytes) + flag byte = 32 bytes per cell, kept as TWO arrays of 16-byte halves — {x, y}
+// and {z, colour, class, flags} — so that the lanes of one store instruction (consecutive winners) write consecutive 16-byte
+// words: whole lines.  As 32-byte records every store instruction wrote the even or the odd halves of its lines, and the
+// memory side fetched what it was not given (counted: the dense fold fetched 6.2 GB for 3.3 GB of tuples).
+struct RecArr {
+    uint8_t *base;
+    uint64_t cap;  // records the arrays have room for: half a of record o at base + 16 o, half b at base + 16 (cap + o)
+    __host__ __device__ __forceinline__ uint4 *a(uint64_t o) const { return reinterpret_cast<uint4 *>(base + o * 16); }
+    __host__ __device__ __forceinline__ uint4 *b(uint64_t o) const { return reinterpret_cast<uint4 *>(base + (cap + o) * 16); }
+};
+__device__ __forceinline__ uint8_t rec_flags(const uint4 &b) { return (uint8_t)(b.w >> 24); }
+__device__ __forceinline__ void st_record(const RecArr &recs, uint64_t o, const GridEntryDev &e, int32_t x, int32_t y, int32_t z, uint32_t w0, uint32_t w1,
                                           uint8_t flags) {
     const uint64_t bx = (uint64_t)__double_as_longlong(world(x, e.scale[0], e.offset[0])),
                    by = (uint64_t)__double_as_longlong(world(y, e.scale[1], e.offset[1])),
@@ -373,9 +383,8 @@ __device__ __forceinline__ void st_record(uint8_t *dst32, const GridEntryDev &e,
     b.x = (uint32_t)bz, b.y = (uint32_t)(bz >> 32);
     b.z = (w0 >> 16) | (w1 << 16);                                          // red, green
     b.w = (w1 >> 16) | ((w0 & 0xffu) << 16) | ((uint32_t)flags << 24);      // blue, classification, flags
-    uint4 *d = reinterpret_cast<uint4 *>(dst32);
-    d[0] = a;
-    d[1] = b;
+    *recs.a(o) = a;
+    *recs.b(o) = b;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1005,13 +1014,13 @@ struct Level2Params {
     unsigned long long *stats;  // k_level2: [5] += 1 when a sub-partition outgrew its room
     // earlier winners, re-cut from f2old partitions per bin into f2 (nullptr: not moved)
     const uint64_t *okeys;
-    const uint8_t *orecs;
+    RecArr orecs;
     const uint64_t *obase;    // [F1 * f2old + 1]
     const uint32_t *ocount;   // [F1 * f2old]
     uint32_t f2old;
     const uint32_t *obinbase; // [F1 + 1] earlier winners in front of each bin
     uint64_t *okeys2;
-    uint8_t *orecs2;
+    RecArr orecs2;
     uint32_t *ooff2;          // [F1 * f2 + 1]
 };
 
@@ -1066,10 +1075,8 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
                 const uint64_t key = P.okeys[base + i];
                 const uint32_t pos = atomicAdd(&s_ocur[sub_of(cell_hash(key), f2)], 1u);
                 P.okeys2[pos] = key;
-                const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + (base + i) * 32);
-                uint4 *dp = reinterpret_cast<uint4 *>(P.orecs2 + (uint64_t)pos * 32);
-                dp[0] = sp[0];
-                dp[1] = sp[1];
+                *P.orecs2.a(pos) = *P.orecs.a(base + i);
+                *P.orecs2.b(pos) = *P.orecs.b(base + i);
             }
         }
 }
@@ -1245,10 +1252,8 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
                 const uint64_t key = P.okeys[base + i];
                 const uint32_t pos = atomicAdd(&s_ocur[sub_of(cell_hash(key), f2)], 1u);
                 P.okeys2[pos] = key;
-                const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + (base + i) * 32);
-                uint4 *dp = reinterpret_cast<uint4 *>(P.orecs2 + (uint64_t)pos * 32);
-                dp[0] = sp[0];
-                dp[1] = sp[1];
+                *P.orecs2.a(pos) = *P.orecs.a(base + i);
+                *P.orecs2.b(pos) = *P.orecs.b(base + i);
             }
         }
 }
@@ -1281,12 +1286,12 @@ struct FoldParams {
     GridRef g;
     // earlier winners by partition (okeys == nullptr: none)
     const uint64_t *okeys;
-    const uint8_t *orecs;
+    RecArr orecs;
     const uint64_t *obase;
     const uint32_t *ocount;
     // output
     uint64_t *wkeys;
-    uint8_t *wrecs;
+    RecArr wrecs;
     const uint64_t *wbase;
     uint32_t *wcount;
     uint32_t *palias;              // [P] 1: the partition holds aliased keys
@@ -1425,19 +1430,21 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                 s_over = 1;
                 continue;
             }
-            const uint8_t *rec = P.orecs + (old_base + i) * 32;
+            const uint4 ra = *P.orecs.a(old_base + i), rb = *P.orecs.b(old_base + i);
             atomicOr(&s_oldbits[s >> 5], 1u << (s & 31));
             pay[s * 5] = (uint32_t)(old_base + i);
             pay[s * 5 + 1] = (uint32_t)((old_base + i) >> 32);
-            if (rec[31] & R_ALIAS) {
+            if (rec_flags(rb) & R_ALIAS) {
                 atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
             } else {
-                const double *pos = reinterpret_cast<const double *>(rec);
+                const double ox = __longlong_as_double((long long)((uint64_t)ra.x | ((uint64_t)ra.y << 32))),
+                             oy = __longlong_as_double((long long)((uint64_t)ra.z | ((uint64_t)ra.w << 32))),
+                             oz = __longlong_as_double((long long)((uint64_t)rb.x | ((uint64_t)rb.y << 32)));
                 uint64_t cell[3];
                 const DevGrid &gf = *P.g.full;
 #pragma unroll
                 for (int a = 0; a < 3; a++) cell[a] = (key >> gf.shift[a]) & gf.mask[a];  // not aliased: unmasked == masked
-                s_dist[s] = (uint64_t)__double_as_longlong(centre_dist(gf, cell, pos[0], pos[1], pos[2]));
+                s_dist[s] = (uint64_t)__double_as_longlong(centre_dist(gf, cell, ox, oy, oz));
                 s_ord[s] = 0;
             }
         }
@@ -1513,13 +1520,12 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                     if (!win[k]) continue;
                     const int sl = slot[k];
                     P.wkeys[o] = s_key[sl];
-                    uint8_t *dst = P.wrecs + o * 32;
                     if ((s_aliasbits[sl >> 5] >> (sl & 31)) & 1) {  // left to the exact replay: no point yet, the flag
                         any_alias = true;
-                        reinterpret_cast<uint4 *>(dst)[0] = make_uint4(0, 0, 0, 0);
-                        reinterpret_cast<uint4 *>(dst)[1] = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
+                        *P.wrecs.a(o) = make_uint4(0, 0, 0, 0);
+                        *P.wrecs.b(o) = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
                     } else {
-                        st_record(dst, P.entries.get((tu[k].w0 >> 8) & 0xff), tu[k].x, tu[k].y, tu[k].z, tu[k].w0, tu[k].w1, R_HAS);
+                        st_record(P.wrecs, o, P.entries.get((tu[k].w0 >> 8) & 0xff), tu[k].x, tu[k].y, tu[k].z, tu[k].w0, tu[k].w1, R_HAS);
                     }
                     o++;
                 }
@@ -1652,27 +1658,24 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                     const uint64_t key = keys[j];
                     if (key == PCQ_EMPTY_KEY) continue;
                     P.wkeys[o] = key;
-                    uint8_t *dst = P.wrecs + o * 32;
                     const bool alias = (s_aliasbits[s >> 5] >> (s & 31)) & 1, old = (s_oldbits[s >> 5] >> (s & 31)) & 1;
                     if (alias) {  // left to the exact replay: the state before this fold (the earlier winner, if there is one) + the flag
                         any_alias = true;
                         uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
                         for (uint32_t i = 0; i < n_old; i++)
                             if (P.okeys[old_base + i] == key) {
-                                const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + (old_base + i) * 32);
-                                a = sp[0], b = sp[1];
+                                a = *P.orecs.a(old_base + i), b = *P.orecs.b(old_base + i);
                                 b.w |= (uint32_t)R_ALIAS << 24;
                                 break;
                             }
-                        reinterpret_cast<uint4 *>(dst)[0] = a;
-                        reinterpret_cast<uint4 *>(dst)[1] = b;
+                        *P.wrecs.a(o) = a;
+                        *P.wrecs.b(o) = b;
                     } else if (old) {
                         const uint64_t oi = (uint64_t)wa[j].x | ((uint64_t)wa[j].y << 32);
-                        const uint4 *sp = reinterpret_cast<const uint4 *>(P.orecs + oi * 32);
-                        reinterpret_cast<uint4 *>(dst)[0] = sp[0];
-                        reinterpret_cast<uint4 *>(dst)[1] = sp[1];
+                        *P.wrecs.a(o) = *P.orecs.a(oi);
+                        *P.wrecs.b(o) = *P.orecs.b(oi);
                     } else {
-                        st_record(dst, P.entries.get((wa[j].w >> 8) & 0xff), (int32_t)wa[j].x, (int32_t)wa[j].y, (int32_t)wa[j].z, wa[j].w, wb[j], R_HAS);
+                        st_record(P.wrecs, o, P.entries.get((wa[j].w >> 8) & 0xff), (int32_t)wa[j].x, (int32_t)wa[j].y, (int32_t)wa[j].z, wa[j].w, wb[j], R_HAS);
                     }
                     o++;
                 }
@@ -1728,7 +1731,7 @@ struct DenseParams {
     EntryRef entries;
     GridRef g;                     // (full: device copy of the whole grid, for the exact computation next to a cell boundary)
     uint64_t *wkeys;
-    uint8_t *wrecs;
+    RecArr wrecs;
     const uint64_t *wbase;
     uint32_t *wcount;
     uint32_t *palias;
@@ -1896,11 +1899,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
             if (!cand[k]) continue;
             const int sl = slot[k];
             P.wkeys[o] = s_key[sl];  // (= key[k]: read back instead of kept in two registers per tuple across the barriers)
-            uint8_t *dst = P.wrecs + o * 32;
             const uint32_t abit = 1u << (sl & 31);
             if (s_aliasbits[sl >> 5] & abit) {  // left to the exact replay: no point yet, the flag
-                reinterpret_cast<uint4 *>(dst)[0] = make_uint4(0, 0, 0, 0);
-                reinterpret_cast<uint4 *>(dst)[1] = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
+                *P.wrecs.a(o) = make_uint4(0, 0, 0, 0);
+                *P.wrecs.b(o) = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
                 atomicAnd(&s_aliasbits[sl >> 5], ~abit);
                 if (atomicExch(&P.palias[p], 1u) == 0) atomicAdd(&P.stats[2], 1ull);
             } else {
@@ -1910,7 +1912,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
                 int32_t x = tu[k].x, y = tu[k].y, z = tu[k].z;
                 uint32_t w0 = tu[k].w0;
                 asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w0));
-                st_record(dst, P.entries.get((w0 >> 8) & 0xff), x, y, z, w0, tu[k].w1, R_HAS);
+                st_record(P.wrecs, o, P.entries.get((w0 >> 8) & 0xff), x, y, z, w0, tu[k].w1, R_HAS);
             }
             s_key[sl] = PCQ_EMPTY_KEY, s_dist[sl] = ~0ull, s_ord[sl] = ~0ull;
         }
@@ -1943,7 +1945,7 @@ __global__ __launch_bounds__(L2_NT) void k_alias_gather(FoldParams P, AliasItem 
     const uint64_t wb = P.wbase[p];
     const uint32_t wn = P.wcount[p];
     for (uint32_t i = threadIdx.x; i < wn; i += L2_NT)
-        if (P.wrecs[(wb + i) * 32 + 31] & R_ALIAS) s_akeys[atomicAdd(&s_n, 1u)] = P.wkeys[wb + i];
+        if (rec_flags(*P.wrecs.b(wb + i)) & R_ALIAS) s_akeys[atomicAdd(&s_n, 1u)] = P.wkeys[wb + i];
     __syncthreads();
     const uint32_t na = s_n;
     uint32_t mine = 0;
@@ -2000,9 +2002,8 @@ __global__ __launch_bounds__(BLOCK) void k_alias_replay(const AliasItem *__restr
     for (uint32_t i = 0; i < wn && o == ~0ull; i++)
         if (P.wkeys[wb + i] == key) o = wb + i;
     if (o == ~0ull) return;  // cannot happen: the fold wrote a record for every key it saw
-    uint8_t *rec = P.wrecs + o * 32;
-    bool has = rec[31] & R_HAS;
-    uint4 ra = reinterpret_cast<const uint4 *>(rec)[0], rb = reinterpret_cast<const uint4 *>(rec)[1];
+    const uint4 ra = *P.wrecs.a(o), rb = *P.wrecs.b(o);
+    bool has = rec_flags(rb) & R_HAS;
     double cx = __longlong_as_double((long long)((uint64_t)ra.x | ((uint64_t)ra.y << 32))),
            cy = __longlong_as_double((long long)((uint64_t)ra.z | ((uint64_t)ra.w << 32))),
            cz = __longlong_as_double((long long)((uint64_t)rb.x | ((uint64_t)rb.y << 32)));
@@ -2026,7 +2027,7 @@ __global__ __launch_bounds__(BLOCK) void k_alias_replay(const AliasItem *__restr
             changed = true;
         }
     }
-    if (changed) st_record(rec, P.entries.get((best.w0 >> 8) & 0xff), best.x, best.y, best.z, best.w0, best.w1, R_HAS | R_ALIAS);
+    if (changed) st_record(P.wrecs, o, P.entries.get((best.w0 >> 8) & 0xff), best.x, best.y, best.z, best.w0, best.w1, R_HAS | R_ALIAS);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2035,7 +2036,7 @@ __global__ __launch_bounds__(BLOCK) void k_alias_replay(const AliasItem *__restr
 constexpr int DRAIN_RECS = 1024;  // records per LDS image
 constexpr int DRAIN_STAGE = DRAIN_RECS * 31 + 16;
 
-__global__ __launch_bounds__(BLOCK) void k_drain(const uint64_t *__restrict__ wkeys, const uint8_t *__restrict__ wrecs, const uint64_t *__restrict__ wbase,
+__global__ __launch_bounds__(BLOCK) void k_drain(const uint64_t *__restrict__ wkeys, RecArr wrecs, const uint64_t *__restrict__ wbase,
                                                  const uint32_t *__restrict__ wcount, const uint32_t *__restrict__ dpre, uint8_t *__restrict__ out31,
                                                  uint64_t *__restrict__ keys_out) {
     __shared__ __attribute__((aligned(16))) uint8_t s_stage[DRAIN_STAGE];
@@ -2052,8 +2053,7 @@ __global__ __launch_bounds__(BLOCK) void k_drain(const uint64_t *__restrict__ wk
         const uint64_t gbyte0 = (dst + c0) * 31ull;
         const uint32_t pad = (uint32_t)(gbyte0 & 15);
         for (uint32_t i = threadIdx.x; i < m; i += BLOCK) {
-            const uint4 *sp = reinterpret_cast<const uint4 *>(wrecs + (src + c0 + i) * 32);
-            const uint4 a = sp[0], b = sp[1];
+            const uint4 a = *wrecs.a(src + c0 + i), b = *wrecs.b(src + c0 + i);
             const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
             uint8_t *dp = s_stage + pad + 31u * i;
 #pragma unroll
@@ -2102,7 +2102,8 @@ struct GridState {
     bool any_wide = false;
     // folded winners, grouped by partition
     uint64_t *wkeys = nullptr;
-    uint8_t *wrecs = nullptr;
+    uint8_t *wrecs = nullptr;    // two arrays of 16-byte halves (RecArr), wrec_cap records each
+    uint64_t wrec_cap = 0;
     uint64_t *wbase = nullptr;   // [P + 1]
     uint32_t *wcount = nullptr;  // [P]
     uint32_t f2 = 1;
@@ -2129,6 +2130,7 @@ static void grid_free_winners(pcq_ctx *ctx, GridState *gs) {
     pcq_pool_free(ctx, gs->wbase);
     pcq_pool_free(ctx, gs->wcount);
     gs->wkeys = nullptr, gs->wrecs = nullptr, gs->wbase = nullptr, gs->wcount = nullptr;
+    gs->wrec_cap = 0;
     gs->wtotal = 0;
     gs->f2 = 1;
 }
@@ -2404,7 +2406,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         const uint64_t *obase = gs->wbase;
         const uint32_t *ocount = gs->wcount;
         const uint64_t *okeys = gs->wkeys;
-        const uint8_t *orecs = gs->wrecs;
+        RecArr orecs{gs->wrecs, gs->wrec_cap};
         const bool recut_old = w_old && gs->f2 != f2;
         if (f2 > 1 || recut_old) {
             Level2Params L{};
@@ -2435,8 +2437,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 if (rc) return rc;
                 hipLaunchKernelGGL(k_old_per_bin, dim3(F1 / BLOCK), dim3(BLOCK), 0, s, gs->wcount, gs->f2, d_obin);
                 hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, d_obin, d_obinbase, (uint32_t)F1);
-                L.okeys = gs->wkeys, L.orecs = gs->wrecs, L.obase = gs->wbase, L.ocount = gs->wcount, L.f2old = gs->f2;
-                L.obinbase = d_obinbase, L.okeys2 = d_okeys2, L.orecs2 = d_orecs2, L.ooff2 = d_ooff2;
+                L.okeys = gs->wkeys, L.orecs = RecArr{gs->wrecs, gs->wrec_cap}, L.obase = gs->wbase, L.ocount = gs->wcount, L.f2old = gs->f2;
+                L.obinbase = d_obinbase, L.okeys2 = d_okeys2, L.orecs2 = RecArr{d_orecs2, w_old}, L.ooff2 = d_ooff2;
             }
             PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
             if (staged) hipLaunchKernelGGL(k_level2, dim3(F1), dim3(L2S_NT), 0, s, L);
@@ -2454,7 +2456,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
             }
             if (recut_old) {
                 hipLaunchKernelGGL(k_unpack_old_dir, dim3((nparts + 1 + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_ooff2, nparts, d_obase2, d_ocount2);
-                okeys = d_okeys2, orecs = d_orecs2, obase = d_obase2, ocount = d_ocount2;
+                okeys = d_okeys2, orecs = RecArr{d_orecs2, w_old}, obase = d_obase2, ocount = d_ocount2;
             }
         }
         // room for the winners
@@ -2490,7 +2492,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         FoldParams F{};
         F.src = src, F.seg = seg2, F.entries = eref, F.g = gref;
         if (w_old) F.okeys = okeys, F.orecs = orecs, F.obase = obase, F.ocount = ocount;
-        F.wkeys = n_wkeys, F.wrecs = n_wrecs, F.wbase = n_wbase, F.wcount = n_wcount, F.palias = d_palias, F.pay_scratch = d_pay, F.stats = d_stats;
+        F.wkeys = n_wkeys, F.wrecs = RecArr{n_wrecs, wcap}, F.wbase = n_wbase, F.wcount = n_wcount, F.palias = d_palias, F.pay_scratch = d_pay, F.stats = d_stats;
         {
             uint32_t resident = resident_wgs;
             if (resident > nparts) resident = nparts;
@@ -2498,7 +2500,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 F.defer_list = d_defer;
                 DenseParams D{};
                 D.tuples = seg2.tuples, D.wide = seg2.wide, D.off = seg2.off, D.cnt = seg2.cnt, D.entries = eref, D.g = gref;
-                D.wkeys = n_wkeys, D.wrecs = n_wrecs, D.wbase = n_wbase, D.wcount = n_wcount, D.palias = d_palias, D.stats = d_stats, D.defer_list = d_defer;
+                D.wkeys = n_wkeys, D.wrecs = RecArr{n_wrecs, wcap}, D.wbase = n_wbase, D.wcount = n_wcount, D.palias = d_palias, D.stats = d_stats, D.defer_list = d_defer;
                 hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, false, 6>), dim3(resident), dim3(DENSE_NT), 0, s, D, nparts);
             }
             if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, true, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
@@ -2551,6 +2553,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         att.keep(n_wkeys), att.keep(n_wrecs), att.keep(n_wbase), att.keep(n_wcount);
         grid_free_winners(ctx, gs);
         gs->wkeys = n_wkeys, gs->wrecs = n_wrecs, gs->wbase = n_wbase, gs->wcount = n_wcount;
+        gs->wrec_cap = wcap;
         gs->f2 = f2;
         gs->wtotal = st[0];
         ctx->grid_last_f2 = f2;
@@ -2587,7 +2590,7 @@ int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_
     if (!rc && keys_out) rc = tmp.get(n, &d_keys);
     if (rc) return rc;
     hipLaunchKernelGGL(k_excl_scan_u32, dim3(1), dim3(1024), 0, s, gs->wcount, d_pre, nparts);
-    hipLaunchKernelGGL(k_drain, dim3(nparts), dim3(BLOCK), 0, s, gs->wkeys, gs->wrecs, gs->wbase, gs->wcount, d_pre, d_out, d_keys);
+    hipLaunchKernelGGL(k_drain, dim3(nparts), dim3(BLOCK), 0, s, gs->wkeys, RecArr{gs->wrecs, gs->wrec_cap}, gs->wbase, gs->wcount, d_pre, d_out, d_keys);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && out) e = hipMemcpyAsync(out, d_out, n * 31, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess && keys_out) e = hipMemcpyAsync(keys_out, d_keys, n * 8, hipMemcpyDeviceToHost, s);
