@@ -613,24 +613,23 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
                 s_akey[place] = ev.key;
                 const bool through = ev.alias || ev.dbits >= 0x7ff0000000000000ull;
                 pk[j] = (through ? 0ull : ((ev.dbits >> AGG_POS_BITS) + 1) << AGG_POS_BITS) | place;
-                metas[j] = bin_of(h) | (((uint32_t)(h >> 24) & (AGG_SLOTS - 1)) << F1_BITS);
-                if (!RGB) rg[j] = sel16_of(h) << 16;  // (no colour: the red half of w0 carries the second level's selector)
+                metas[j] = bin_of(h) | (sel16_of(h) << 16);  // (the bin, and the second level's selector for the red half of a colourless w0)
+                ranks[j] = (uint32_t)(h >> 24) & (AGG_SLOTS - 1);  // the table slot, until the tile's fold is over
             } else {
                 const uint64_t h = cell_hash(key_only(g, px, py, pz));
-                metas[j] = bin_of(h);
-                if (!RGB) rg[j] = sel16_of(h) << 16;
+                metas[j] = bin_of(h) | (sel16_of(h) << 16);
             }
         }
         if (agg) {
             __syncthreads();  // the table is clear, the keys are in place
 #pragma unroll
             for (int j = 0; j < ITEMS; j++)
-                if (passes[j]) atomicMin((unsigned long long *)&s_atab[metas[j] >> F1_BITS], (unsigned long long)pk[j]);
+                if (passes[j]) atomicMin((unsigned long long *)&s_atab[ranks[j]], (unsigned long long)pk[j]);
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {
                 if (!passes[j]) continue;
-                const uint64_t w = s_atab[metas[j] >> F1_BITS];
+                const uint64_t w = s_atab[ranks[j]];
                 const uint64_t wkey = s_akey[(uint32_t)w & ((1u << AGG_POS_BITS) - 1)], mykey = s_akey[(uint32_t)j * NT + tid];
                 passes[j] = wkey != mykey || (w >> AGG_POS_BITS) == 0 || (w >> AGG_POS_BITS) == (pk[j] >> AGG_POS_BITS);
             }
@@ -678,7 +677,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
             uint32_t *q = s_img + at * (TS / 4);  // (5 or 6 words per tuple: an odd stride, or two-way conflicts — the LDS is not what this kernel waits for)
             q[0] = (uint32_t)cur[j].rp.x, q[1] = (uint32_t)cur[j].rp.y, q[2] = (uint32_t)cur[j].rp.z;
             q[3] = (uint32_t)(idx_base + base) + (uint32_t)j * NT + tid;
-            q[4] = cl[j] | (entry << 8) | (RGB ? rg[j] << 16 : rg[j]);
+            q[4] = cl[j] | (entry << 8) | (RGB ? rg[j] << 16 : metas[j] & 0xffff0000u);
             if (RGB) q[5] = (rg[j] >> 16) | (bb[j] << 16);
         }
 #pragma unroll
@@ -1381,8 +1380,7 @@ template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool BINS, bool DIRECT, int 
 __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t nparts) {
     constexpr int SPT = (NSLOT + NT - 1) / NT;   // slots per thread in the compaction
     constexpr int CHUNK = NT * FOLD_K;
-    constexpr int FB = BINS ? BIG_FB : 1;
-    static_assert(!BINS || NT > BIG_FB, "one window entry per thread");
+    constexpr int FB = BINS ? (NT > BIG_FB ? BIG_FB : NT - 64) : 1;  // one window entry per thread
     __shared__ uint64_t s_key[NSLOT];
     __shared__ uint64_t s_dist[NSLOT];   // f64 bits of the best squared distance (monotone for d >= 0)
     __shared__ uint64_t s_ord[NSLOT];    // file order of the winner: 0 = an earlier fold's winner, ~0 = none yet
@@ -1697,7 +1695,8 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
 // The fold of a dense grid's partitions, on its own: one segment (the second level's output), no earlier winners, the
 // partition's tuples in one chunk of registers.  k_fold handles every case and pays for it in registers (168, three waves
 // per SIMD) — and a small partition is a chain of latencies (its offsets, its tuples, three barriers, the stores), so the
-// waves per CU decide its speed.  This kernel keeps only the common case: 512 threads x 3 tuples, 6 waves per SIMD.
+// waves per CU decide its speed — as long as nothing is spilled.  This kernel keeps only the common case: 512 threads x 3 tuples,
+// two workgroups per CU (three needed 80 registers and spilled 92 bytes per lane and partition: 4.8 GB of scratch each way).
 //  * every thread holds its tuples from the load to the end: the winner of a cell writes the record from registers;
 //  * the table is cleared once: every occupied slot has exactly one winner, which resets the slot behind itself;
 //  * the tuples are loaded and evaluated BEFORE the barrier that separates the partitions;
@@ -1738,7 +1737,7 @@ struct DenseParams {
     unsigned long long *stats;
     uint32_t *defer_list;
 };
-template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool PREFETCH, int MIN_WAVES>
+template <int NSLOT, int NT, int FOLD_K, int LIMIT, int MIN_WAVES>
 __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uint32_t nparts) {
     constexpr int CHUNK = NT * FOLD_K;
     __shared__ uint64_t s_key[NSLOT];
@@ -1762,30 +1761,11 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     // (the partition's range and output base are the same for the whole workgroup: scalar registers)
     const uint32_t *cntp = P.cnt;
     if (p < nparts) cur_lo = uni32(off[p]), cur_cnt = cntp ? uni32(cntp[p]) : uni32(off[p + 1]) - cur_lo, cur_out = uni64(P.wbase[p]);
-    GridTuple tn[PREFETCH ? FOLD_K : 1];  // PREFETCH: the tuples of the partition after the current one, in flight while it is folded
-    if (PREFETCH && p < nparts) {
-#pragma unroll
-        for (int k = 0; k < FOLD_K; k++) {
-            const uint32_t i = k * NT + threadIdx.x;
-            tn[PREFETCH ? k : 0] = ld_tuple(tuples + (uint64_t)(cur_lo + (i < cur_cnt ? i : (cur_cnt ? cur_cnt - 1 : 0))) * ts, wide);
-        }
-    }
     for (; p < nparts; p += gridDim.x) {
         const uint32_t pn = p + gridDim.x;
         if (pn < nparts) nxt_lo = uni32(off[pn]), nxt_cnt = cntp ? uni32(cntp[pn]) : uni32(off[pn + 1]) - nxt_lo, nxt_out = uni64(P.wbase[pn]);
         const uint32_t cnt = cur_cnt;
         GridTuple tu[FOLD_K];
-        if (PREFETCH) {
-#pragma unroll
-            for (int k = 0; k < FOLD_K; k++) tu[k] = tn[PREFETCH ? k : 0];
-            if (pn < nparts) {
-#pragma unroll
-                for (int k = 0; k < FOLD_K; k++) {
-                    const uint32_t i = k * NT + threadIdx.x;
-                    tn[PREFETCH ? k : 0] = ld_tuple(tuples + (uint64_t)(nxt_lo + (i < nxt_cnt ? i : (nxt_cnt ? nxt_cnt - 1 : 0))) * ts, wide);
-                }
-            }
-        }
         if (cnt > (uint32_t)CHUNK) {  // (the same for every thread of the workgroup)
             if (threadIdx.x == 0) P.defer_list[atomicAdd(&P.stats[3], 1ull)] = p;
             cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
@@ -1793,12 +1773,10 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
         }
         uint64_t key[FOLD_K], dbits[FOLD_K];
         bool alias[FOLD_K];
-        if (!PREFETCH) {
 #pragma unroll
-            for (int k = 0; k < FOLD_K; k++) {
-                const uint32_t i = k * NT + threadIdx.x;
-                tu[k] = ld_tuple(tuples + (uint64_t)(cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0))) * ts, wide);
-            }
+        for (int k = 0; k < FOLD_K; k++) {
+            const uint32_t i = k * NT + threadIdx.x;
+            tu[k] = ld_tuple(tuples + (uint64_t)(cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0))) * ts, wide);
         }
         uint32_t inexact = 0;  // bit k: tuple k is next to a cell boundary (or outside the short computation's range)
 #pragma unroll
@@ -1886,10 +1864,6 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
         for (int w = 0; w < NT / 64; w++) {
             before += w < wave ? s_wsum[w] : 0;
             total += s_wsum[w];
-        }
-        if (PREFETCH) {  // the next partition's tuples have arrived — before this one's stores are issued (one counter, k_p0_part)
-#pragma unroll
-            for (int k = 0; k < FOLD_K; k++) asm volatile("" ::"v"(tn[PREFETCH ? k : 0].x), "v"(tn[PREFETCH ? k : 0].w0));
         }
         uint64_t run_base = cur_out + before;  // the first place of this wave's winners of tuple slot k
 #pragma unroll
@@ -2501,7 +2475,11 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 DenseParams D{};
                 D.tuples = seg2.tuples, D.wide = seg2.wide, D.off = seg2.off, D.cnt = seg2.cnt, D.entries = eref, D.g = gref;
                 D.wkeys = n_wkeys, D.wrecs = RecArr{n_wrecs, wcap}, D.wbase = n_wbase, D.wcount = n_wcount, D.palias = d_palias, D.stats = d_stats, D.defer_list = d_defer;
-                hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, false, 6>), dim3(resident), dim3(DENSE_NT), 0, s, D, nparts);
+                // two workgroups per CU (4 waves per SIMD, 103 registers, nothing spilled) — three (6 waves per SIMD, 80 registers)
+                // spilled 92 bytes per lane and partition, 4.8 GB of scratch each way per file: 2.58 against 2.20 ms in one process
+                uint32_t dense_wgs = (uint32_t)ctx->num_cus * 2u;
+                if (dense_wgs > nparts) dense_wgs = nparts;
+                hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, 4>), dim3(dense_wgs), dim3(DENSE_NT), 0, s, D, nparts);
             }
             if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, true, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
             else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, true, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
