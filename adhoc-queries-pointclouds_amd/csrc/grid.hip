@@ -28,12 +28,13 @@
 //           32-byte record + key per cell, coalesced.  A coarse grid folds its level-1 bins directly (k_fold<BIG>:
 //           a CU's whole LDS as one 6400-slot table); a denser grid first gets a second partition level (k_level2:
 //           one pass into fixed regions with slack, fan-out chosen from a measured estimate of the distinct cells per
-//           bin) and folds the small partitions three workgroups to a CU (k_fold_dense; k_fold<SMALL> for what that
+//           bin) and folds the small partitions two workgroups to a CU (k_fold_dense; k_fold<SMALL> for what that
 //           leaves: earlier winners, partitions longer than a chunk).
 // What the kernels had to learn about gfx950: every pass is bound by vector instructions before
 // it is bound by memory unless the cell arithmetic is cut down (cell_fast); loads and stores share one in-order
 // counter, so a prefetch must be waited for before the stores behind it are issued; pointers loaded from memory make
-// flat loads, which also hold every LDS wait.
+// flat loads, which also hold every LDS wait; a device-scope fence writes the L2 back; registers spilled to scratch are
+// HBM traffic (the dense fold: 4.8 GB each way per file until it ran with more registers and fewer waves).
 // The folded winners are kept grouped by partition, so a later fold (more scans into the same collector: sequential
 // mode shares one grid, main.rs:129-133; a file streamed in chunks) merges them with the new tuples partition by
 // partition: an old winner is earlier in file order than every new tuple and its distance is recomputed from its
@@ -67,7 +68,7 @@ static_assert(P0_TILE <= (1 << AGG_POS_BITS) && P0_TILE <= 65535, "tile places f
 static_assert((P0_TILE * 20) % 16 == 0 && (P0_TILE * 24) % 16 == 0, "a tile's block starts 16-byte aligned and holds whole 16-byte words");
 // The fold's shapes.  BIG: one 1024-thread workgroup owns a CU's whole LDS — 6400 slots of {key, distance, file order},
 // the winner's payload parked in HBM scratch — and folds a level-1 bin directly (coarse grids: few cells, many tuples
-// per cell).  SMALL / DENSE: 2048 slots, three workgroups per CU, a whole partition of the second level (about 1000
+// per cell).  SMALL / DENSE: 2048 slots, three / two workgroups per CU, a whole partition of the second level (about 1000
 // cells, 1330 tuples) in registers, so that the winner of a cell writes its record straight from there (dense grids:
 // about one tuple per cell, many small partitions) — 256 threads x 6 tuples in the general kernel, 512 x 3 in
 // k_fold_dense.
