@@ -255,10 +255,14 @@ int pcq_bind_thread_near_device(pcq_ctx *ctx);
 
 /* Options: "blocks_per_cu" (persistent blocks per CU of the strided count kernels), "chunk_points" (points per staging
  * chunk of the host paths), "copy_threads" (threads filling a staging chunk, default 8), "numa_local",
- * "allreduce_single_rank", "grid_pending_budget" (matches a grid collector may hold before it folds them; 0 = default),
+ * "allreduce_single_rank", "allreduce_fail" (tests: 1 = pcq_allreduce_sum_u64 fails before it touches anything, 2 = after the
+ * reduction ran), "grid_pending_budget" (points a grid collector may hold unfolded; 0 = default), "grid_agg" (pass 0 folds a
+ * tile's duplicate cells before they travel: 0 = while it pays, 1 = every tile, 2 = never; same results in every mode),
  * "grid_f2" (tests: the second-level fan-out a fold starts from; 0 = from the measured estimate).  pcq_get_option also
  * reads "numa_node" and the grid diagnostics "grid_folds", "grid_level2" (folds that needed a second partition level),
- * "grid_refolds" (folds repeated with more partitions), "grid_level2_exact" (second levels repeated in the counting form), "grid_last_f2".  (The kernel-shape experiments of round 1 —
+ * "grid_refolds" (folds repeated with more partitions), "grid_level2_exact" (second levels repeated in the counting form),
+ * "grid_compactions" (folds that copied short fragments together first), "grid_last_f2", "grid_last_tuples" (tuples the last
+ * fold found pending: what is left of the matches after pass 0's own fold).  (The kernel-shape experiments of round 1 —
  * "k1_variant", "batch_variant", ... — are options of libpcq_lab.so only: include/pcq_lab.h.) */
 int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value);
 int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value);
