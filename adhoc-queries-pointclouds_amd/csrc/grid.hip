@@ -540,7 +540,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
     uint32_t *s_img = reinterpret_cast<uint32_t *>(s_raw);                     // the block as it will lie in memory: TS bytes per tuple
     uint64_t *s_akey = reinterpret_cast<uint64_t *>(s_raw);                    // the cell key of every place in the tile
     uint64_t *s_atab = s_akey + P0_TILE;                                       // the table
-    __shared__ uint32_t s_cnt[F1], s_base[F1 + 1], s_wsum[NT / 64], s_npass[2];
+    __shared__ uint32_t s_cnt[F1], s_base[F1 + 1], s_npass[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (uint32_t t = tid; t < F1; t += NT) s_cnt[t] = 0;
     if (tid < 2) s_npass[tid] = 0;
@@ -644,26 +644,26 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
             if (lane == 0 && npass) atomicAdd(&s_npass[parity], npass);
         }
         __syncthreads();
-        {  // exclusive scan of the tile's counts over the bins (thread t = bin t); the counters are cleared for the next tile
-            const uint32_t v = tid < (uint32_t)F1 ? s_cnt[tid] : 0;
-            uint32_t incl = v;
+        if (wave == 0) {  // exclusive scan of the tile's counts over the bins, by ONE wave (lane l = bins 8 l .. 8 l + 7): no barrier inside;
+                          // the counters are cleared for the next tile
+            constexpr int BPL = F1 / 64;
+            uint32_t v[BPL], mine = 0;
+#pragma unroll
+            for (int q = 0; q < BPL; q++) v[q] = s_cnt[lane * BPL + q], mine += v[q];
+            uint32_t incl = mine;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const uint32_t up = __shfl_up(incl, off, 64);
                 if (lane >= (uint32_t)off) incl += up;
             }
-            if (lane == 63) s_wsum[wave] = incl;
-            __syncthreads();
-            uint32_t before = incl - v, total = 0;
-            for (int w = 0; w < NT / 64; w++) {
-                before += (uint32_t)w < wave ? s_wsum[w] : 0;
-                total += s_wsum[w];
+            uint32_t before = incl - mine;
+#pragma unroll
+            for (int q = 0; q < BPL; q++) {
+                s_base[lane * BPL + q] = before;
+                s_cnt[lane * BPL + q] = 0;
+                before += v[q];
             }
-            if (tid < (uint32_t)F1) {
-                s_base[tid] = before;
-                s_cnt[tid] = 0;
-            }
-            if (tid == 0) s_base[F1] = total;
+            if (lane == 63) s_base[F1] = incl;
         }
         __syncthreads();
         const uint32_t total = s_base[F1], matched = s_npass[parity];
@@ -1090,7 +1090,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
 // The bin arrives through the fragment reader: a window of 2048 fragments (about five tiles' worth of tuples) in LDS,
 // whole tiles out of it — the next window starts at the fragment the last whole tile ended in.
 __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
-    constexpr int BPT = L2_STAGED_F2 / L2S_NT;  // sub-partitions per thread in the per-tile scan
+    constexpr int BPT = L2_STAGED_F2 / L2S_NT;  // sub-partitions per thread when the cursors move on
     static_assert(BPT >= 1 && BPT * L2S_NT == L2_STAGED_F2, "whole sub-partitions per thread");
     __shared__ uint32_t s_cur[L2_STAGED_F2], s_ohist[L2_STAGED_F2], s_ocur[L2_STAGED_F2];
     __shared__ uint32_t s_cnt[L2_STAGED_F2], s_base[L2_STAGED_F2];
@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
     __shared__ uint32_t s_tpos[L2S_TILE];
     __shared__ uint32_t s_pre[L2S_FB + 1];
     __shared__ uint64_t s_addr[L2S_FB];
-    __shared__ uint32_t s_wsum[L2S_NT / 64], s_total, s_overflow;
+    __shared__ uint32_t s_total, s_overflow;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t bin = xcd_order(blockIdx.x, F1), f2 = P.f2, cap = P.cap;
     for (uint32_t t = threadIdx.x; t < L2_STAGED_F2; t += L2S_NT) s_cur[t] = 0, s_ohist[t] = 0, s_cnt[t] = 0;
@@ -1166,31 +1166,25 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
                         if (valid[j]) ranks[j] = atomicAdd(&s_cnt[subs[j]], 1u);
                     }
                     __syncthreads();
-                    {  // exclusive scan of the tile's counts over the sub-partitions (BPT per thread)
-                        const uint32_t s0 = threadIdx.x * BPT;
-                        uint32_t v[BPT], mine = 0;
+                    if (wave == 0) {  // exclusive scan of the tile's counts over the sub-partitions, by ONE wave (lane l = entries 16 l ..): no barrier inside
+                        constexpr int BPL = L2_STAGED_F2 / 64;
+                        uint32_t v[BPL], mine = 0;
 #pragma unroll
-                        for (int q = 0; q < BPT; q++) v[q] = s_cnt[s0 + q], mine += v[q];
+                        for (int q = 0; q < BPL; q++) v[q] = s_cnt[lane * BPL + q], mine += v[q];
                         uint32_t incl = mine;
 #pragma unroll
                         for (int off = 1; off < 64; off <<= 1) {
                             const uint32_t up = __shfl_up(incl, off, 64);
                             if (lane >= off) incl += up;
                         }
-                        if (lane == 63) s_wsum[wave] = incl;
-                        __syncthreads();
-                        uint32_t before = incl - mine, total = 0;
-                        for (int w = 0; w < L2S_NT / 64; w++) {
-                            before += w < wave ? s_wsum[w] : 0;
-                            total += s_wsum[w];
-                        }
+                        uint32_t before = incl - mine;
 #pragma unroll
-                        for (int q = 0; q < BPT; q++) {
-                            s_base[s0 + q] = before;
-                            s_cnt[s0 + q] = 0;
+                        for (int q = 0; q < BPL; q++) {
+                            s_base[lane * BPL + q] = before;
+                            s_cnt[lane * BPL + q] = 0;
                             before += v[q];
                         }
-                        if (threadIdx.x == 0) s_total = total;
+                        if (lane == 63) s_total = incl;
                     }
                     __syncthreads();
 #pragma unroll
