@@ -696,7 +696,6 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
         const uint32_t nq = (total * TS + 15) / 16;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         for (uint32_t t = tid; t < nq; t += NT) *(PCQ_GLOBAL u32x4 *)(blk + t) = reinterpret_cast<const u32x4 *>(s_img)[t];
-        __syncthreads();  // the image is rewritten by the next tile
         if (agg && agg_mode == 0) {
             if (total * 4 > matched * 3) {  // less than a quarter shed: not worth the table for a while
                 agg_backoff = agg_backoff < 16 ? agg_backoff * 2 : 16;
@@ -707,6 +706,11 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
         } else if (agg_skip) {
             agg_skip--;
         }
+        // The next tile rewrites the image.  Without the tile's table that happens behind its first two barriers — no thread
+        // gets there before every thread has left this copy-out —, so only a tile that starts with the table (clear + key
+        // array, in the image's LDS) needs a barrier here: three barriers per tile instead of four (five at the start of the
+        // round: 1.18 -> 1.10 -> see profiles/r03_grid_progress.txt).
+        if (agg_mode == 1 || (agg_mode == 0 && agg_skip == 0)) __syncthreads();
     }
 }
 
@@ -1222,7 +1226,8 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
                             if (wide_out) *(PCQ_GLOBAL uint32_t *)(q + 20) = b.y;
                         }
                     }
-                    __syncthreads();
+                    // (no barrier at the end of a tile: the next tile writes the sorted image and the cursors only behind its
+                    // first two barriers, and nobody passes those before everybody has left this copy-out)
                 }
             }
             // the next window: at the fragment tuple `hi` of the bin lies in
