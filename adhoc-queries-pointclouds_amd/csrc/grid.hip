@@ -540,13 +540,9 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
     uint32_t *s_img = reinterpret_cast<uint32_t *>(s_raw);                     // the block as it will lie in memory: TS bytes per tuple
     uint64_t *s_akey = reinterpret_cast<uint64_t *>(s_raw);                    // the cell key of every place in the tile
     uint64_t *s_atab = s_akey + P0_TILE;                                       // the table
-    // (the bin counters and bases are padded by a word per 8 bins: the one wave that scans them reads 8 consecutive bins per lane —
-    // 9 words from lane to lane instead of 8, no two lanes in one bank)
-    auto pad8 = [](uint32_t b) { return b + (b >> 3); };
-    __shared__ uint32_t s_cnt[F1 + F1 / 8], s_base[F1 + F1 / 8], s_npass[2];
-    __shared__ uint32_t s_tile_total;
+    __shared__ uint32_t s_cnt[F1], s_base[F1 + 1], s_npass[2];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (uint32_t t = tid; t < F1 + F1 / 8; t += NT) s_cnt[t] = 0;
+    for (uint32_t t = tid; t < F1; t += NT) s_cnt[t] = 0;
     if (tid < 2) s_npass[tid] = 0;
     __syncthreads();
     uint32_t agg_skip = 0, agg_backoff = 1, parity = 0;
@@ -641,7 +637,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; j++)
-            if (passes[j]) ranks[j] = atomicAdd(&s_cnt[pad8(metas[j] & (F1 - 1))], 1u);
+            if (passes[j]) ranks[j] = atomicAdd(&s_cnt[metas[j] & (F1 - 1)], 1u);
         {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) npass += __shfl_xor(npass, o, 64);
@@ -653,7 +649,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
             constexpr int BPL = F1 / 64;
             uint32_t v[BPL], mine = 0;
 #pragma unroll
-            for (int q = 0; q < BPL; q++) v[q] = s_cnt[pad8(lane * BPL + q)], mine += v[q];
+            for (int q = 0; q < BPL; q++) v[q] = s_cnt[lane * BPL + q], mine += v[q];
             uint32_t incl = mine;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
@@ -663,22 +659,22 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
             uint32_t before = incl - mine;
 #pragma unroll
             for (int q = 0; q < BPL; q++) {
-                s_base[pad8(lane * BPL + q)] = before;
-                s_cnt[pad8(lane * BPL + q)] = 0;
+                s_base[lane * BPL + q] = before;
+                s_cnt[lane * BPL + q] = 0;
                 before += v[q];
             }
-            if (lane == 63) s_tile_total = incl;
+            if (lane == 63) s_base[F1] = incl;
         }
         __syncthreads();
-        const uint32_t total = s_tile_total, matched = s_npass[parity];
+        const uint32_t total = s_base[F1], matched = s_npass[parity];
         if (tid < (uint32_t)DIR_WORDS) {  // the directory row, two entries per word
-            const uint32_t lo = 2 * tid < (uint32_t)F1 ? s_base[pad8(2 * tid)] : total, hi = 2 * tid + 1 < (uint32_t)F1 ? s_base[pad8(2 * tid + 1)] : (2 * tid + 1 == (uint32_t)F1 ? total : 0);
+            const uint32_t lo = s_base[2 * tid], hi = 2 * tid + 1 <= (uint32_t)F1 ? s_base[2 * tid + 1] : 0;
             *(PCQ_GLOBAL uint32_t *)(reinterpret_cast<uint32_t *>(dir + (size_t)tile * DIR_STRIDE) + tid) = lo | (hi << 16);
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
             if (!passes[j]) continue;
-            const uint32_t at = s_base[pad8(metas[j] & (F1 - 1))] + ranks[j];
+            const uint32_t at = s_base[metas[j] & (F1 - 1)] + ranks[j];
             uint32_t *q = s_img + at * (TS / 4);  // (5 or 6 words per tuple: an odd stride, or two-way conflicts — the LDS is not what this kernel waits for)
             q[0] = (uint32_t)cur[j].rp.x, q[1] = (uint32_t)cur[j].rp.y, q[2] = (uint32_t)cur[j].rp.z;
             q[3] = (uint32_t)(idx_base + base) + (uint32_t)j * NT + tid;
@@ -1101,8 +1097,7 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
     constexpr int BPT = L2_STAGED_F2 / L2S_NT;  // sub-partitions per thread when the cursors move on
     static_assert(BPT >= 1 && BPT * L2S_NT == L2_STAGED_F2, "whole sub-partitions per thread");
     __shared__ uint32_t s_cur[L2_STAGED_F2], s_ohist[L2_STAGED_F2], s_ocur[L2_STAGED_F2];
-    auto pad16 = [](uint32_t b) { return b + (b >> 4); };  // (a word per 16 entries: the one-wave scan reads 16 consecutive entries per lane without bank conflicts)
-    __shared__ uint32_t s_cnt[L2_STAGED_F2 + L2_STAGED_F2 / 16], s_base[L2_STAGED_F2 + L2_STAGED_F2 / 16];
+    __shared__ uint32_t s_cnt[L2_STAGED_F2], s_base[L2_STAGED_F2];
     __shared__ uint4 s_xyzi[L2S_TILE];   // the tile's tuples, sorted by sub-partition: x, y, z, idx
     __shared__ uint2 s_attr[L2S_TILE];   //                                                 w0, w1
     __shared__ uint32_t s_tpos[L2S_TILE];
@@ -1111,8 +1106,7 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
     __shared__ uint32_t s_total, s_overflow;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t bin = xcd_order(blockIdx.x, F1), f2 = P.f2, cap = P.cap;
-    for (uint32_t t = threadIdx.x; t < L2_STAGED_F2; t += L2S_NT) s_cur[t] = 0, s_ohist[t] = 0;
-    for (uint32_t t = threadIdx.x; t < L2_STAGED_F2 + L2_STAGED_F2 / 16; t += L2S_NT) s_cnt[t] = 0;
+    for (uint32_t t = threadIdx.x; t < L2_STAGED_F2; t += L2S_NT) s_cur[t] = 0, s_ohist[t] = 0, s_cnt[t] = 0;
     if (threadIdx.x == 0) s_overflow = 0;
     __syncthreads();
     if (P.okeys)
@@ -1173,14 +1167,14 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
                         valid[j] = base + j * L2S_NT + threadIdx.x < hi;
                         subs[j] = tuple_sub(P.g, P.entries, t[j], f2);
                         ranks[j] = 0;
-                        if (valid[j]) ranks[j] = atomicAdd(&s_cnt[pad16(subs[j])], 1u);
+                        if (valid[j]) ranks[j] = atomicAdd(&s_cnt[subs[j]], 1u);
                     }
                     __syncthreads();
                     if (wave == 0) {  // exclusive scan of the tile's counts over the sub-partitions, by ONE wave (lane l = entries 16 l ..): no barrier inside
                         constexpr int BPL = L2_STAGED_F2 / 64;
                         uint32_t v[BPL], mine = 0;
 #pragma unroll
-                        for (int q = 0; q < BPL; q++) v[q] = s_cnt[pad16(lane * BPL + q)], mine += v[q];
+                        for (int q = 0; q < BPL; q++) v[q] = s_cnt[lane * BPL + q], mine += v[q];
                         uint32_t incl = mine;
 #pragma unroll
                         for (int off = 1; off < 64; off <<= 1) {
@@ -1190,8 +1184,8 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
                         uint32_t before = incl - mine;
 #pragma unroll
                         for (int q = 0; q < BPL; q++) {
-                            s_base[pad16(lane * BPL + q)] = before;
-                            s_cnt[pad16(lane * BPL + q)] = 0;
+                            s_base[lane * BPL + q] = before;
+                            s_cnt[lane * BPL + q] = 0;
                             before += v[q];
                         }
                         if (lane == 63) s_total = incl;
@@ -1200,7 +1194,7 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
 #pragma unroll
                     for (int j = 0; j < L2S_ITEMS; j++) {
                         if (!valid[j]) continue;
-                        const uint32_t at = s_base[pad16(subs[j])] + ranks[j];
+                        const uint32_t at = s_base[subs[j]] + ranks[j];
                         s_xyzi[at] = make_uint4((uint32_t)t[j].x, (uint32_t)t[j].y, (uint32_t)t[j].z, t[j].idx);
                         s_attr[at] = make_uint2(t[j].w0, t[j].w1);
                         const uint32_t within = s_cur[subs[j]] + ranks[j];  // place in the sub-partition's region
@@ -1216,7 +1210,7 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
                         const uint32_t s0 = threadIdx.x * BPT, total = s_total;
 #pragma unroll
                         for (int q = 0; q < BPT; q++) {
-                            const uint32_t lo_b = s_base[pad16(s0 + q)], hi_b = s0 + q + 1 < L2_STAGED_F2 ? s_base[pad16(s0 + q + 1)] : total;
+                            const uint32_t lo_b = s_base[s0 + q], hi_b = s0 + q + 1 < L2_STAGED_F2 ? s_base[s0 + q + 1] : total;
                             s_cur[s0 + q] += hi_b - lo_b;
                             if (s_cur[s0 + q] > cap) s_overflow = 1;
                         }
