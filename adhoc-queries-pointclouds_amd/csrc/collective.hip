@@ -46,11 +46,16 @@ int load_rccl() {
     // :179, :313-316) and nothing else.  Whatever level the environment asks for goes to stderr unless it names a file.
     setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const auto t0 = std::chrono::steady_clock::now();
     for (const char *n : names) {
         g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (g_rccl.lib) break;
     }
     if (!g_rccl.lib) return pcq_fail(PCQ_ERR_HIP, "RCCL not found (dlopen librccl.so.1): %s", dlerror());
+    // (the library carries code objects for every architecture it supports: loading it registers them all with the HIP
+    // runtime, which is where the seconds go — profiles/r03_rccl_cost.log)
+    if (getenv("PCQ_TIMING") && getenv("PCQ_TIMING")[0] == '1')
+        fprintf(stderr, "[pcq] librccl loaded in %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
 #define BIND(field, sym)                                                               \
     g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(g_rccl.lib, sym)); \
     if (!g_rccl.field) return pcq_fail(PCQ_ERR_HIP, "RCCL symbol %s missing", sym);

@@ -312,9 +312,26 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
     size_t nthreads = devices.size() * (size_t)tpd;
     if (nthreads > work.size()) nthreads = work.size();  // README.md:12
     const bool counting = !opt.collectors_yield_points;
-    // several GPUs, count query: the RCCL communicator is built on a helper thread while the files are scanned
-    // (ncclCommInitAll is of the order of the whole query on eight GPUs; the all-reduce at the end waits for it)
-    if (counting && devices.size() > 1 && !work.empty()) (void)pcq_allreduce_prepare(devices.data(), (int)devices.size());
+    // Several GPUs, count query: how are the per-GPU counts merged?  main.rs:164-180 is a sum; across GPUs it is ONE all-reduce of
+    // a u64 — or, in this process that holds every context, N eight-byte reads and a host loop.  RCCL costs what it costs to
+    // start: measured at ONE rank (tools/r03_rccl_cost.sh) dlopen of librccl.so 1.2-4.8 s and ncclCommInitAll 0.6 s, for a
+    // query that scans 16 files in 0.12 s.  So the all-reduce is the merge when the scans are long enough to hide that start
+    // (estimated from the planned bytes at the measured PCIe rate; the communicator is then built on a helper thread while
+    // the files are scanned), or when PCQ_MERGE=rccl says so; otherwise — and whenever the collective fails — the exact
+    // per-GPU counts are summed on the host.  (One process per GPU, as in bench.py: the all-reduce, through the process group.)
+    bool merge_rccl = false;
+    if (counting && !work.empty()) {
+        const char *policy = getenv("PCQ_MERGE");
+        double planned_bytes = 0;
+        for (size_t w : work)
+            if (plans[w]) planned_bytes += (double)plans[w]->cols.n * (plans[w]->pred.kind == PCQ_PRED_CLASS ? 1.0 : 12.0);
+        const double scan_seconds = planned_bytes / (40e9 * (double)devices.size());
+        merge_rccl = getenv("PCQ_TEST_ALLREDUCE_FAIL") != nullptr || (policy ? !strcmp(policy, "rccl") : (devices.size() > 1 && scan_seconds > 3.0));
+        if (timing)
+            fprintf(stderr, "[pcq] count merge: %s (estimated scan time %.2f s on %zu GPU(s))\n", merge_rccl ? "RCCL all-reduce" : devices.size() > 1 ? "host sum of the per-GPU counts" : "one GPU, its counter is the total",
+                    scan_seconds, devices.size());
+        if (merge_rccl && devices.size() > 1) (void)pcq_allreduce_prepare(devices.data(), (int)devices.size());
+    }
     // per-GPU device counters (count queries): owned by the first worker of the device
     std::vector<uint64_t *> dev_counter(devices.size(), nullptr);
     std::vector<pcq_ctx *> dev_ctx(devices.size(), nullptr);
@@ -406,7 +423,9 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         std::vector<uint64_t *> recvs;
         for (size_t d = 0; d < devices.size(); d++)
             if (dev_counter[d]) ctxs.push_back(dev_ctx[d]), sends.push_back(dev_counter[d]), recvs.push_back(dev_counter[d] + 1);
-        if (!ctxs.empty()) {
+        if (!ctxs.empty() && !merge_rccl && ctxs.size() > 1) {
+            total = merge_counts_on_host(ctxs, sends, &final_status);  // (a short query: RCCL would take longer to load than the scans took)
+        } else if (!ctxs.empty()) {
             if (const char *inj = getenv("PCQ_TEST_ALLREDUCE_FAIL")) {  // tests: make the collective fail ("early" / "late"), through the real RCCL calls
                 (void)pcq_set_option(ctxs[0], "allreduce_single_rank", 1);
                 (void)pcq_set_option(ctxs[0], "allreduce_fail", !strcmp(inj, "late") ? 2 : 1);
