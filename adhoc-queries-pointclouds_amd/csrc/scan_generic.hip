@@ -240,6 +240,9 @@ __global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, co
     const uint32_t tile = blockIdx.x;
     const uint64_t base_count = *d_npoints_in, before = offsets[tile];
     if (tile == 0 && threadIdx.x == 0) *d_npoints_out = base_count + offsets[ntiles];
+    // launch 1 found no match in this tile: nothing of it is read a second time (a box that cuts a flight-line-ordered
+    // file leaves most tiles empty; block-uniform, in front of the first load and the first barrier)
+    if (offsets[tile + 1] == before) return;
     for (int t = threadIdx.x; t < STAGE_WORDS; t += BLOCK) s_stage[t] = 0;
     {
         const uint64_t base = (uint64_t)tile * EMIT_TILE;

@@ -118,7 +118,7 @@ def header_fields(spec: SynthSpec) -> dict:
     """The LAS header fields the query path reads (number of points, scale, offset, min/max bounds)
     for a synthetic file, computed exactly as the generator writes them: extreme integer
     coordinates mapped with `(i as f64 * scale) + offset` (last.rs:156-160).  Python floats are IEEE
-    doubles, so these equal the bytes in the generated header (tests/test_synth.py)."""
+    doubles, so these equal the bytes in the generated header (tests/test_synth_and_sharding.py::test_header_fields_equal_the_generated_header)."""
     mn, mx = [], []
     for a in range(3):
         lo = spec.lo[a]

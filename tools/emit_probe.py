@@ -1,4 +1,6 @@
-"""Developer probe: buffer-collector scans of one resident file (for rocprofv3).  usage: emit_probe.py QUERY [POINTS] [REPEATS]"""
+"""Developer probe: buffer-collector scans of one resident file (for rocprofv3).  usage: emit_probe.py QUERY [POINTS] [REPEATS]
+FRAC=<0..1>: the query box is the file's own box cut to that fraction of its x range (instead of QUERY's box);
+SORTED=1: the file's points are sorted along x first (matches of such a box are then one contiguous run of the file)."""
 import importlib, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,8 +13,20 @@ with pkg.Context(0) as ctx:
     xyz, cls = ctx.alloc(12 * n), ctx.alloc(n)
     ctx.synth_fill(spec, 0, n, xyz, cls)
     ctx.synchronize()
+    if os.environ.get("SORTED"):
+        import numpy as np
+        host = np.zeros((n, 3), dtype=np.int32)
+        ctx.to_host(host, xyz)
+        host = host[np.argsort(host[:, 0], kind="stable")]
+        ctx.to_device(xyz, np.ascontiguousarray(host))
+        del host
     cols = binding.make_columns(xyz=xyz, cls=cls, n=n, scale=list(spec.scale), offset=list(spec.offset))
     bmin, bmax = specs.box(q)
+    if os.environ.get("FRAC"):
+        hf = specs.header_fields(spec)
+        lo, hi = list(hf["min"]), list(hf["max"])
+        hi[0] = lo[0] + float(os.environ["FRAC"]) * (hi[0] - lo[0])
+        bmin, bmax, q = lo, hi, "x<%s" % os.environ["FRAC"]
     lmin, lmax = pkg.box_to_local(bmin, bmax, list(spec.scale), list(spec.offset))
     b = ctx.buffer_collector()
     for _ in range(int(sys.argv[3]) if len(sys.argv) > 3 else 3):

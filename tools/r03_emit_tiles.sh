@@ -1,0 +1,13 @@
+# Buffer collector on one 163 M-point file: boxes that keep 100 % / 50 % / 10 % / 1 % of the file, generator order and x-sorted order
+# (a tile of 2048 points without a match is not read a second time) -> profiles/r03_emit_tiles.log
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out/r03
+O=gpurun_out/r03/emit_tiles.log; : > $O
+for sorted in "" 1; do for frac in 1.0 0.5 0.1 0.01; do
+  echo "== SORTED=${sorted:-0} FRAC=$frac ==" >> $O
+  SORTED=$sorted FRAC=$frac timeout -k 10 300 python tools/emit_probe.py ca13_XL 163000000 4 >> $O 2>&1 || exit 1
+done; done
+cd /tmp && export TMPDIR=/tmp
+SORTED=1 FRAC=0.1 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/r03/prof_emit_tiles -o e -- python $GRAFT_REPO_ROOT/tools/emit_probe.py ca13_XL 163000000 4 > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT && python tools/kstats.py $(find gpurun_out/r03/prof_emit_tiles -name 'e_kernel_stats.csv' | head -1) >> $O 2>&1
+cat $O
