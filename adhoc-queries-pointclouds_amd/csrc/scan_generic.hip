@@ -102,12 +102,14 @@ struct TileIn {
 };
 // Everything is requested together, before the first compare.  (Loading the attributes where the record is built — behind
 // the ranks, one dependent round trip per row of 256 points — left the waves waiting 80 % of the time.)
-template <int KIND, bool ATTRS>
+// RGB: the file has a colour block (formats 2, 3, 5).  Compile-time, because a colourless file otherwise pays three masked
+// loads per point from one address — 24 of a thread's 40 memory instructions per tile.
+template <int KIND, bool ATTRS, bool RGB>
 __device__ __forceinline__ void tile_load_and_test(const DevCols &c, const DevPred &pr, uint64_t base, TileIn<KIND, ATTRS> &T) {
     // No branch around a load: with `c.cls ? c.cls[i] : 0` in the unrolled loop every load sat in its own block and was
     // waited for at the block's end (eight serial round trips per tile).  A missing column is read from a valid address
     // with stride 0 and masked instead.
-    const bool has_cls = (ATTRS || KIND == PCQ_PRED_CLASS) && c.cls, has_rgb = ATTRS && c.rgb;
+    const bool has_cls = (ATTRS || KIND == PCQ_PRED_CLASS) && c.cls, has_rgb = ATTRS && RGB && c.rgb;
     const uint8_t *fallback = c.xyz ? c.xyz : c.cls;  // (one of the two exists: the predicate reads it)
     const uint8_t *clsp = has_cls ? c.cls : fallback, *rgbp = has_rgb ? c.rgb : fallback;
     const uint64_t cls_stride = has_cls ? c.cls_stride : 0, rgb_stride = has_rgb ? c.rgb_stride : 0;
@@ -118,7 +120,7 @@ __device__ __forceinline__ void tile_load_and_test(const DevCols &c, const DevPr
         const uint64_t i0 = base + (uint64_t)j * BLOCK + threadIdx.x, i = i0 < c.n ? i0 : c.n - 1;
         raw_cls[j] = clsp[i * cls_stride];  // last.rs:138-142
         raw_rg[j] = raw_b[j] = 0;
-        if (ATTRS) {  // last.rs:145-153
+        if (ATTRS && RGB) {  // last.rs:145-153
             const uint8_t *q = rgbp + i * rgb_stride;
             raw_rg[j] = (uint32_t)ld_u16(q) | ((uint32_t)ld_u16(q + 2) << 16);
             raw_b[j] = ld_u16(q + 4);
@@ -149,7 +151,7 @@ template <int KIND>
 __global__ __launch_bounds__(BLOCK) void k_tile_counts(DevCols c, DevPred pr, uint64_t *__restrict__ counts) {
     __shared__ uint32_t s_w[WAVES];
     TileIn<KIND, false> T;
-    tile_load_and_test<KIND, false>(c, pr, (uint64_t)blockIdx.x * EMIT_TILE, T);
+    tile_load_and_test<KIND, false, false>(c, pr, (uint64_t)blockIdx.x * EMIT_TILE, T);
     uint32_t cnt = 0;
 #pragma unroll
     for (int j = 0; j < EMIT_ITEMS; j++) cnt += (uint32_t)__popcll(__ballot(T.passes[j]));  // wave-uniform
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(1024) void k_scan_pieces(const uint64_t *__restrict
 }
 
 // Launch 3: tile t's matches go to records [*d_npoints_in + offsets[t], ...), in file order; tile 0 stores the new count.
-template <int KIND>
+template <int KIND, bool RGB>
 __global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, const uint64_t *__restrict__ offsets,
                                                        const uint64_t *__restrict__ d_npoints_in, uint64_t *__restrict__ d_npoints_out,
                                                        uint8_t *__restrict__ out31, uint32_t ntiles) {
@@ -242,12 +244,15 @@ __global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, co
     if (tile == 0 && threadIdx.x == 0) *d_npoints_out = base_count + offsets[ntiles];
     // launch 1 found no match in this tile: nothing of it is read a second time (a box that cuts a flight-line-ordered
     // file leaves most tiles empty; block-uniform, in front of the first load and the first barrier)
-    if (offsets[tile + 1] == before) return;
-    for (int t = threadIdx.x; t < STAGE_WORDS; t += BLOCK) s_stage[t] = 0;
+    const uint64_t in_tile = offsets[tile + 1] - before;
+    if (in_tile == 0) return;
+    // the image a flush assembles is [pad, pad + 31 * matches of the flush): nothing behind the tile's matches is ever OR-ed
+    const uint32_t stage_words = (uint32_t)min((uint64_t)STAGE_WORDS, (16 + 31 * in_tile) / 4 + 10);
+    for (uint32_t t = threadIdx.x; t < stage_words; t += BLOCK) s_stage[t] = 0;
     {
         const uint64_t base = (uint64_t)tile * EMIT_TILE;
         TileIn<KIND, true> T;
-        tile_load_and_test<KIND, true>(c, pr, base, T);
+        tile_load_and_test<KIND, true, RGB>(c, pr, base, T);
         RawPoint (&rps)[EMIT_ITEMS] = T.rps;
         bool (&passes)[EMIT_ITEMS] = T.passes;
         uint32_t (&attr_cls)[EMIT_ITEMS] = T.attr_cls, (&attr_rg)[EMIT_ITEMS] = T.attr_rg, (&attr_b)[EMIT_ITEMS] = T.attr_b;
@@ -365,9 +370,15 @@ int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pre
     hipLaunchKernelGGL(k_scan_piece_sums, dim3((unsigned)npieces), dim3(1024), 0, s, counts, (uint32_t)ntiles, pieces);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, pieces, (uint32_t)npieces);
     hipLaunchKernelGGL(k_scan_pieces, dim3((unsigned)npieces), dim3(1024), 0, s, counts, (uint32_t)ntiles, pieces, offsets);
-    if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_emit_points<PCQ_PRED_BOUNDS>, g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles);
-    else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_emit_points<PCQ_PRED_CLASS>, g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles);
-    else hipLaunchKernelGGL(k_emit_points<PCQ_PRED_BOUNDS_F64>, g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles);
+#define PCQ_EMIT(KIND)                                                                                                                                   \
+    do {                                                                                                                                                 \
+        if (cols.rgb) hipLaunchKernelGGL((k_emit_points<KIND, true>), g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles); \
+        else hipLaunchKernelGGL((k_emit_points<KIND, false>), g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles);  \
+    } while (0)
+    if (pred.kind == PCQ_PRED_BOUNDS) PCQ_EMIT(PCQ_PRED_BOUNDS);
+    else if (pred.kind == PCQ_PRED_CLASS) PCQ_EMIT(PCQ_PRED_CLASS);
+    else PCQ_EMIT(PCQ_PRED_BOUNDS_F64);
+#undef PCQ_EMIT
     PCQ_HIP(hipGetLastError());
     return PCQ_OK;
 }

@@ -189,6 +189,47 @@ def test_buffer_collector_dev_matches_oracle(oracle, gpu_ctx, fmt, n):
         f.free()
 
 
+@pytest.mark.parametrize("fmt", [1, 2])
+@pytest.mark.parametrize("n", [2048 * 5, 50_021])
+def test_buffer_collector_skips_tiles_without_a_match(oracle, gpu_ctx, fmt, n):
+    """A file whose points are sorted along x, cut by boxes in x: the emit does not read a 2048-point tile again in which the
+    count pass found nothing — empty tiles in front, behind and between, tiles with one match, a box that matches nothing at
+    all, and a second scan appended behind the first (record base not a multiple of 16).  Same image for the oracle."""
+    spec = small_spec(777 + n + fmt, n, fmt=fmt)
+    image = oracle.synth_image(spec, transposed=True).copy()
+    hdr = oracle.parse_header(image[:400].tobytes())
+    otp = hdr.offset_to_point_data
+    pos = image[otp:otp + 12 * n].view(np.int32).reshape(n, 3)
+    pos[:] = pos[np.argsort(pos[:, 0], kind="stable")]
+    xs = pos[:, 0].astype(np.float64) * 0.01
+    f = DevFile(gpu_ctx, image, hdr)
+    try:
+        boxes = [((xs[n // 3], -60.0, -20.0), (xs[n // 3 + 2500], 60.0, 20.0)),      # a run in the middle
+                 ((xs[0], -60.0, -20.0), (xs[10], 60.0, 20.0)),                     # the first tile only
+                 ((xs[n - 1], -60.0, -20.0), (60.0, 60.0, 20.0)),                   # the last point(s) only
+                 ((xs[2048 * 2], -60.0, -20.0), (xs[2048 * 3 - 1], 60.0, 20.0)),    # one whole tile (ties at its ends permitting)
+                 ((xs[5000], 49.999, 9.9999), (xs[5001], 50.0, 10.0)),              # nothing
+                 ((-60.0, -0.5, -20.0), (60.0, 0.5, 20.0))]                         # a slab across x: a few matches in every tile
+        ob, gb = oracle.buffer_collector(), gpu_ctx.buffer_collector()
+        for bmin, bmax in boxes:
+            one_o, one_g = oracle.buffer_collector(), gpu_ctx.buffer_collector()
+            lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+            for o, g in ((one_o, one_g), (ob, gb)):
+                assert oracle.search_last_bounds(image, bmin, bmax, o) == 0
+                if oracle.aabb_intersects(list(hdr.min), list(hdr.max), bmin, bmax):  # (the column scan has no header early-out)
+                    gpu_ctx.scan_dev(f.columns(True), pkg.Predicate.bounds(lmin, lmax), g)
+            assert one_g.point_count() == one_o.point_count(), (bmin, bmax)
+            assert one_g.points().tobytes() == one_o.points().tobytes()
+            one_o.free()
+            one_g.free()
+        assert gb.point_count() == ob.point_count() > 0
+        assert gb.points().tobytes() == ob.points().tobytes()
+        ob.free()
+        gb.free()
+    finally:
+        f.free()
+
+
 @pytest.mark.parametrize("n,cell", [(1, 1.0), (5000, 2.5), (200_003, 0.7), (200_003, 10.0)])
 def test_grid_collector_dev_matches_oracle(oracle, gpu_ctx, n, cell):
     spec = small_spec(31337 + n, n, fmt=2)

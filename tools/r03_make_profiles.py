@@ -104,7 +104,8 @@ if counters("random", 100):
 # emit
 if os.path.exists(f"{O}/emit_probe_ca13_XL.log"):
     L = [f"# round 3 (git {head}): buffer collector (stable emit of 31-byte records) on one 163 M-point ca13 file, tools/emit_probe.py under",
-         "# rocprofv3 --kernel-trace --stats (unchanged kernels: scan_generic.hip was not touched this round).", ""]
+         "# rocprofv3 --kernel-trace --stats (tools/r03_emit_tiles.sh).  k_emit_points<KIND, RGB>: the colourless form no longer issues the three",
+         "# masked colour loads per point, and a tile without a match returns before its first load (r03_emit_tiles.log).", ""]
     for q in ("ca13_XL", "ca13_S"):
         L.append(f"== {q} ==")
         L += ["  " + l.strip() for l in open(f"{O}/emit_probe_{q}.log") if "matches" in l]
@@ -126,6 +127,14 @@ if os.path.exists(f"{O}/experiments/product.txt"):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "manual", "format_experiments.py"), f"{O}/experiments"], capture_output=True, text=True)
     if r.returncode == 0:
         open(f"{P}/r03_query_experiments.txt", "w").write(r.stdout)
+
+if os.path.exists(f"{O}/emit_tiles.log"):
+    L = [f"# round 3 (git {head}): buffer collector on one 163 M-point ca13 file, boxes that keep 100 % / 10 % / 1 % of the file's x range (FRAC), the file in",
+         "# generator order (SORTED=0: every 2048-point tile holds a few matches) and sorted along x (SORTED=1: the matches are one run of the file, the",
+         "# emit skips every other tile); tools/emit_probe.py through tools/r03_emit_tiles.sh.  The kernel lines at the end: SORTED=1 FRAC=0.1 under",
+         "# rocprofv3 --kernel-trace --stats.  GB/s = algorithmic bytes (13 B read per point + 31 B written per match) / wall time.", ""]
+    L += [l.rstrip() for l in open(f"{O}/emit_tiles.log") if "amdgpu.ids" not in l]
+    open(f"{P}/r03_emit_tiles.log", "w").write("\n".join(L) + "\n")
 
 # the K1 line, from the committed summary
 ks = f"{P}/r03_bench_n1_kernel_stats.csv"
