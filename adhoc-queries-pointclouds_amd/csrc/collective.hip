@@ -118,13 +118,21 @@ void join_prepare() {
     std::lock_guard<std::mutex> lk(g_prepare_mu);
     if (g_prepare.joinable()) g_prepare.join();
 }
+// A prepare that no all-reduce ever waited for (the query failed before its merge, or the all-reduce refused its arguments)
+// must not reach the end of the process as a joinable std::thread: that is std::terminate.  Declared behind g_prepare, so
+// destroyed in front of it.
+struct PrepareJoiner {
+    ~PrepareJoiner() { join_prepare(); }
+} g_prepare_joiner;
 
 }  // namespace
 
-// Starts building the communicator for `devices` on a helper thread and returns: ncclCommInitAll takes from tens of
-// milliseconds to more than the whole query on eight GPUs, and nothing in it depends on the scans — the `query` CLI calls
-// this when it knows its device list, the scans run meanwhile, and pcq_allreduce_sum_u64 finds the communicator ready (or
-// waits for it).  Errors surface in the all-reduce, which then builds (and fails) synchronously.
+// Starts building the communicator for `devices` on a helper thread and returns; pcq_allreduce_sum_u64 finds the communicator
+// ready (or waits for it).  What this hides and what it does not (measured, profiles/r03_rccl_cost.log): ncclCommInitAll
+// (0.64 s on one device) overlaps the caller's scans; LOADING librccl (1.0-5.0 s: it registers its code objects with the HIP
+// runtime) does not — while it runs, context creation and launches on the other threads wait for the runtime's lock.  A
+// process that already carries RCCL (PyTorch) pays neither.  Errors surface in the all-reduce, which then builds (and
+// fails) synchronously.
 extern "C" int pcq_allreduce_prepare(const int *devices, int n) {
     if (!devices || n < 1) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_prepare: bad arguments");
     std::vector<int> devs(devices, devices + n);
@@ -143,6 +151,7 @@ extern "C" int pcq_allreduce_prepare(const int *devices, int n) {
 }
 
 extern "C" int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, const uint64_t *const *send, uint64_t *const *recv, int n) {
+    join_prepare();  // on every path: whatever this call returns, no helper thread is left behind it
     if (!ctxs || !send || !recv || n < 1) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: bad arguments");
     for (int i = 0; i < n; i++)
         if (!ctxs[i] || !send[i] || !recv[i]) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: null entry %d", i);
@@ -160,7 +169,6 @@ extern "C" int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, const uint64_t *const
         return PCQ_OK;
     }
     DeviceGuard restore(ctxs[0]->device);  // the calls below move the thread from device to device; put it back at the end
-    join_prepare();
     std::lock_guard<std::mutex> lk(g_mu);
     std::vector<int> devs(n);
     for (int i = 0; i < n; i++) devs[i] = ctxs[i]->device;

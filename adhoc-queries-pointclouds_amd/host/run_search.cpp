@@ -308,17 +308,32 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
     std::vector<double> file_ms(nfiles, 0.0);
     std::atomic<size_t> next{0};
     std::vector<int> devices = opt.devices.empty() ? std::vector<int>{0} : opt.devices;
+    // tests: "0,0" = two device SLOTS on one physical GPU — each with its own workers, contexts and counter block, merged like
+    // two GPUs (the tests have one GPU; a communicator over a repeated device is refused by RCCL, which is the failure the
+    // fallback exists for)
+    if (const char *list = getenv("PCQ_TEST_DEVICE_SLOTS")) {
+        devices.clear();
+        for (const char *p = list; *p;) {
+            char *end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            devices.push_back((int)v);
+            p = *end == ',' ? end + 1 : end;
+        }
+        if (devices.empty()) devices.push_back(0);
+    }
     const int tpd = opt.threads_per_device < 1 ? 1 : opt.threads_per_device;
     size_t nthreads = devices.size() * (size_t)tpd;
     if (nthreads > work.size()) nthreads = work.size();  // README.md:12
     const bool counting = !opt.collectors_yield_points;
-    // Several GPUs, count query: how are the per-GPU counts merged?  main.rs:164-180 is a sum; across GPUs it is ONE all-reduce of
-    // a u64 — or, in this process that holds every context, N eight-byte reads and a host loop.  RCCL costs what it costs to
-    // start: measured at ONE rank (tools/r03_rccl_cost.sh) dlopen of librccl.so 1.2-4.8 s and ncclCommInitAll 0.6 s, for a
-    // query that scans 16 files in 0.12 s.  So the all-reduce is the merge when the scans are long enough to hide that start
-    // (estimated from the planned bytes at the measured PCIe rate; the communicator is then built on a helper thread while
-    // the files are scanned), or when PCQ_MERGE=rccl says so; otherwise — and whenever the collective fails — the exact
-    // per-GPU counts are summed on the host.  (One process per GPU, as in bench.py: the all-reduce, through the process group.)
+    // Several GPUs, count query: how are the per-GPU counts merged?  main.rs:164-180 is a sum.  This process holds every context,
+    // so the sum is N eight-byte reads and a host loop (< 1 ms).  The RCCL all-reduce of the same u64 (pcq_allreduce_sum_u64:
+    // what a one-process-per-GPU integration calls, as bench.py does through its process group) costs a process that does
+    // not carry RCCL yet 1.0-5.0 s to load librccl and 0.6 s for ncclCommInitAll — measured at ONE rank, tools/r03_rccl_cost.sh
+    // — and the load stalls context creation and launches on every other thread meanwhile, helper thread or not (a 6 ms file
+    // took 1.0 s next to it).  The whole 16-file query scans for 0.12 s.  So: host sum, unless PCQ_MERGE=rccl asks for the
+    // collective (then the communicator is built on a helper thread while the files are scanned); and whenever the
+    // collective fails, the exact per-GPU counts are summed on the host anyway.
     bool merge_rccl = false;
     if (counting && !work.empty()) {
         const char *policy = getenv("PCQ_MERGE");
@@ -326,7 +341,7 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         for (size_t w : work)
             if (plans[w]) planned_bytes += (double)plans[w]->cols.n * (plans[w]->pred.kind == PCQ_PRED_CLASS ? 1.0 : 12.0);
         const double scan_seconds = planned_bytes / (40e9 * (double)devices.size());
-        merge_rccl = getenv("PCQ_TEST_ALLREDUCE_FAIL") != nullptr || (policy ? !strcmp(policy, "rccl") : (devices.size() > 1 && scan_seconds > 3.0));
+        merge_rccl = getenv("PCQ_TEST_ALLREDUCE_FAIL") != nullptr || (policy && !strcmp(policy, "rccl"));
         if (timing)
             fprintf(stderr, "[pcq] count merge: %s (estimated scan time %.2f s on %zu GPU(s))\n", merge_rccl ? "RCCL all-reduce" : devices.size() > 1 ? "host sum of the per-GPU counts" : "one GPU, its counter is the total",
                     scan_seconds, devices.size());

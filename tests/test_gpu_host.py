@@ -447,6 +447,32 @@ def test_cli_count_merge_survives_a_failing_allreduce(files, when):
         assert ("before the reduction" if when == "early" else "after the reduction") in err_p
 
 
+@pytest.mark.parametrize("merge", ["auto", "host", "rccl"])
+def test_cli_two_device_slots_merge_like_two_gpus(files, merge):
+    """The N > 1 paths of run_search_parallel on the one GPU the tests have: PCQ_TEST_DEVICE_SLOTS=0,0 gives two device slots
+    (own workers, own contexts, own two-word counter block each).  Count queries: the short query sums the two counter blocks on
+    the host (auto, host); PCQ_MERGE=rccl asks for the all-reduce, RCCL refuses a communicator over a repeated device — a real
+    failure of the real library, not an injected one — and the host sum answers with the warning.  Queries whose collectors
+    yield points merge per file and need no collective.  stdout is the oracle's in every case."""
+    d = os.path.dirname(files[0])
+    env = {"PCQ_TEST_DEVICE_SLOTS": "0,0", "PCQ_TIMING": "1"}
+    if merge != "auto":
+        env["PCQ_MERGE"] = merge
+    for query_args in (["--bounds", "0;-400;-100;200;0;100"], ["--class", "6"], ["--bounds", "0;-400;-100;200;0;100", "--density", "5"]):
+        args = ["-i", d, "--optimized", "--parallel"] + query_args
+        rc_p, body_p, _, err_p = _cli(QUERY, args + ["--threads-per-gpu", "2"], env=env)
+        rc_o, body_o, _, _ = _cli(ORACLE_CLI, args)
+        assert rc_p == rc_o == 0, err_p
+        assert sorted(body_p) == sorted(body_o)
+        assert err_p.count("context on device 0 ready") >= 2  # both slots worked
+        if "--density" in query_args:
+            assert "count merge" not in err_p
+        elif merge == "rccl":
+            assert "count merge: RCCL all-reduce" in err_p and "all-reduce of the per-GPU counts failed" in err_p and "summing on the host" in err_p
+        else:
+            assert "count merge: host sum of the per-GPU counts" in err_p and "warning" not in err_p
+
+
 def test_cli_more_files_than_descriptors(oracle, tmp_path):
     """run_search_parallel plans every file before the first worker starts; a plan keeps the header's values, not the open
     file (the reference opens inside the rayon task: at most one file per thread is open at a time).  1100 small LAST files

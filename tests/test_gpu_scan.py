@@ -589,6 +589,25 @@ def test_allreduce_single_rank_through_the_real_rccl_calls(gpu_ctx):
         gpu_ctx.free(d)
 
 
+def test_a_prepare_nobody_waited_for_does_not_end_the_process():
+    """pcq_allreduce_prepare starts a helper thread; a process that ends without the all-reduce (the query failed before its
+    merge, or the all-reduce refused its arguments before it joined) used to die in std::terminate on the joinable thread."""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import importlib, ctypes as C, sys\n"
+            "sys.path.insert(0, %r)\n"
+            "pkg = importlib.import_module('adhoc-queries-pointclouds_amd')\n"
+            "ctx = pkg.Context(0)\n"
+            "assert ctx.lib.pcq_allreduce_prepare((C.c_int * 2)(0, 0), 2) == 0\n"   # (a list RCCL refuses: the thread fails fast or slow)
+            "assert ctx.lib.pcq_allreduce_sum_u64(None, None, None, 0) != 0\n"       # refused before anything else
+            "assert ctx.lib.pcq_allreduce_prepare((C.c_int * 1)(0), 1) == 0\n"       # and one that nobody waits for
+            "print('done', flush=True)\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "done" in r.stdout, (r.returncode, r.stderr[-2000:])
+
+
 def test_allreduce_entry_point_single_rank(gpu_ctx):
     """pcq_allreduce_sum_u64 with one rank copies the value (the n > 1 RCCL path needs several GPUs)."""
     d = gpu_ctx.alloc(16)

@@ -12,8 +12,10 @@ for i, s in enumerate(specs.synth_ca13(points_per_file=2_000_000, files=4)):
 q = "adhoc-queries-pointclouds_amd/host/query"
 xl = "643431.76;3883547.565;-46194.145;736910.93;3977026.735;47285.025"
 # one GPU: the default merge (a device-to-device copy), then the all-reduce forced through the real RCCL calls at one rank
-for env in ({}, {"PCQ_MERGE": "rccl"}, {"PCQ_TEST_ALLREDUCE_FAIL": "late"}):
+# two device slots on the one GPU (PCQ_TEST_DEVICE_SLOTS): the N > 1 paths — host sum; then PCQ_MERGE=rccl, whose helper thread loads
+# librccl while the workers start (their contexts and first files wait for it) and whose communicator RCCL refuses (repeated device)
+for env in ({}, {"PCQ_MERGE": "rccl"}, {"PCQ_TEST_ALLREDUCE_FAIL": "late"}, {"PCQ_TEST_DEVICE_SLOTS": "0,0"}, {"PCQ_TEST_DEVICE_SLOTS": "0,0", "PCQ_MERGE": "rccl"}):
     for rep in range(2):
         r = subprocess.run([q, "-i", d, "--optimized", "--parallel", "--bounds", xl], capture_output=True, text=True, env=dict(os.environ, PCQ_TIMING="1", **env))
-        print(env, [l for l in r.stderr.splitlines() if "RCCL" in l or "rccl" in l or "count merge" in l or "all-reduce" in l or "merged" in l or "workers done" in l or "context on" in l], r.stdout.splitlines()[1:2])
+        print(env, [l for l in r.stderr.splitlines() if "RCCL" in l or "rccl" in l or "count merge" in l or "all-reduce" in l or "merged" in l or "workers done" in l or "context on" in l or "searched in" in l or "warning" in l], r.stdout.splitlines()[1:2])
 PY
