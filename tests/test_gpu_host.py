@@ -448,7 +448,7 @@ def test_cli_count_merge_survives_a_failing_allreduce(files, when):
 
 
 @pytest.mark.parametrize("merge", ["auto", "host", "rccl"])
-def test_cli_two_device_slots_merge_like_two_gpus(files, merge):
+def test_cli_two_device_slots_merge_like_two_gpus(files, merge, tmp_path):
     """The N > 1 paths of run_search_parallel on the one GPU the tests have: PCQ_TEST_DEVICE_SLOTS=0,0 gives two device slots
     (own workers, own contexts, own two-word counter block each).  Count queries: the short query sums the two counter blocks on
     the host (auto, host); PCQ_MERGE=rccl asks for the all-reduce, RCCL refuses a communicator over a repeated device — a real
@@ -471,6 +471,16 @@ def test_cli_two_device_slots_merge_like_two_gpus(files, merge):
             assert "count merge: RCCL all-reduce" in err_p and "all-reduce of the per-GPU counts failed" in err_p and "summing on the host" in err_p
         else:
             assert "count merge: host sum of the per-GPU counts" in err_p and "warning" not in err_p
+    if merge == "auto":  # -o: the files written from two slots are the files written from one, byte for byte
+        outs = []
+        for slots in ("0,0", "0"):
+            out = tmp_path / ("o" + str(len(slots)))
+            out.mkdir()
+            args = ["-i", d, "--optimized", "--parallel", "--bounds", "0;-400;-100;200;0;100", "-o", str(out), "--threads-per-gpu", "2"]
+            rc, body, _, err = _cli(QUERY, args, env={"PCQ_TEST_DEVICE_SLOTS": slots})
+            assert rc == 0, err
+            outs.append((sorted(body), {f: open(out / f, "rb").read() for f in sorted(os.listdir(out))}))
+        assert outs[0] == outs[1] and len(outs[0][1]) > 0
 
 
 def test_cli_more_files_than_descriptors(oracle, tmp_path):
