@@ -1,6 +1,8 @@
 // core.cpp — Status, AABB, LAS header parsing, mmap, per-thread GPU contexts.
 #include "pcq_host.hpp"
 
+#include <atomic>
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -163,16 +165,27 @@ Status MappedFile::open(const std::string &path) {
 
 // ---- per-thread contexts ------------------------------------------------------------------------------
 namespace {
+std::atomic<bool> g_process_is_ending{false};
 struct ThreadContexts {
     std::map<int, pcq_ctx *> by_device;
     ~ThreadContexts() {
+        if (g_process_is_ending.load()) return;  // the `query` binary: the process ends right behind the query (main.cpp)
         for (auto &kv : by_device) pcq_shutdown(kv.second);
     }
 };
 }  // namespace
 
-Status thread_context(int device, pcq_ctx **out) {
+void contexts_die_with_the_process(bool yes) { g_process_is_ending.store(yes); }
+
+namespace {
+ThreadContexts &this_threads_contexts() {
     static thread_local ThreadContexts tc;
+    return tc;
+}
+}  // namespace
+
+Status thread_context(int device, pcq_ctx **out) {
+    ThreadContexts &tc = this_threads_contexts();
     auto it = tc.by_device.find(device);
     if (it != tc.by_device.end()) {
         *out = it->second;

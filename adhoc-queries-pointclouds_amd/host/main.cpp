@@ -1,12 +1,29 @@
 // main.cpp — the `query` CLI: same flag surface and stdout contract as the reference's binary
 // (query/src/main.rs:191-319), with the per-file scans running on the GPU(s).
+#include <unistd.h>
+
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 
 #include "pcq_host.hpp"
 
 int main(int argc, char **argv) {
     setvbuf(stdout, nullptr, _IOLBF, 0);
-    return pcq::query_main(
+    // How the process ends (profiles/r03_cli_exit.log).  A `query` process ends with its query; what a normal return would still run
+    // — the workers releasing streams, events, pinned and device memory one by one (9 ms), then the exit handlers and static
+    // destructors of the HIP runtime (40 ms) — changes nothing anybody can observe: the answer is printed, the files are
+    // written and closed, and the kernel reclaims a process's GPU resources either way (at no measurable cost: 13.6 ms
+    // outside main() with or without the releases, 12 ms for a query that never woke the GPU).  PCQ_EXIT=full keeps the
+    // normal path; it is also what runs when something hooks the end of the process (a profiler or a sanitizer writes its
+    // report there), unless PCQ_EXIT=fast insists.
+    const char *mode = getenv("PCQ_EXIT");
+    const char *preload = getenv("LD_PRELOAD");
+    const bool hooked = getenv("HSA_TOOLS_LIB") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ASAN_OPTIONS") ||
+                        (preload && (strstr(preload, "rocprof") || strstr(preload, "roctracer") || strstr(preload, "san")));
+    const bool fast_exit = mode ? strcmp(mode, "fast") == 0 : !hooked;
+    pcq::contexts_die_with_the_process(fast_exit);
+    const int rc = pcq::query_main(
         argc, argv,
         [](const std::string &s) {
             fputs(s.c_str(), stdout);
@@ -16,4 +33,7 @@ int main(int argc, char **argv) {
             fputs(s.c_str(), stderr);
             fputc('\n', stderr);
         });
+    fflush(nullptr);
+    if (fast_exit) _exit(rc);
+    return rc;
 }

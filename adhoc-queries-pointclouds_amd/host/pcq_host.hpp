@@ -91,6 +91,10 @@ private:
 
 // One GPU context per (thread, device); created on first use, destroyed with the thread.
 Status thread_context(int device, pcq_ctx **out);
+// The `query` binary ends with its query: its threads then leave their contexts to the end of the process instead of releasing
+// streams, events, pinned and device memory one by one (main.cpp).  Off by default: a library user's threads release what
+// they created.
+void contexts_die_with_the_process(bool yes);
 
 // ---- collect_points.rs ------------------------------------------------------------------------
 // The per-match `collect_one(Point)` callback of the reference does not exist here: matches are

@@ -29,7 +29,7 @@ def run(exe, args, repeat=3, tag=None):
     best, out, times = None, None, []
     for _ in range(repeat):
         t0 = time.perf_counter()
-        r = subprocess.run([exe] + args, capture_output=True, text=True)
+        r = subprocess.run([exe] + args, capture_output=True, text=True, env=dict(os.environ, PCQ_EXIT=os.environ.get("PCQ_EXIT", "fast")))
         dt = time.perf_counter() - t0
         if r.returncode != 0:
             raise SystemExit(f"{exe} failed: {r.stderr}")
@@ -43,7 +43,7 @@ def run(exe, args, repeat=3, tag=None):
 
 def phases(exe, args):
     """One more run with PCQ_TIMING=1: the per-phase lines (plans, context ready, per file, merge) of the CLI's stderr."""
-    r = subprocess.run([exe] + args, capture_output=True, text=True, env=dict(os.environ, PCQ_TIMING="1"))
+    r = subprocess.run([exe] + args, capture_output=True, text=True, env=dict(os.environ, PCQ_TIMING="1", PCQ_EXIT=os.environ.get("PCQ_EXIT", "fast")))
     lines = [l for l in r.stderr.splitlines() if l.startswith("[pcq]") or l.startswith("pcq:")]
     files = [float(l.split(" searched in ")[1].split(" ms")[0]) for l in lines if " searched in " in l]
     keep = [l for l in lines if " searched in " not in l and "pool block" not in l]

@@ -483,6 +483,28 @@ def test_cli_two_device_slots_merge_like_two_gpus(files, merge, tmp_path):
         assert outs[0] == outs[1] and len(outs[0][1]) > 0
 
 
+def test_cli_fast_exit_changes_nothing_observable(files, tmp_path):
+    """The `query` binary leaves through _exit once its answer is flushed (PCQ_EXIT=fast; the default unless a profiler or a
+    sanitizer hooks the end of the process) instead of releasing its contexts and running the HIP runtime's teardown: same exit
+    code, same stdout, same stderr, same files as the normal return path (PCQ_EXIT=full) — also for a query that fails."""
+    d = os.path.dirname(files[0])
+    seen = {}
+    for mode in ("fast", "full"):
+        out = tmp_path / mode
+        out.mkdir()
+        runs = []
+        for args in (["-i", d, "--optimized", "--parallel", "--bounds", "0;-400;-100;200;0;100"],
+                     ["-i", d, "--optimized", "--bounds", "0;-400;-100;200;0;100", "--density", "5"],
+                     ["-i", d, "--optimized", "--parallel", "--class", "6", "-o", str(out)],
+                     ["-i", d, "--optimized", "--parallel", "--bounds", "not;a;box"],
+                     ["-i", str(tmp_path / "missing"), "--optimized", "--parallel", "--class", "6"]):
+            rc, body, _, err = _cli(QUERY, args, env={"PCQ_EXIT": mode})
+            runs.append((rc, sorted(body), err.replace(str(out), "OUT")))
+        seen[mode] = (runs, {f: open(out / f, "rb").read() for f in sorted(os.listdir(out))})
+    assert seen["fast"] == seen["full"]
+    assert seen["fast"][0][0][0] == 0 and seen["fast"][0][3][0] != 0 and len(seen["fast"][1]) > 0
+
+
 def test_cli_more_files_than_descriptors(oracle, tmp_path):
     """run_search_parallel plans every file before the first worker starts; a plan keeps the header's values, not the open
     file (the reference opens inside the rayon task: at most one file per thread is open at a time).  1100 small LAST files
