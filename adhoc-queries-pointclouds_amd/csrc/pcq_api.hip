@@ -865,8 +865,7 @@ static int ensure_stage(pcq_ctx *ctx, size_t bytes) {
                         sched_setaffinity(0, sizeof ctx->node_cpus, &ctx->node_cpus) == 0;
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; i++) {
-        e = hipHostMalloc((void **)&ctx->h_stage[i], bytes, hipHostMallocDefault);
-        if (e == hipSuccess) memset(ctx->h_stage[i], 0, bytes);  // first touch, should the runtime not have done it
+        e = hipHostMalloc((void **)&ctx->h_stage[i], bytes, hipHostMallocDefault);  // (pinned = resident: the pages exist when this returns)
         if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stage[i], bytes);
     }
     if (rebind) (void)sched_setaffinity(0, sizeof saved, &saved);
