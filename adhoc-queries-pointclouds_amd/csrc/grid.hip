@@ -182,8 +182,9 @@ __device__ __forceinline__ double centre_dist(const DevGrid &g, const uint64_t (
     return (a + b) + c;
 }
 
-// The same cell, the short way.  Every pass over the matches is bound by its vector instructions (a point costs ~125 of
-// them through cell_of + the 64-bit hash), so the common case is cut down to what it needs:
+// The same cell, the short way.  With cell_of + the murmur hash a point cost ~125 vector instructions per pass and the passes
+// were bound by them; the common case is cut down to what it needs (today the exact f64 arithmetic is 19-47 of a pass's
+// 115-280 vector instructions per 64 points and vector issue is 17-31 % busy: profiles/r03_grid_valu_mix.txt):
 //   q = (p - bmin) * k, k = RN(dims / extent) computed once on the host — one multiply instead of two.  q is within
 //   (1 + 2^-53)^3 of the exact quotient num / extent the reference rounds (num = RN((p - bmin) * dims)), and RN of that is
 //   another half ulp away: |q - RN(num / extent)| < 4.01 * 2^-53 * q.  With q < qmax <= 2^31 and both q - floor(q) and
