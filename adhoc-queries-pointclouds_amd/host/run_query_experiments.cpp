@@ -12,6 +12,11 @@
 //     is warm-cache runs (the GPU box has no privileged cache control);
 //   * --extensions las,last,lazer restricts the formats (the reference always runs las, laz, last, lazer;
 //     `laz` needs the arithmetic decoder, which is outside this repository's scope);
+//   * the reference's `sync; purge` in front of EVERY run (:8-27, :32, :80) also means that no query process ever starts right
+//     behind the previous one (macOS `purge` takes seconds).  That matters to a GPU process and to nothing else: started right
+//     behind another GPU process it waits 0.1-0.2 s in hsa_init for the driver's teardown of its predecessor
+//     (profiles/r03_hip_startup_env.log, r03_teardown.log).  --settle-ms N (default 1000) sleeps that long before every run,
+//     outside the timed region, as the stand-in for the time `sync; purge` take; --settle-ms 0 runs back to back;
 //   * --runs N, --query PATH, --extra "flags" (e.g. --gpus) are additions.
 #include <dirent.h>
 #include <fcntl.h>
@@ -118,7 +123,7 @@ void report(const std::string &name, std::vector<double> t) {
 int main(int argc, char **argv) {
     std::string in_path, query_exe, extra;
     std::vector<std::string> extensions = {"las", "laz", "last", "lazer"};  // :109, :297
-    int experiment = 0, runs = 5;
+    int experiment = 0, runs = 5, settle_ms = 1000;
     bool cold = false;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
@@ -129,13 +134,14 @@ int main(int argc, char **argv) {
         else if (a == "--query") query_exe = val();
         else if (a == "--extra") extra = val();
         else if (a == "--cold") cold = true;
+        else if (a == "--settle-ms") settle_ms = atoi(val().c_str());
         else if (a == "--extensions") {
             extensions.clear();
             std::stringstream ss(val());
             for (std::string e; std::getline(ss, e, ',');)
                 if (!e.empty()) extensions.push_back(e);
         } else {
-            fprintf(stderr, "USAGE: run_query_experiments -i <DIRECTORY> -e <EXPERIMENT_ID> [--runs N] [--extensions a,b] [--cold] [--query PATH] [--extra \"flags\"]\n");
+            fprintf(stderr, "USAGE: run_query_experiments -i <DIRECTORY> -e <EXPERIMENT_ID> [--runs N] [--extensions a,b] [--cold] [--settle-ms N] [--query PATH] [--extra \"flags\"]\n");
             return a == "-h" || a == "--help" ? 0 : 2;
         }
     }
@@ -184,6 +190,7 @@ int main(int argc, char **argv) {
         std::vector<double> times;
         for (int r = 0; r < runs; r++) {
             if (cold) evict(dir);
+            if (settle_ms > 0) usleep((useconds_t)settle_ms * 1000u);  // the reference: `sync; purge` here (:32, :80)
             std::vector<std::string> args = {"-i", dir};
             args.insert(args.end(), qargs.begin(), qargs.end());
             args.push_back("--optimized");

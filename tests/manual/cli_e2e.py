@@ -23,11 +23,14 @@ ORACLE = os.path.join(ROOT, "oracle", "query_oracle")
 
 
 ALL_TIMES = {}
+SETTLE = 1.0  # seconds in front of every run: a GPU process started right behind another one waits 0.1-0.2 s in hsa_init for the
+              # driver's teardown of its predecessor (profiles/r03_hip_startup_env.log); the reference's protocol has `sync; purge` here
 
 
 def run(exe, args, repeat=3, tag=None):
     best, out, times = None, None, []
     for _ in range(repeat):
+        time.sleep(SETTLE)
         t0 = time.perf_counter()
         r = subprocess.run([exe] + args, capture_output=True, text=True, env=dict(os.environ, PCQ_EXIT=os.environ.get("PCQ_EXIT", "fast")))
         dt = time.perf_counter() - t0
@@ -43,6 +46,7 @@ def run(exe, args, repeat=3, tag=None):
 
 def phases(exe, args):
     """One more run with PCQ_TIMING=1: the per-phase lines (plans, context ready, per file, merge) of the CLI's stderr."""
+    time.sleep(SETTLE)
     r = subprocess.run([exe] + args, capture_output=True, text=True, env=dict(os.environ, PCQ_TIMING="1", PCQ_EXIT=os.environ.get("PCQ_EXIT", "fast")))
     lines = [l for l in r.stderr.splitlines() if l.startswith("[pcq]") or l.startswith("pcq:")]
     files = [float(l.split(" searched in ")[1].split(" ms")[0]) for l in lines if " searched in " in l]
@@ -58,7 +62,10 @@ def main():
     ap.add_argument("--files", type=int, default=16)
     ap.add_argument("--points", type=int, default=20_000_000)
     ap.add_argument("--threads-per-gpu", type=int, default=1)
+    ap.add_argument("--settle", type=float, default=1.0, help="seconds in front of every run (0: back to back)")
     args = ap.parse_args()
+    global SETTLE
+    SETTLE = args.settle
     o = _oracle.Oracle()
     d = tempfile.mkdtemp(prefix="pcq_e2e_", dir="/tmp")
     ss = specs.synth_ca13(points_per_file=args.points, files=args.files)

@@ -17,7 +17,9 @@ def read(name):
 
 prod, orac = read("product.txt"), read("oracle.txt")
 print("# run_query_experiments (paper protocol: one `query --optimized --parallel` process per run, wall clock of the")
-print("# whole process incl. HIP start-up, 5 runs, warm page cache) on scaled-down synthetic datasets:")
+print("# whole process incl. HIP start-up, 5 runs, warm page cache; one second in front of every run where the reference has `sync; purge`")
+print("# — started right behind another GPU process a query waits 0.1-0.2 s in hsa_init: r03_query_experiments_back_to_back.txt is that case) on")
+print("# scaled-down synthetic datasets:")
 print("# " + " | ".join(l.strip() for l in open(os.path.join(d, "datasets.txt")) if l.strip()))
 print("# product = this repository's CLI on one MI355X; oracle = single-threaded C restatement of the reference (1 run)")
 print(f"{'experiment':<30} {'product mean':>12} {'median':>8} {'stddev':>8} {'oracle':>10} {'oracle/product':>14}")

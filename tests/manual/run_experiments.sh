@@ -13,9 +13,9 @@ DRV=adhoc-queries-pointclouds_amd/host/run_query_experiments
 export PCQ_EXIT=${PCQ_EXIT:-fast}
 for e in 1 2 3 4 5; do
   echo "== experiment $e (product, 5 runs, warm cache)" | tee -a "$OUT/product.txt"
-  $DRV -i "$ROOT" -e $e --extensions las,last,lazer 2>>"$OUT/product.err" | tee -a "$OUT/product.txt"
+  $DRV -i "$ROOT" -e $e --extensions las,last,lazer --settle-ms ${SETTLE_MS:-1000} 2>>"$OUT/product.err" | tee -a "$OUT/product.txt"
 done
 for e in 1 2 3 4 5; do
   echo "== experiment $e (oracle CLI: single-threaded restatement of the reference, 1 run)" | tee -a "$OUT/oracle.txt"
-  $DRV -i "$ROOT" -e $e --extensions las,last,lazer --runs 1 --query oracle/query_oracle 2>>"$OUT/oracle.err" | tee -a "$OUT/oracle.txt"
+  $DRV -i "$ROOT" -e $e --extensions las,last,lazer --runs 1 --settle-ms 0 --query oracle/query_oracle 2>>"$OUT/oracle.err" | tee -a "$OUT/oracle.txt"
 done

@@ -264,7 +264,8 @@ def test_run_query_experiments_driver_protocol(oracle, tmp_path):
     q = os.path.join(ROOT, "oracle", "query_oracle")
 
     def run(exp, *extra):
-        r = subprocess.run([drv, "-i", str(root), "-e", str(exp), "--extensions", "las,last", "--query", q, *extra],
+        settle = [] if "--settle-ms" in extra else ["--settle-ms", "0"]  # (default: 1 s in front of every run, for `sync; purge`)
+        r = subprocess.run([drv, "-i", str(root), "-e", str(exp), "--extensions", "las,last", "--query", q, *settle, *extra],
                            capture_output=True, text=True)
         return r.returncode, r.stdout.splitlines(), r.stderr
 
@@ -282,9 +283,14 @@ def test_run_query_experiments_driver_protocol(oracle, tmp_path):
     assert all(l.endswith(";0") for l in lines)  # one run: stddev 0
     rc, lines, err = run(4, "--runs", "1", "--cold")
     assert rc == 0 and len(lines) == 4
+    import time
+    t0 = time.perf_counter()
+    rc, lines, err = run(5, "--runs", "2", "--settle-ms", "150")  # the pause stands outside the timed region
+    assert rc == 0 and len(lines) == 4 and time.perf_counter() - t0 >= 8 * 0.15
+    assert all(float(l.split(";")[1]) < 0.15 for l in lines)
     assert run(6)[0] == 1 and "Invalid experiment ID 6" in run(6)[2]
     # a format the query cannot search fails the run, like the reference's `?` on the child's exit status
-    rc, lines, err = subprocess.run([drv, "-i", str(root), "-e", "1", "--query", q, "--runs", "1"], capture_output=True, text=True).returncode, None, None
+    rc, lines, err = subprocess.run([drv, "-i", str(root), "-e", "1", "--query", q, "--runs", "1", "--settle-ms", "0"], capture_output=True, text=True).returncode, None, None
     assert rc == 1
 
 
