@@ -261,10 +261,13 @@ struct FileStat {  // filled by the drivers when RunOptions::stats is set (extra
 };
 struct RunOptions {
     std::vector<int> devices = {0};  // GPUs to use; files are the independent units (main.rs:153-161)
-    // host threads feeding each GPU in --parallel mode.  One is the measured optimum: the library splits
-    // the staging copy over its own helper threads and reaches the PCIe rate from a single caller, while a
-    // second context on the same GPU costs another ~100-200 ms of HIP start-up (profiles/r01_cli_fixed_cost.log)
-    int threads_per_device = 1;
+    // host threads feeding each GPU in --parallel mode; 0 = chosen by the driver.  One is the measured optimum for count
+    // queries and for large files: the library splits the staging copy over its own helper threads and reaches the PCIe rate
+    // from a single caller, while a second context on the same GPU costs another 20-40 ms of start-up.  A collector that
+    // yields points ends every file on a synchronisation (a grid folds to its winners), which drains a single thread's
+    // pipeline for ~1 ms per file: with many small files a second thread per GPU fills those gaps (64 files x 2 M points,
+    // --density: 229 -> 200 ms; 16 x 20 M: no difference; 4 files: 20 ms worse — profiles/r03_density_threads.log).
+    int threads_per_device = 0;
     // false: the factory makes count collectors (points() is None, main.rs:171-179) — the parallel driver then gives
     // every GPU one device counter and merges the counters with one all-reduce
     bool collectors_yield_points = true;
