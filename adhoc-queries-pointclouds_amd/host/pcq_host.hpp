@@ -271,6 +271,8 @@ struct RunOptions {
     // false: the factory makes count collectors (points() is None, main.rs:171-179) — the parallel driver then gives
     // every GPU one device counter and merges the counters with one all-reduce
     bool collectors_yield_points = true;
+    // the factory makes grid collectors (--density): every file ends on a fold, i.e. on a synchronisation (see threads_per_device)
+    bool collectors_fold_per_file = false;
     std::vector<FileStat> *stats = nullptr;
 };
 // stdout lines go through `print` (so tests can capture them).

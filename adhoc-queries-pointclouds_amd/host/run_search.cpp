@@ -328,7 +328,7 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         for (size_t w : work)
             if (plans[w]) planned_points += plans[w]->cols.n;
         const size_t per_device = work.size() / devices.size();
-        tpd = opt.collectors_yield_points && per_device >= 32 && planned_points / (work.size() ? work.size() : 1) < 8000000ull ? 2 : 1;
+        tpd = opt.collectors_fold_per_file && per_device >= 32 && planned_points / (work.size() ? work.size() : 1) < 8000000ull ? 2 : 1;
     }
     size_t nthreads = devices.size() * (size_t)tpd;
     if (nthreads > work.size()) nthreads = work.size();  // README.md:12
@@ -513,7 +513,7 @@ int query_main(int argc, const char *const *argv, const PrintFn &out, const Prin
                 "OPTIONS:\n        --bounds <BOUNDS>    \"minX;minY;minZ;maxX;maxY;maxZ\"\n        --class <CLASS>      object class (u8)\n"
                 "        --density <DENSITY>  maximum density (grid cell size)\n    -i, --input <FILE>       file or directory\n"
                 "    -o, --output <OUTPUT>    output directory\n        --gpus <N>           (extra) number of GPUs to shard files over\n"
-                "        --device <D>         (extra) first GPU to use\n        --threads-per-gpu <T> (extra) host threads feeding each GPU (default: 1, or 2 for many small files with --density / -o)\n"
+                "        --device <D>         (extra) first GPU to use\n        --threads-per-gpu <T> (extra) host threads feeding each GPU (default: 1; 2 for many small files with --density)\n"
                 "        --stats-json <PATH>  (extra) write per-file timings as JSON");
             return 0;
         } else {
@@ -628,6 +628,7 @@ int query_main(int argc, const char *const *argv, const PrintFn &out, const Prin
         }
         const double cell = *maybe_density;
         factory = [gb, cell](pcq_ctx *ctx, uint64_t *, std::unique_ptr<ResultCollector> *o) { return GridSampledCollector::create(ctx, gb, cell, o); };
+        opt.collectors_fold_per_file = true;
     } else if (output) {
         factory = [](pcq_ctx *ctx, uint64_t *, std::unique_ptr<ResultCollector> *o) { return BufferCollector::create(ctx, o); };
     } else {
