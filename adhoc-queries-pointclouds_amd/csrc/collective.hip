@@ -13,7 +13,6 @@
 #include <chrono>
 #include <cstdlib>
 #include <mutex>
-#include <thread>
 #include <vector>
 
 #include "pcq_internal.h"
@@ -111,47 +110,30 @@ int ensure_comm(const std::vector<int> &devs) {
     return PCQ_OK;
 }
 
-// a communicator being built on a helper thread (pcq_allreduce_prepare): joined by whoever needs the lock next
-std::thread g_prepare;
-std::mutex g_prepare_mu;
-void join_prepare() {
-    std::lock_guard<std::mutex> lk(g_prepare_mu);
-    if (g_prepare.joinable()) g_prepare.join();
-}
-// A prepare that no all-reduce ever waited for (the query failed before its merge, or the all-reduce refused its arguments)
-// must not reach the end of the process as a joinable std::thread: that is std::terminate.  Declared behind g_prepare, so
-// destroyed in front of it.
-struct PrepareJoiner {
-    ~PrepareJoiner() { join_prepare(); }
-} g_prepare_joiner;
-
 }  // namespace
 
-// Starts building the communicator for `devices` on a helper thread and returns; pcq_allreduce_sum_u64 finds the communicator
-// ready (or waits for it).  What this hides and what it does not (measured, profiles/r03_rccl_cost.log): ncclCommInitAll
-// (0.64 s on one device) overlaps the caller's scans; LOADING librccl (1.0-5.0 s: it registers its code objects with the HIP
-// runtime) does not — while it runs, context creation and launches on the other threads wait for the runtime's lock.  A
-// process that already carries RCCL (PyTorch) pays neither.  Errors surface in the all-reduce, which then builds (and
-// fails) synchronously.
+// Builds the communicator for `devices` now, so that the all-reduce finds it ready: loading librccl (1.0-5.0 s in a process that
+// does not carry it yet: it registers its code objects with the HIP runtime, and context creation and launches on other
+// threads wait for the runtime's lock meanwhile) and ncclCommInitAll (0.64 s on one device) — profiles/r03_rccl_cost.log.
+// Synchronous and thread-safe: a caller that wants ncclCommInitAll beside its scans calls this from a thread of its own and
+// joins it before the all-reduce (host/run_search.cpp does).  The library itself starts no thread: round 3 had the helper
+// thread in here, and a process that ended while it was still inside RCCL died in the runtime's exit handlers — or, once
+// an exit handler waited for it, hung in them.
 extern "C" int pcq_allreduce_prepare(const int *devices, int n) {
     if (!devices || n < 1) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_prepare: bad arguments");
     std::vector<int> devs(devices, devices + n);
-    join_prepare();
-    std::lock_guard<std::mutex> lk(g_prepare_mu);
-    g_prepare = std::thread([devs]() {
-        int prev = -1;
-        (void)hipGetDevice(&prev);
-        {
-            std::lock_guard<std::mutex> g(g_mu);
-            (void)ensure_comm(devs);  // (a failure is reported by the all-reduce that finds no communicator)
-        }
-        if (prev >= 0) (void)hipSetDevice(prev);
-    });
-    return PCQ_OK;
+    int prev = -1;
+    (void)hipGetDevice(&prev);
+    int rc;
+    {
+        std::lock_guard<std::mutex> g(g_mu);
+        rc = ensure_comm(devs);
+    }
+    if (prev >= 0) (void)hipSetDevice(prev);
+    return rc;
 }
 
 extern "C" int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, const uint64_t *const *send, uint64_t *const *recv, int n) {
-    join_prepare();  // on every path: whatever this call returns, no helper thread is left behind it
     if (!ctxs || !send || !recv || n < 1) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: bad arguments");
     for (int i = 0; i < n; i++)
         if (!ctxs[i] || !send[i] || !recv[i]) return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: null entry %d", i);

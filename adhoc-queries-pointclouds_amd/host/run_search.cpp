@@ -337,11 +337,18 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
     // so the sum is N eight-byte reads and a host loop (< 1 ms).  The RCCL all-reduce of the same u64 (pcq_allreduce_sum_u64:
     // what a one-process-per-GPU integration calls, as bench.py does through its process group) costs a process that does
     // not carry RCCL yet 1.0-5.0 s to load librccl and 0.6 s for ncclCommInitAll — measured at ONE rank, tools/r03_rccl_cost.sh
-    // — and the load stalls context creation and launches on every other thread meanwhile, helper thread or not (a 6 ms file
+    // — and the load stalls context creation and launches on every other thread meanwhile, on whatever thread it runs (a 6 ms file
     // took 1.0 s next to it).  The whole 16-file query scans for 0.12 s.  So: host sum, unless PCQ_MERGE=rccl asks for the
-    // collective (then the communicator is built on a helper thread while the files are scanned); and whenever the
+    // collective (then the communicator is built on a thread of this function while the files are scanned); and whenever the
     // collective fails, the exact per-GPU counts are summed on the host anyway.
     bool merge_rccl = false;
+    std::thread comm_thread;
+    struct JoinOnExit {
+        std::thread &t;
+        ~JoinOnExit() {
+            if (t.joinable()) t.join();
+        }
+    } comm_joiner{comm_thread};
     if (counting && !work.empty()) {
         const char *policy = getenv("PCQ_MERGE");
         double planned_bytes = 0;
@@ -352,7 +359,9 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         if (timing)
             fprintf(stderr, "[pcq] count merge: %s (estimated scan time %.2f s on %zu GPU(s))\n", merge_rccl ? "RCCL all-reduce" : devices.size() > 1 ? "host sum of the per-GPU counts" : "one GPU, its counter is the total",
                     scan_seconds, devices.size());
-        if (merge_rccl && devices.size() > 1) (void)pcq_allreduce_prepare(devices.data(), (int)devices.size());
+        // PCQ_MERGE=rccl: the communicator is built on a thread of THIS function while the files are scanned, and joined before
+        // the merge — and on every other way out of this function (comm_joiner): no thread outlives the query
+        if (merge_rccl && devices.size() > 1) comm_thread = std::thread([devices] { (void)pcq_allreduce_prepare(devices.data(), (int)devices.size()); });
     }
     // per-GPU device counters (count queries): owned by the first worker of the device
     std::vector<uint64_t *> dev_counter(devices.size(), nullptr);
@@ -445,6 +454,7 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         std::vector<uint64_t *> recvs;
         for (size_t d = 0; d < devices.size(); d++)
             if (dev_counter[d]) ctxs.push_back(dev_ctx[d]), sends.push_back(dev_counter[d]), recvs.push_back(dev_counter[d] + 1);
+        if (comm_thread.joinable()) comm_thread.join();
         if (!ctxs.empty() && !merge_rccl && ctxs.size() > 1) {
             total = merge_counts_on_host(ctxs, sends, &final_status);  // (a short query: RCCL would take longer to load than the scans took)
         } else if (!ctxs.empty()) {

@@ -232,8 +232,9 @@ int pcq_scan_dev_indexed(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predic
  * collective fails pass a different word, so that send[] is never touched.  One rank per GPU (two entries on one device
  * are refused).  n == 1 copies send to recv without RCCL unless option "allreduce_single_rank" is set on ctxs[0] (then
  * the one-rank communicator and the all-reduce really run).  RCCL is bound at run time; failure to find it is an error.
- * pcq_allreduce_prepare(devices, n) builds the communicator for that device list on a helper thread and returns at once
- * (ncclCommInitAll overlaps the scans); the all-reduce waits for it. */
+ * pcq_allreduce_prepare(devices, n) builds the communicator for that device list NOW (synchronous, thread-safe: loading RCCL
+ * takes a fresh process 1-5 s, ncclCommInitAll 0.6 s), so that the all-reduce finds it ready; a caller that wants that beside
+ * its scans calls it from a thread of its own and joins it before the all-reduce.  The library starts no thread. */
 int pcq_allreduce_prepare(const int *devices, int n);
 int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, const uint64_t *const *send, uint64_t *const *recv, int n);
 

@@ -322,7 +322,7 @@ def test_every_entry_point_runs_on_the_context_device():
               "pcq_bind_thread_near_device", "pcq_box_to_local", "pcq_collector_has_points", "pcq_collector_grid_params",
               "pcq_collector_new_buffer",  # new_collector() sets the device
               "pcq_allreduce_sum_u64",     # sets each rank's device around its own calls
-              "pcq_allreduce_prepare"}     # takes a device list, no context; its helper thread restores the device it found
+              "pcq_allreduce_prepare"}     # takes a device list, no context; restores the device it found
     checked = 0
     for f in sorted(os.listdir(os.path.join(PKG, "csrc"))):
         if not f.endswith(".hip"):

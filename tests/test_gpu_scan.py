@@ -551,7 +551,7 @@ def test_synth_device_generator_is_bit_identical(oracle, gpu_ctx):
 
 def test_allreduce_single_rank_through_the_real_rccl_calls(gpu_ctx):
     """With option "allreduce_single_rank" a ONE-rank all-reduce still binds RCCL at run time (dlopen, the six symbols),
-    builds a communicator of one device — here on the helper thread of pcq_allreduce_prepare, as the CLI does — and runs
+    builds a communicator of one device — here through pcq_allreduce_prepare, as the CLI does from a thread of its own — and runs
     ncclAllReduce(sum, ncclUint64 = 5, count 1) on the context's stream, out of place (word 0 -> word 1): the whole call
     path of the multi-GPU merge (main.rs:164-180), minus a second GPU.  Two entries on one device are refused (one rank
     per GPU).  The injected failures (option "allreduce_fail") leave the value that was sent untouched — what the CLI's
@@ -565,7 +565,7 @@ def test_allreduce_single_rank_through_the_real_rccl_calls(gpu_ctx):
     try:
         devs = (C.c_int * 1)(0)  # the fixture's context is on device 0
         assert gpu_ctx.lib.pcq_allreduce_prepare(devs, 1) == 0
-        for _ in range(3):  # the communicator is built once (by the helper thread) and reused
+        for _ in range(3):  # the communicator is built once (by the prepare) and reused
             assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, recv, 1) == 0, gpu_ctx.lib.pcq_last_error()
         out = np.zeros(2, dtype=np.uint64)
         gpu_ctx.to_host(out, d)
@@ -589,23 +589,27 @@ def test_allreduce_single_rank_through_the_real_rccl_calls(gpu_ctx):
         gpu_ctx.free(d)
 
 
-def test_a_prepare_nobody_waited_for_does_not_end_the_process():
-    """pcq_allreduce_prepare starts a helper thread; a process that ends without the all-reduce (the query failed before its
-    merge, or the all-reduce refused its arguments before it joined) used to die in std::terminate on the joinable thread."""
+def test_prepare_leaves_no_thread_behind():
+    """pcq_allreduce_prepare builds the communicator synchronously; the library starts no thread.  (Round 3 first had a helper
+    thread in there: a process that ended while it was still inside RCCL died of std::terminate on the joinable thread, then of
+    SIGSEGV in the runtime's exit handlers, then hung in them.)  A process that prepares and ends without an all-reduce —
+    after a device list RCCL refuses, and after one it accepts — ends with status 0."""
     import os
     import subprocess
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = ("import importlib, ctypes as C, sys\n"
+    code = ("import importlib, ctypes as C, sys, threading\n"
             "sys.path.insert(0, %r)\n"
             "pkg = importlib.import_module('adhoc-queries-pointclouds_amd')\n"
             "ctx = pkg.Context(0)\n"
-            "assert ctx.lib.pcq_allreduce_prepare((C.c_int * 2)(0, 0), 2) == 0\n"   # (a list RCCL refuses: the thread fails fast or slow)
-            "assert ctx.lib.pcq_allreduce_sum_u64(None, None, None, 0) != 0\n"       # refused before anything else
-            "assert ctx.lib.pcq_allreduce_prepare((C.c_int * 1)(0), 1) == 0\n"       # and one that nobody waits for
+            "n0 = threading.active_count()\n"
+            "assert ctx.lib.pcq_allreduce_prepare((C.c_int * 2)(0, 0), 2) != 0\n"    # a repeated device: refused, reported at once
+            "assert ctx.lib.pcq_allreduce_sum_u64(None, None, None, 0) != 0\n"
+            "assert ctx.lib.pcq_allreduce_prepare((C.c_int * 1)(0), 1) == 0\n"       # ready when this returns
             "print('done', flush=True)\n") % ROOT
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "done" in r.stdout, (r.returncode, r.stderr[-2000:])
+    for _ in range(2):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "done" in r.stdout, (r.returncode, r.stderr[-2000:])
 
 
 def test_allreduce_entry_point_single_rank(gpu_ctx):
