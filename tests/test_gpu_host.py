@@ -505,6 +505,30 @@ def test_cli_fast_exit_changes_nothing_observable(files, tmp_path):
     assert seen["fast"][0][0][0] == 0 and seen["fast"][0][3][0] != 0 and len(seen["fast"][1]) > 0
 
 
+def test_cli_density_over_many_small_files_takes_two_threads_per_gpu(oracle, tmp_path):
+    """A --density query folds every file's grid when the file is done (a synchronisation); over 32 or more small files per GPU
+    the driver feeds the GPU from two host threads unless --threads-per-gpu says otherwise (profiles/r03_density_threads.log).
+    Same stdout as the oracle CLI either way; a count query over the same files keeps its single thread."""
+    d = tmp_path / "small"
+    d.mkdir()
+    for k in range(40):
+        spec = specs._spec(81000 + k, 3000, 2, (0.01, 0.01, 0.01), (0.0, 0.0, 0.0), (-5000, -5000, -1000), (10001, 10001, 2001), zo=None,
+                           classes=[(1, 0.5), (6, 0.5)])
+        oracle.synth_image(spec, transposed=True).tofile(str(d / f"f{k:02d}.last"))
+    base = ["-i", str(d), "--optimized", "--parallel", "--bounds", "-20;-20;-5;20;20;5"]
+    want = {}
+    for name, extra in (("density", ["--density", "2.5"]), ("count", [])):
+        rc_o, body_o, _, _ = _cli(ORACLE_CLI, base + extra)
+        assert rc_o == 0
+        want[name] = sorted(body_o)
+    for name, extra, flags, contexts in (("density", ["--density", "2.5"], [], 2), ("density", ["--density", "2.5"], ["--threads-per-gpu", "1"], 1),
+                                         ("count", [], [], 1)):
+        rc, body, _, err = _cli(QUERY, base + extra + flags, env={"PCQ_TIMING": "1"})
+        assert rc == 0, err
+        assert sorted(body) == want[name]
+        assert err.count("context on device 0 ready") == contexts, (name, flags, err)
+
+
 def test_cli_more_files_than_descriptors(oracle, tmp_path):
     """run_search_parallel plans every file before the first worker starts; a plan keeps the header's values, not the open
     file (the reference opens inside the rayon task: at most one file per thread is open at a time).  1100 small LAST files
