@@ -5,6 +5,8 @@ every mode of the tile fold, on scan-ordered files with equal-distance ties that
 keys inside tiles, and with runs of both tuple widths in one fold."""
 import importlib
 
+import os
+
 import numpy as np
 import pytest
 
@@ -20,6 +22,7 @@ def scan_ordered_image(oracle, seed, n, fmt, snap_step=512, snap_fraction=0.5):
     """A LAST image whose points are sorted along x inside y strips (scan lines, boustrophedon), half of them snapped to a
     coarse lattice — runs of identical positions with different attributes: equal distances, the first in file order must
     win — and with the last point of every tile repeated as the first point of the next one (a tie across the boundary)."""
+    seed += int(os.environ.get("PCQ_TEST_SEED_BASE", "0"))  # a soak run: other seeds than the committed ones
     spec = small_spec(seed, n, fmt=fmt)
     image = oracle.synth_image(spec, transposed=True).copy()
     hdr = oracle.parse_header(image[:400].tobytes())

@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 from test_gpu_host import Q  # noqa: E402  (ctypes view of include/pcq_query.h)
 
+SEED_BASE = int(os.environ.get("PCQ_TEST_SEED_BASE", "0"))  # a soak run: other seeds than the committed ones
 FORMAT_LEN = {0: 20, 1: 28, 2: 26, 3: 34, 4: 57, 5: 63, 6: 30, 7: 36, 8: 38, 9: 59, 10: 67}
 COLOR_AT = {2: 20, 3: 28, 5: 28}  # the colour offsets the optimized scans know (last.rs:83-88)
 
@@ -98,7 +99,7 @@ def sorted_grid(q, h):
 
 @pytest.mark.parametrize("seed", range(150))
 def test_random_files_and_queries(oracle, tmp_path, seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(1000 + SEED_BASE + seed)
     q = Q()
     transposed = bool(seed % 2)
     image, world, meta = build(rng, transposed)
@@ -156,7 +157,7 @@ def test_random_lazer_files_and_queries(oracle, tmp_path, seed):
     """The same randomly built point sets as LAZER files (random block size, LZ4 frame flags, every point
     format): world-space `contains` on the GPU vs the oracle's streaming restatement, boxes whose faces
     pass exactly through points included; n = 0 panics on both sides (lazer_reader.rs:123,143)."""
-    rng = np.random.default_rng(7000 + seed)
+    rng = np.random.default_rng(7000 + SEED_BASE + seed)
     q = Q()
     image, world, meta = build(rng, True)
     if meta["n"] == 0:
