@@ -284,6 +284,9 @@ def main():
                 if same:
                     traffic = pmc.get("hbm_bytes_per_launch")
                     traffic_source = f"profiles/pmc_latest.json@{pmc.get('git_head', '?')} (tools/pmc_traffic.py, not measured by this run)"
+                elif kernel_name in str(pmc.get("kernel_name", "")) and pmc.get("kernel_source_id") == kernel_source_id():
+                    traffic_source = (f"profiles/pmc_latest.json@{pmc.get('git_head', '?')} counted this kernel with {pmc.get('points_per_launch')} points per launch "
+                                      f"(traffic / algorithmic {pmc.get('traffic_over_algorithmic')}); this run's launches differ: not reported")
                 else:
                     traffic_source = "profiles/pmc_latest.json is from another kernel build: not reported"
             except Exception:
