@@ -336,6 +336,10 @@ class Context:
     def synchronize(self) -> None:
         _check(self.lib.pcq_ctx_synchronize(self.handle))
 
+    def stream_handle(self) -> int:
+        """The context's own HIP stream (hipStream_t as an integer): what scans without a caller's stream and every fold run on."""
+        return int(self.lib.pcq_ctx_stream(self.handle) or 0)
+
     # collectors -------------------------------------------------------------------------------
     def count_collector(self, device_counter: Optional[int] = None) -> Collector:
         h = C.c_void_p()

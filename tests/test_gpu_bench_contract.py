@@ -42,6 +42,25 @@ def test_bench_json_contract_single_process():
     pb = d["parity_batched_on_sample"]  # the TIMED kernel on a selective box (ca13_L) against the oracle
     assert pb["equal"] is True and pb["gpu"] == pb["oracle"] and pb["kernel"] == d["roofline"]["kernel"] and pb["query"] == "ca13_L"
     assert d["rccl_ranks"] == 0
+    # the other configs and the PCIe-inclusive path, measured after the timed region ("as a separate line")
+    sec = d["secondary"]
+    for key in ("end_to_end", "config2", "config3", "config4"):
+        assert key in sec, key
+        assert sec[key]["kernels"] and sec[key]["what"]
+    e = sec["end_to_end"]
+    assert e["bound"] == "pcie" and e["bytes"] == 12 * 4 * 100003 and e["GBps"] > 0 and e["matches"] == 4 * 100003
+    assert abs(e["frac_of_pcie_spec"] - e["GBps"] / e["pcie_spec_GBps"]) < 1e-12
+    c3 = sec["config3"]
+    assert c3["class_histogram_sums_to_n"] is True and c3["class_19"] == 0 and c3["algorithmic_bytes"] == c3["points"] and 0 < c3["matches"] < c3["points"]
+    c4 = sec["config4"]
+    for cell in ("density_10", "density_100"):
+        g = c4[cell]
+        assert 0 < g["cells"] <= 300007 and g["algorithmic_bytes"] == 12 * 300007 and g["event_ms"] > 0 and g["wall_ms"] > 0
+        assert abs(g["frac"] - g["GBps"] / 8000.0) < 1e-12
+    assert c4["density_100"]["cells"] <= c4["density_10"]["cells"]
+    c2 = sec["config2"]
+    assert c2["halves_sum_to_whole"] is True and c2["algorithmic_bytes"] == 12 * c2["points"]
+    assert sec["seconds_spent"] < 60
 
 
 def test_bench_under_torch_distributed_run_exercises_rccl():
