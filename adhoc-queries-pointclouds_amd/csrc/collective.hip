@@ -28,6 +28,7 @@ struct Rccl {
     void *lib = nullptr;
     ncclResult_t (*CommInitAll)(ncclComm_t *, int, const int *) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
@@ -43,7 +44,9 @@ int load_rccl() {
     if (g_rccl.lib) return PCQ_OK;
     // RCCL writes its banner and its NCCL_DEBUG output to stdout; the stdout of a query is the reference's (main.rs:289,
     // :179, :313-316) and nothing else.  Whatever level the environment asks for goes to stderr unless it names a file.
-    setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);
+    // (A caller that builds the communicator beside threads that read the environment sets the variable itself, before
+    // those threads exist — host/run_search.cpp does; then nothing is written here.)
+    if (!getenv("NCCL_DEBUG_FILE")) setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     const auto t0 = std::chrono::steady_clock::now();
     for (const char *n : names) {
@@ -60,6 +63,7 @@ int load_rccl() {
     if (!g_rccl.field) return pcq_fail(PCQ_ERR_HIP, "RCCL symbol %s missing", sym);
     BIND(CommInitAll, "ncclCommInitAll")
     BIND(CommDestroy, "ncclCommDestroy")
+    BIND(CommAbort, "ncclCommAbort")
     BIND(GroupStart, "ncclGroupStart")
     BIND(GroupEnd, "ncclGroupEnd")
     BIND(AllReduce, "ncclAllReduce")
@@ -91,7 +95,7 @@ int ensure_comm(const std::vector<int> &devs) {
     {
         // RCCL prints its version banner to stdout when a communicator is created (plain printf, whatever NCCL_DEBUG_FILE
         // says); the stdout of a query is the reference's and nothing else.  For the duration of the call descriptor 1 is
-        // descriptor 2.  (The CLI prints nothing of its own between "Searching N files..." and the merged result.)
+        // descriptor 2.  (The CLI joins the thread it builds the communicator on before it prints its first line behind the scans.)
         fflush(stdout);
         const int saved = dup(1);
         if (saved >= 0) (void)dup2(2, 1);
@@ -141,7 +145,8 @@ extern "C" int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, const uint64_t *const
         for (int j = 0; j < i; j++)
             if (ctxs[i]->device == ctxs[j]->device)
                 return pcq_fail(PCQ_ERR_ARG, "pcq_allreduce_sum_u64: entries %d and %d are both on device %d (one rank per GPU)", j, i, ctxs[i]->device);
-    const int inject = ctxs[0]->allreduce_fail;  // test hook: 1 = fail before anything is touched, 2 = fail after the reduction ran
+    const int inject = ctxs[0]->allreduce_fail;  // test hook: 1 = fail before anything is touched, 2 = fail after the reduction ran,
+                                                 // 3 = fail inside the RCCL group with rank 0 already enqueued (as a later rank's failure would)
     if (inject == 1) return pcq_fail(PCQ_ERR_HIP, "pcq_allreduce_sum_u64: injected failure (before the reduction)");
     if (n == 1 && !ctxs[0]->allreduce_single_rank) {  // a single rank: the sum is the value itself
         PCQ_ON_DEVICE_OF_CTX(ctxs[0]);
@@ -158,7 +163,7 @@ extern "C" int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, const uint64_t *const
     if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     // Whatever fails between GroupStart and GroupEnd, the group is closed before this function returns: an open group
-    // would swallow the next caller's collectives.
+    // would swallow the next caller's collectives — but never as a collective some ranks are missing from (below).
     PCQ_NCCL(g_rccl.GroupStart());
     int failed = PCQ_OK;
     for (int i = 0; i < n && !failed; i++) {
@@ -169,9 +174,21 @@ extern "C" int pcq_allreduce_sum_u64(pcq_ctx *const *ctxs, const uint64_t *const
         }
         const ncclResult_t r = g_rccl.AllReduce(send[i], recv[i], 1, kNcclUint64, kNcclSum, g_rccl.comms[i], ctxs[i]->stream);
         if (r != 0) failed = pcq_fail(PCQ_ERR_HIP, "ncclAllReduce (rank %d) failed: %s", i, g_rccl.GetErrorString(r));
+        else if (inject == 3 && i == 0) failed = pcq_fail(PCQ_ERR_HIP, "pcq_allreduce_sum_u64: injected failure (inside the group, behind rank 0)");
+    }
+    if (failed) {
+        // Ranks in front of the failing one are already part of the group: closing it as it is would launch a collective
+        // that waits for ranks that never come — on the very streams the caller's fallback reads the counts with.  The
+        // communicators are aborted first (kernels of an aborted communicator return), the group is closed whatever it
+        // says, and the communicator is built again by whoever asks next.
+        for (ncclComm_t c : g_rccl.comms)
+            if (c) (void)g_rccl.CommAbort(c);
+        (void)g_rccl.GroupEnd();
+        g_rccl.comms.clear();
+        g_rccl.devices.clear();
+        return failed;
     }
     const ncclResult_t ge = g_rccl.GroupEnd();
-    if (failed) return failed;
     if (ge != 0) return pcq_fail(PCQ_ERR_HIP, "ncclGroupEnd failed: %s", g_rccl.GetErrorString(ge));
     for (int i = 0; i < n; i++) {
         PCQ_HIP(hipSetDevice(devs[i]));

@@ -1,0 +1,275 @@
+#include "grid_common.h"
+
+namespace pcqgrid {
+
+// ---------------------------------------------------------------------------------------------------------------
+// the fold of a coarse grid's level-1 bins, as a stream (round 4)
+// ---------------------------------------------------------------------------------------------------------------
+// A coarse grid has few cells and many tuples per cell: of the ~320 k tuples of a bin of ca13 XL at 100 m all but a few
+// per cent lose against a tuple the table has already seen.  k_fold<BIG> pays three workgroup barriers per chunk of 4096
+// tuples for the exact (distance, file order) minimum and parks every provisional winner's payload in HBM; its waves wait
+// 60 % of their cycles (profiles/r03_grid_sq_counters.txt).  This kernel splits the work the other way round:
+//   1. STREAM, no barrier: every wave walks its own share of the bin's tuples.  A tuple finds its cell's slot, reads the
+//      best distance seen so far and is OUT when its own is larger (the minimum only falls, a stale value is only too
+//      large); otherwise it lowers the minimum (atomicMin on the f64 bits) and is appended to the workgroup's SURVIVOR list
+//      in HBM scratch.  The tuple that ends up at the cell's minimum — and every tuple that ties with it — survives: when it
+//      was tested the minimum was not below it.
+//   2. EXACT, two barriers per BIN: among the survivors at their cell's final minimum the earliest in file order
+//      (atomicMin on the order), then that one survivor leaves its list index in the slot, and the slots' owners write the
+//      cells out in slot order — from the survivor records; nothing was parked.
+// A file in random order leaves a few survivors per cell (the running minima of a random sequence: ln n, a little more
+// for what 1024 lanes see at the same time); a file sorted TOWARDS the cell centres makes every tuple a running minimum:
+// a bin whose survivors outgrow the list goes on the defer list, and k_fold<BIG> folds it the old way.
+// A wave's share of the bin is a range of the bin's TUPLES (not of its tiles: a compacted sparse run has ONE fragment per
+// bin); it finds the fragment its range starts in by a 64-ary search of the bin's prefix row, then takes the fragments 64
+// at a time — lane L holds fragment L's prefix and address — and turns "tuple g of the bin" into an address by a binary
+// search across the lanes (six bpermutes): no window in LDS, nothing shared with the other waves.
+struct Survivor {   // 32 bytes, two 16-byte words
+    int32_t x, y, z;
+    uint32_t idx;
+    uint32_t w0, w1;  // as GridTuple (w0 carries the entry)
+    uint32_t slot;
+    uint32_t _pad;
+};
+
+template <int NSLOT, int NT, int LIMIT, int U>
+__global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t nparts, uint32_t surv_cap, uint4 *__restrict__ surv_scratch) {
+    constexpr int SPT = (NSLOT + NT - 1) / NT;  // slots per thread in the compaction
+    constexpr int NW = NT / 64;
+    __shared__ uint64_t s_key[NSLOT];
+    __shared__ uint64_t s_dist[NSLOT];   // f64 bits of the best squared distance (monotone for d >= 0)
+    __shared__ uint32_t s_ord[NSLOT];    // file order (+ 1) of the winner: 0 = an earlier fold's winner, ~0 = none yet
+    __shared__ uint32_t s_widx[NSLOT];   // the winner's place in the survivor list (an earlier fold's winner: its index among the partition's old winners)
+    __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32];
+    __shared__ uint32_t s_ncell, s_over, s_nsurv, s_wsum[NW];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const BinSrc &S = P.src;
+    uint4 *surv = surv_scratch + (size_t)blockIdx.x * surv_cap * 2;
+    for (uint32_t it = blockIdx.x; it < nparts; it += gridDim.x) {
+        const uint32_t p = xcd_order(it, nparts);
+        const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
+        const uint64_t old_base = P.okeys ? P.obase[p] : 0;
+        const uint64_t out_base = P.wbase[p];
+        for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0u;
+        for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
+        if (threadIdx.x == 0) s_ncell = 0, s_over = 0, s_nsurv = 0;
+        __syncthreads();
+
+        // earlier winners first: their distance is recomputed from the record (same f64 expressions, same bits)
+        for (uint32_t i = threadIdx.x; i < n_old; i += NT) {
+            const uint64_t key = P.okeys[old_base + i];
+            const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, key, cell_hash(key), &s_ncell);
+            if (s < 0) {
+                s_over = 1;
+                continue;
+            }
+            const uint4 ra = *P.orecs.a(old_base + i), rb = *P.orecs.b(old_base + i);
+            s_widx[s] = i;
+            s_ord[s] = 0;
+            if (rec_flags(rb) & R_ALIAS) {
+                atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
+            } else {
+                const double ox = __longlong_as_double((long long)((uint64_t)ra.x | ((uint64_t)ra.y << 32))),
+                             oy = __longlong_as_double((long long)((uint64_t)ra.z | ((uint64_t)ra.w << 32))),
+                             oz = __longlong_as_double((long long)((uint64_t)rb.x | ((uint64_t)rb.y << 32)));
+                uint64_t cell[3];
+                const DevGrid &gf = *P.g.full;
+#pragma unroll
+                for (int a = 0; a < 3; a++) cell[a] = (key >> gf.shift[a]) & gf.mask[a];  // not aliased: unmasked == masked
+                s_dist[s] = (uint64_t)__double_as_longlong(centre_dist(gf, cell, ox, oy, oz));
+            }
+        }
+        if (n_old) __syncthreads();
+
+        // ---- 1. the stream: this wave's tuples g_lo .. g_hi of the bin ----
+        {
+            const uint32_t *pre = S.preT + (size_t)p * S.Tp1;
+            const uint32_t total = uni32(ldg(pre + S.T));
+            const uint32_t g_lo = (uint32_t)((uint64_t)total * wave / NW), g_hi = (uint32_t)((uint64_t)total * (wave + 1) / NW);
+            if (g_lo < g_hi) {
+                // the fragment tuple g_lo lies in: the last f with pre[f] <= g_lo — 64-ary search (lane L probes lo + L * step)
+                uint32_t f_lo = 0, f_n = S.T;  // the answer is in [f_lo, f_lo + f_n)
+                while (f_n > 1) {
+                    const uint32_t step = (f_n + 63) / 64;
+                    const uint32_t f = f_lo + lane * step;
+                    const bool le = f < f_lo + f_n && ldg(pre + f) <= g_lo;
+                    const uint32_t k = (uint32_t)__popcll(__ballot(le));  // lanes 0 .. k - 1 say yes (pre is monotone; lane 0 always does)
+                    const uint32_t nf = f_lo + (k - 1) * step;
+                    f_n = f_lo + f_n - nf < step ? f_lo + f_n - nf : step;
+                    f_lo = nf;
+                }
+                uint32_t f0 = uni32(f_lo);
+                uint32_t g = g_lo;  // the next tuple of the wave's share
+                while (g < g_hi) {
+                    // a batch: fragments f0 .. f0 + 63, lane L holds fragment f0 + L: its prefix, its address | wide
+                    const uint32_t f = f0 + lane;
+                    const bool fv = f < S.T;
+                    const uint32_t myp = ldg(pre + (fv ? f : S.T));
+                    const uint32_t b_end = uni32(ldg(pre + (f0 + 64 < S.T ? f0 + 64 : S.T)));  // tuples of the bin in front of the next batch
+                    uint64_t faddr = 0;
+                    if (fv) faddr = frag_addr(S, p, f);
+                    const uint32_t fa_lo = (uint32_t)faddr, fa_hi = (uint32_t)(faddr >> 32);
+                    const uint32_t stop = b_end < g_hi ? b_end : g_hi;
+                    while (g < stop) {
+                        RawTuple raw[U];
+                        bool wd[U], act[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const uint32_t q = g + (uint32_t)u * 64 + lane;
+                            act[u] = q < stop;
+                            const uint32_t qq = act[u] ? q : stop - 1;
+                            uint32_t lo = 0;  // the last lane whose prefix is <= qq (empty fragments repeat their neighbour's and are never it)
+#pragma unroll
+                            for (int st = 32; st >= 1; st >>= 1) {
+                                const uint32_t cand = lo + st;
+                                const uint32_t pc = (uint32_t)__shfl((int)myp, (int)cand, 64);
+                                const bool fin = f0 + cand < S.T;
+                                if (fin && pc <= qq) lo = cand;
+                            }
+                            const uint32_t pb = (uint32_t)__shfl((int)myp, (int)lo, 64);
+                            const uint32_t al = (uint32_t)__shfl((int)fa_lo, (int)lo, 64), ah = (uint32_t)__shfl((int)fa_hi, (int)lo, 64);
+                            const uint64_t a = (uint64_t)al | ((uint64_t)ah << 32);
+                            wd[u] = a & 1;
+                            raw[u] = ld_raw(reinterpret_cast<const uint8_t *>(a & ~1ull) + (uint64_t)(qq - pb) * tuple_bytes(wd[u]), wd[u]);
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const GridTuple t = decode_raw(raw[u], wd[u], P.entries);
+                            bool surv_me = false;
+                            int s = -1;
+                            if (act[u]) {
+                                const TupleEval ev = eval_tuple(P.g, P.entries, t);
+                                s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, cell_hash(ev.key), &s_ncell);
+                                if (s < 0) {
+                                    s_over = 1;
+                                } else {
+                                    if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
+                                    const uint64_t seen = __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a stale value is only too large)
+                                    if (ev.dbits <= seen) {
+                                        if (ev.dbits < seen) {
+                                            const uint64_t old = atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
+                                            if (ev.dbits < old) s_ord[s] = ~0u;  // a new minimum: an earlier fold's winner is out (racing writers store the same value)
+                                        }
+                                        surv_me = true;
+                                    }
+                                }
+                            }
+                            const unsigned long long m = __ballot(surv_me);
+                            if (m) {  // (the same for the whole wave)
+                                uint32_t base = 0;
+                                if (lane == 0) base = atomicAdd(&s_nsurv, (uint32_t)__popcll(m));
+                                base = uni32(base);
+                                const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                                if (surv_me && pos < surv_cap) {
+                                    surv[2 * (size_t)pos] = make_uint4((uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx);
+                                    surv[2 * (size_t)pos + 1] = make_uint4(t.w0, t.w1, (uint32_t)s, 0u);
+                                }
+                            }
+                        }
+                        g += 64 * U;
+                    }
+                    g = stop;
+                    f0 += 64;
+                }
+            }
+        }
+        // The survivor records are read back by other threads of THIS workgroup: a workgroup-scope fence (the stores have
+        // left the wave; all waves of a workgroup share one L1), as k_fold does for its parked payloads.
+        __threadfence_block();
+        __syncthreads();
+        const uint32_t nsurv = s_nsurv;
+        if (s_over) {  // more cells than the table holds: the host repeats the fold with more partitions
+            if (threadIdx.x == 0) {
+                P.wcount[p] = 0;
+                atomicAdd(&P.stats[1], 1ull);
+            }
+        } else if (nsurv > surv_cap) {  // more running minima than the list holds (a file sorted towards the cell centres): k_fold<BIG> takes the bin
+            if (threadIdx.x == 0) {
+                P.wcount[p] = 0;
+                P.defer_list[atomicAdd(&P.stats[3], 1ull)] = p;
+            }
+        } else {
+            // ---- 2. exact: (distance, file order) among the survivors ----
+            for (uint32_t i = threadIdx.x; i < nsurv; i += NT) {
+                const uint4 ra = surv[2 * (size_t)i], rb = surv[2 * (size_t)i + 1];
+                GridTuple t{(int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, ra.w, rb.x, rb.y};
+                const uint32_t s = rb.z;
+                if (eval_tuple(P.g, P.entries, t).dbits == s_dist[s]) atomicMin(&s_ord[s], (uint32_t)ord_of(t));
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < nsurv; i += NT) {
+                const uint4 ra = surv[2 * (size_t)i], rb = surv[2 * (size_t)i + 1];
+                GridTuple t{(int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, ra.w, rb.x, rb.y};
+                const uint32_t s = rb.z;
+                if (s_ord[s] == (uint32_t)ord_of(t) && eval_tuple(P.g, P.entries, t).dbits == s_dist[s]) s_widx[s] = i;
+            }
+            __syncthreads();
+            // compaction: thread t owns slots [t * SPT, ...): the cells leave in slot order
+            uint32_t mine = 0;
+            const int s0 = threadIdx.x * SPT;
+            uint64_t keys[SPT];
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                keys[j] = s0 + j < NSLOT ? s_key[s0 + j] : PCQ_EMPTY_KEY;
+                mine += keys[j] != PCQ_EMPTY_KEY ? 1 : 0;
+            }
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t up = __shfl_up(incl, off, 64);
+                if (lane >= (uint32_t)off) incl += up;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = incl - mine, total = 0;
+            for (int w = 0; w < NW; w++) {
+                before += (uint32_t)w < wave ? s_wsum[w] : 0;
+                total += s_wsum[w];
+            }
+            bool any_alias = false;
+            uint64_t o = out_base + before;
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                const int s = s0 + j;
+                const uint64_t key = keys[j];
+                if (key == PCQ_EMPTY_KEY) continue;
+                P.wkeys[o] = key;
+                const bool alias = (s_aliasbits[s >> 5] >> (s & 31)) & 1;
+                if (alias) {  // left to the exact replay: the state before this fold (the earlier winner, if there is one) + the flag
+                    any_alias = true;
+                    uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
+                    for (uint32_t i = 0; i < n_old; i++)
+                        if (P.okeys[old_base + i] == key) {
+                            a = *P.orecs.a(old_base + i), b = *P.orecs.b(old_base + i);
+                            b.w |= (uint32_t)R_ALIAS << 24;
+                            break;
+                        }
+                    *P.wrecs.a(o) = a;
+                    *P.wrecs.b(o) = b;
+                } else if (s_ord[s] == 0) {  // the earlier winner stays
+                    const uint64_t oi = old_base + s_widx[s];
+                    *P.wrecs.a(o) = *P.orecs.a(oi);
+                    *P.wrecs.b(o) = *P.orecs.b(oi);
+                } else {
+                    const uint32_t wi = s_widx[s];
+                    const uint4 ra = surv[2 * (size_t)wi], rb = surv[2 * (size_t)wi + 1];
+                    st_record(P.wrecs, o, P.entries.get((rb.x >> 8) & 0xff), (int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, rb.x, rb.y, R_HAS);
+                }
+                o++;
+            }
+            if (__syncthreads_or(any_alias) && threadIdx.x == 0) {
+                P.palias[p] = 1;
+                atomicAdd(&P.stats[2], 1ull);
+            }
+            if (threadIdx.x == 0) {
+                P.wcount[p] = total;
+                if (total) atomicAdd(&P.stats[0], (unsigned long long)total);
+            }
+        }
+        __syncthreads();  // the table is cleared for the next partition
+    }
+}
+
+template __global__ void k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 4>(FoldParams, uint32_t, uint32_t, uint4 *);
+
+}  // namespace pcqgrid

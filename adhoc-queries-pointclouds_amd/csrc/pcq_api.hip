@@ -317,7 +317,7 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "allreduce_single_rank")) {
         ctx->allreduce_single_rank = value != 0;
     } else if (!strcmp(key, "allreduce_fail")) {
-        if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "allreduce_fail must be 0, 1 or 2");
+        if (value < 0 || value > 3) return pcq_fail(PCQ_ERR_ARG, "allreduce_fail must be 0, 1, 2 or 3");
         ctx->allreduce_fail = (int)value;
     } else if (!strcmp(key, "grid_pending_budget")) {
         // (points scanned into a grid collector before it folds; a fold's tuple counts and offsets are 32-bit, grid.hip clamps to that)
@@ -326,6 +326,12 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "grid_agg")) {
         if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "grid_agg must be 0 (adaptive), 1 (always) or 2 (never)");
         ctx->grid_agg = (int)value;
+    } else if (!strcmp(key, "grid_stream")) {
+        if (value < 0 || value > 1) return pcq_fail(PCQ_ERR_ARG, "grid_stream must be 0 or 1");
+        ctx->grid_stream = (int)value;
+    } else if (!strcmp(key, "grid_tuple16")) {
+        if (value < 0 || value > 1) return pcq_fail(PCQ_ERR_ARG, "grid_tuple16 must be 0 or 1");
+        ctx->grid_tuple16 = (int)value;
     } else if (!strcmp(key, "grid_f2")) {
         if (value < 0 || value > 4096) return pcq_fail(PCQ_ERR_ARG, "grid_f2 must be 0..4096");
         ctx->grid_f2 = (int)value;
@@ -374,6 +380,9 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     else if (!strcmp(key, "allreduce_fail")) *value = ctx->allreduce_fail;
     else if (!strcmp(key, "grid_f2")) *value = ctx->grid_f2;
     else if (!strcmp(key, "grid_agg")) *value = ctx->grid_agg;
+    else if (!strcmp(key, "grid_tuple16")) *value = ctx->grid_tuple16;
+    else if (!strcmp(key, "grid_stream")) *value = ctx->grid_stream;
+    else if (!strcmp(key, "grid_deferred")) *value = ctx->grid_deferred;
     else if (!strcmp(key, "grid_last_tuples")) *value = ctx->grid_last_tuples;
     else if (!strcmp(key, "grid_folds")) *value = ctx->grid_folds;
     else if (!strcmp(key, "grid_level2")) *value = ctx->grid_level2;

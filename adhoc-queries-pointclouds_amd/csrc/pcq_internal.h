@@ -158,10 +158,13 @@ struct pcq_ctx {
     int64_t grid_pending_budget = 0;    // option: tuples a grid collector may hold before it folds (0 = default)
     int allreduce_single_rank = 0;      // option: pcq_allreduce_sum_u64 with ONE rank still goes through RCCL (communicator of one
                                         // device, ncclAllReduce) — exercises the run-time binding on a single-GPU box
-    int allreduce_fail = 0;             // option (tests): pcq_allreduce_sum_u64 fails — 1: before anything is touched, 2: after the reduction has run
+    int allreduce_fail = 0;             // option (tests): pcq_allreduce_sum_u64 fails — 1: before anything is touched, 2: after the reduction has run, 3: inside the group
     int grid_f2 = 0;                    // option (tests): second-level fan-out a fold starts from (0 = from the measured estimate)
     int grid_agg = 0;                   // option: pass 0 folds a tile's duplicate cells before they travel — 0 = while it pays (per workgroup),
                                         // 1 = every tile, 2 = never; the results are the same, the tuples moved are not
+    int grid_stream = 1;                // option (tests): 0 = a coarse grid's bins are folded by k_fold<BIG> (the fallback of the streaming fold) only
+    int64_t grid_deferred = 0;          // diagnostics: bins the streaming fold left to k_fold<BIG> (survivor list outgrown)
+    int grid_tuple16 = 1;               // option (tests): 0 = every scan writes 24-byte tuples (the form a 16-byte tuple falls back to)
     int64_t grid_last_tuples = 0;       // diagnostics: tuples the last fold found pending (after pass 0's own fold)
     // options
     int grid_blocks_per_cu = 2;   // persistent blocks per CU of the generic (strided) count kernels and the chunk index
@@ -228,7 +231,7 @@ int pcq_launch_generic_count(pcq_ctx *ctx, const DevCols &cols, const DevPred &p
                              uint64_t *d_count, hipStream_t s);
 int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pred, uint8_t *d_out31, const uint64_t *d_npoints_in,
                            uint64_t *d_npoints_out, hipStream_t s);
-// grid.hip
+// grid_host.hip (kernels: grid_pass0.hip, grid_dir.hip, grid_level2.hip, grid_fold.hip, grid_finish.hip; shared: grid_common.h)
 int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols, const DevPred &pred, hipStream_t s);
 void pcq_grid_release(pcq_collector *c);
 int pcq_grid_drain(pcq_collector *c, pcq_point *out, uint64_t *keys_out, uint64_t cap, uint64_t *out_n);

@@ -1,5 +1,6 @@
 // capi.cpp — extern "C" view of the host layer (include/pcq_query.h).
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "lz4_frame.hpp"
@@ -152,6 +153,50 @@ extern "C" int pcq_query_main(int argc, const char *const *argv) {
             fputs(s.c_str(), stderr);
             fputc('\n', stderr);
         });
+}
+
+// Test entry: the CLI with the driver's test hooks (RunOptions::test_device_slots / test_allreduce_fail).  The `query`
+// binary has no way to set them.  device_slots: "0,0"-style list or NULL; allreduce_fail: 0, 1 (early), 2 (late).
+extern "C" int pcq_query_main_with_hooks(int argc, const char *const *argv, const char *device_slots, int allreduce_fail) {
+    RunOptions hooks;
+    for (const char *p = device_slots ? device_slots : ""; *p;) {
+        char *end = nullptr;
+        const long v = strtol(p, &end, 10);
+        if (end == p) break;
+        hooks.test_device_slots.push_back((int)v);
+        p = *end == ',' ? end + 1 : end;
+    }
+    hooks.test_allreduce_fail = allreduce_fail;
+    return query_main(
+        argc, argv,
+        [](const std::string &s) {
+            fputs(s.c_str(), stdout);
+            fputc('\n', stdout);
+            fflush(stdout);
+        },
+        [](const std::string &s) {
+            fputs(s.c_str(), stderr);
+            fputc('\n', stderr);
+        },
+        &hooks);
+}
+
+// The file -> device-slot schedule of run_search_parallel (FileScheduler) under staggered context start-up, without a GPU:
+// slot_of_file[i] = the slot that takes file i when slot k is ready at ready_ms[k] and a file costs ms_per_unit x cost.
+extern "C" int pcq_query_simulate_schedule(const uint64_t *cost, size_t nfiles, const double *ready_ms, int nslots, double ms_per_unit,
+                                           int *slot_of_file, int *home_slot, double *makespan_ms) {
+    if ((!cost && nfiles) || !ready_ms || nslots < 1 || (!slot_of_file && nfiles)) return done(Status::Err(PCQ_ERR_ARG, "pcq_query_simulate_schedule: bad arguments"));
+    const std::vector<uint64_t> c(cost, cost + nfiles);
+    const std::vector<double> r(ready_ms, ready_ms + nslots);
+    std::vector<int> slots;
+    const double end = simulate_schedule(c, r, ms_per_unit, &slots);
+    for (size_t i = 0; i < nfiles; i++) slot_of_file[i] = slots[i];
+    if (home_slot) {
+        FileScheduler sched(c, (size_t)nslots);
+        for (size_t i = 0; i < nfiles; i++) home_slot[i] = (int)sched.home_slot(i);
+    }
+    if (makespan_ms) *makespan_ms = end;
+    return 0;
 }
 
 // ---- resident dataset -------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 #include <cstring>
 #include <mutex>
 #include <map>
+#include <memory>
 
 namespace pcq {
 
@@ -149,6 +150,8 @@ Status MappedFile::open(const std::string &path) {
         return Status::Err(PCQ_ERR_IO, path + ": " + strerror(e));
     }
     size_ = (size_t)st.st_size;
+    dev_ = (uint64_t)st.st_dev, ino_ = (uint64_t)st.st_ino;
+    mtime_ns_ = (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec;
     if (size_ > 0) {
         void *p = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd, 0);
         if (p == MAP_FAILED) {
@@ -184,6 +187,19 @@ ThreadContexts &this_threads_contexts() {
 }
 }  // namespace
 
+// The calling thread's contexts, released NOW — from ordinary code, while every library the release calls into is whole.
+// Left to the thread_local's destructor the same calls run in the thread-exit (or process-exit) phase: behind the
+// destructors of thread-locals constructed later, which is where a preloaded profiler keeps the per-thread state its HIP
+// interception uses (a `query` under rocprofv3 --memory-copy-trace printed its answer, wrote its traces and did not end:
+// DESIGN.md section 10).  The drivers call this at the end of every worker and before main() returns; the destructor stays
+// as the net under a library user's threads.
+void release_thread_contexts() {
+    if (g_process_is_ending.load()) return;
+    ThreadContexts &tc = this_threads_contexts();
+    for (auto &kv : tc.by_device) pcq_shutdown(kv.second);
+    tc.by_device.clear();
+}
+
 Status thread_context(int device, pcq_ctx **out) {
     ThreadContexts &tc = this_threads_contexts();
     auto it = tc.by_device.find(device);
@@ -194,10 +210,20 @@ Status thread_context(int device, pcq_ctx **out) {
     pcq_ctx *ctx = nullptr;
     int rc;
     {
-        // one at a time: HIP start-up (runtime init, first queue creation) run concurrently from several
-        // threads was measured to take longer in total than back to back
-        static std::mutex init_mutex;
-        std::lock_guard<std::mutex> g(init_mutex);
+        // One at a time PER DEVICE: several threads bringing up contexts on ONE GPU were measured to take longer in total than
+        // back to back (runtime init, first queue creation: profiles/r01_cli_fixed_cost.log) — that is all the measurement says.
+        // Different devices start together: with one process-wide mutex the eight contexts of `--gpus 8` came up one after
+        // the other (8 x 50-230 ms) while the first GPU's worker was already scanning.
+        static std::mutex table_mutex;
+        static std::map<int, std::unique_ptr<std::mutex>> per_device;
+        std::mutex *dev_mutex;
+        {
+            std::lock_guard<std::mutex> g(table_mutex);
+            auto &slot = per_device[device];
+            if (!slot) slot = std::make_unique<std::mutex>();
+            dev_mutex = slot.get();
+        }
+        std::lock_guard<std::mutex> g(*dev_mutex);
         rc = pcq_init(device, &ctx);
     }
     if (rc) return Status::FromLib(rc);

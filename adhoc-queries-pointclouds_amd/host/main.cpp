@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <initializer_list>
 
 #include "pcq_host.hpp"
 
@@ -15,13 +16,33 @@ int main(int argc, char **argv) {
     // destructors of the HIP runtime (40 ms) — changes nothing anybody can observe: the answer is printed, the files are
     // written and closed, and the kernel reclaims a process's GPU resources either way (at no measurable cost: 13.6 ms
     // outside main() with or without the releases, 12 ms for a query that never woke the GPU).  PCQ_EXIT=full keeps the
-    // normal path; it is also what runs when something hooks the end of the process (a profiler or a sanitizer writes its
-    // report there), unless PCQ_EXIT=fast insists.
+    // normal path; it is also what runs when something hooks the end of the process (a profiler, a sanitizer or a coverage
+    // run-time writes its report there), unless PCQ_EXIT=fast insists.  PCQ_TIMING=1 says which way out was taken, and why.
     const char *mode = getenv("PCQ_EXIT");
-    const char *preload = getenv("LD_PRELOAD");
-    const bool hooked = getenv("HSA_TOOLS_LIB") || getenv("ROCP_TOOL_LIBRARIES") || getenv("ASAN_OPTIONS") ||
-                        (preload && (strstr(preload, "rocprof") || strstr(preload, "roctracer") || strstr(preload, "san")));
+    // Something that writes its report when the process ends normally: a profiler's tool library, a sanitizer's or a coverage
+    // run-time — compiled in (then this binary knows) or preloaded / configured through the environment.
+#if defined(__SANITIZE_ADDRESS__) || defined(__SANITIZE_THREAD__) || defined(PCQ_EXIT_FULL)
+    const bool built_with_reporter = true;
+#elif defined(__has_feature)
+#if __has_feature(address_sanitizer) || __has_feature(thread_sanitizer) || __has_feature(memory_sanitizer) || __has_feature(undefined_behavior_sanitizer)
+    const bool built_with_reporter = true;
+#else
+    const bool built_with_reporter = false;
+#endif
+#else
+    const bool built_with_reporter = false;
+#endif
+    bool hooked = built_with_reporter;
+    for (const char *name : {"HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD", "ASAN_OPTIONS", "TSAN_OPTIONS", "UBSAN_OPTIONS",
+                             "LSAN_OPTIONS", "MSAN_OPTIONS", "LLVM_PROFILE_FILE", "GCOV_PREFIX"})
+        if (getenv(name)) hooked = true;
+    if (const char *preload = getenv("LD_PRELOAD"))
+        for (const char *lib : {"rocprof", "roctracer", "libasan", "libtsan", "libubsan", "liblsan", "libmsan", "libclang_rt", "libprofiler", "gcov"})
+            if (strstr(preload, lib)) hooked = true;
     const bool fast_exit = mode ? strcmp(mode, "fast") == 0 : !hooked;
+    if (const char *t = getenv("PCQ_TIMING"))
+        if (t[0] == '1') fprintf(stderr, "[pcq] process exit: %s (%s)\n", fast_exit ? "fast (_exit once the answer is flushed)" : "full (normal return)",
+                                 mode ? "PCQ_EXIT" : hooked ? "something reports at exit" : "default");
     pcq::contexts_die_with_the_process(fast_exit);
     const int rc = pcq::query_main(
         argc, argv,
@@ -35,5 +56,6 @@ int main(int argc, char **argv) {
         });
     fflush(nullptr);
     if (fast_exit) _exit(rc);
+    pcq::release_thread_contexts();  // the main thread's own (sequential driver): before the exit phase, like the workers' (core.cpp)
     return rc;
 }

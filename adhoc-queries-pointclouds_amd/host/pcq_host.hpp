@@ -82,11 +82,17 @@ public:
     const uint8_t *data() const { return data_; }
     size_t size() const { return size_; }
     int fd() const { return fd_; }  // kept open: column blocks are streamed with pread (pcq_scan_fd)
+    // which file this was when it was opened: device, inode, size, modification time (st_mtim)
+    uint64_t dev() const { return dev_; }
+    uint64_t ino() const { return ino_; }
+    int64_t mtime_ns() const { return mtime_ns_; }
 
 private:
     const uint8_t *data_ = nullptr;
     size_t size_ = 0;
     int fd_ = -1;
+    uint64_t dev_ = 0, ino_ = 0;
+    int64_t mtime_ns_ = 0;
 };
 
 // One GPU context per (thread, device); created on first use, destroyed with the thread.
@@ -95,6 +101,8 @@ Status thread_context(int device, pcq_ctx **out);
 // streams, events, pinned and device memory one by one (main.cpp).  Off by default: a library user's threads release what
 // they created.
 void contexts_die_with_the_process(bool yes);
+// Releases the calling thread's contexts now (no-op once contexts_die_with_the_process(true)): see core.cpp.
+void release_thread_contexts();
 
 // ---- collect_points.rs ------------------------------------------------------------------------
 // The per-match `collect_one(Point)` callback of the reference does not exist here: matches are
@@ -157,7 +165,9 @@ struct FilePlan {
     bool needs_gpu = false;      // false: resolved on the host
     int las_record_size = -1;    // las.rs:73 (printed even for a file that is then skipped)
     std::string path;            // opened again by execute_plan, for the duration of the scan
-    uint64_t file_size = 0;      // as the prologue saw it
+    uint64_t file_size = 0;      // as the prologue saw it; and WHICH file it saw — execute_plan opens the path again and the
+    uint64_t file_dev = 0, file_ino = 0;  // offsets, scale and point count of the plan hold for that file only: one that was
+    int64_t file_mtime_ns = 0;            // replaced or rewritten in between is an error, not a scan with the old header
     pcq_columns cols{};          // the column "pointers" are byte offsets into the file (pcq_scan_fd)
     pcq_predicate pred{};
 };
@@ -274,7 +284,36 @@ struct RunOptions {
     // the factory makes grid collectors (--density): every file ends on a fold, i.e. on a synchronisation (see threads_per_device)
     bool collectors_fold_per_file = false;
     std::vector<FileStat> *stats = nullptr;
+    // Test hooks, set only by the test entry of the C view (capi.cpp: pcq_query_main_with_hooks) — nothing in the `query`
+    // binary reads the environment for them.  device_slots: the device list as given, repeats allowed ("0,0" = two device
+    // SLOTS on one physical GPU, each with its own workers, contexts and counter block, merged like two GPUs; RCCL refuses
+    // a communicator over a repeated device, which is the failure the merge's fallback exists for).  allreduce_fail: make
+    // the count merge's collective fail through the real RCCL calls, 1 = before anything is touched, 2 = after the reduction.
+    std::vector<int> test_device_slots;
+    int test_allreduce_fail = 0;
 };
+
+// Files of a parallel query over device slots.  main.rs:153-161 hands files to whichever rayon thread is free; with a GPU
+// behind every slot, a slot whose context is still coming up (50-230 ms of HIP start-up) must not find the queue drained by
+// the slot that was ready first — and a slot that is ready must not idle next to files nobody has started.  So every slot
+// starts with its OWN share, longest-processing-time first by planned points (the rule sharding.py applies across
+// processes: equal files give file i -> slot i % N), takes its own files largest first, and once its share is gone takes
+// the smallest file left on the slot with the most work left.  Thread-safe.
+class FileScheduler {
+  public:
+    static constexpr size_t npos = (size_t)-1;
+    FileScheduler(const std::vector<uint64_t> &cost, size_t nslots);
+    size_t next(size_t slot);                                   // a file for a worker of `slot`, or npos when every file is taken
+    size_t home_slot(size_t file) const { return home_[file]; }  // the slot the file was assigned to at the start
+  private:
+    struct Impl;
+    std::shared_ptr<Impl> impl_;
+    std::vector<size_t> home_;
+};
+// The schedule `nslots` workers (one per slot) produce when slot k's context is ready at ready_ms[k] and a file costs
+// ms_per_unit x cost: slot_of_file[i] = the slot that scanned file i; returns the time the last worker finishes.
+double simulate_schedule(const std::vector<uint64_t> &cost, const std::vector<double> &ready_ms, double ms_per_unit, std::vector<int> *slot_of_file);
+
 // stdout lines go through `print` (so tests can capture them).
 using PrintFn = std::function<void(const std::string &)>;
 Status run_search_sequential(const std::vector<std::string> &files, const Searcher &searcher, SearchImplementation impl,
@@ -311,6 +350,6 @@ private:
 };
 
 // The whole CLI (main.rs:191-319): returns the process exit code; stdout/stderr text via callbacks.
-int query_main(int argc, const char *const *argv, const PrintFn &out, const PrintFn &err);
+int query_main(int argc, const char *const *argv, const PrintFn &out, const PrintFn &err, const RunOptions *test_hooks = nullptr);
 
 }  // namespace pcq

@@ -5,6 +5,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <cerrno>
 #include <chrono>
 #include <cmath>
@@ -267,6 +268,73 @@ Status run_search_sequential(const std::vector<std::string> &files, const Search
     return Status::Ok();
 }
 
+// ---- file -> device slot (pcq_host.hpp) -----------------------------------------------------------------
+struct FileScheduler::Impl {
+    std::mutex mu;
+    std::vector<std::deque<size_t>> q;  // per slot: its files, largest first
+    std::vector<uint64_t> left;         // per slot: cost not yet taken
+    std::vector<uint64_t> cost;
+};
+FileScheduler::FileScheduler(const std::vector<uint64_t> &cost, size_t nslots) : impl_(std::make_shared<Impl>()), home_(cost.size(), 0) {
+    if (nslots < 1) nslots = 1;
+    impl_->q.resize(nslots);
+    impl_->left.assign(nslots, 0);
+    impl_->cost = cost;
+    std::vector<size_t> order(cost.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost[a] > cost[b]; });  // (equal files keep their input order)
+    std::vector<uint64_t> load(nslots, 0);
+    for (size_t i : order) {
+        size_t best = 0;
+        for (size_t k = 1; k < nslots; k++)
+            if (load[k] < load[best]) best = k;
+        load[best] += cost[i] ? cost[i] : 1;
+        impl_->q[best].push_back(i);
+        impl_->left[best] += cost[i];
+        home_[i] = best;
+    }
+}
+size_t FileScheduler::next(size_t slot) {
+    Impl &m = *impl_;
+    std::lock_guard<std::mutex> g(m.mu);
+    if (slot >= m.q.size()) slot = 0;
+    size_t from = slot;
+    bool own = !m.q[slot].empty();
+    if (!own) {  // the slot with the most work left gives up its smallest file
+        from = m.q.size();
+        for (size_t k = 0; k < m.q.size(); k++)
+            if (!m.q[k].empty() && (from == m.q.size() || m.left[k] > m.left[from])) from = k;
+        if (from == m.q.size()) return npos;
+    }
+    size_t f;
+    if (own) f = m.q[from].front(), m.q[from].pop_front();
+    else f = m.q[from].back(), m.q[from].pop_back();
+    m.left[from] -= m.cost[f];
+    return f;
+}
+double simulate_schedule(const std::vector<uint64_t> &cost, const std::vector<double> &ready_ms, double ms_per_unit, std::vector<int> *slot_of_file) {
+    FileScheduler sched(cost, ready_ms.size());
+    std::vector<double> t = ready_ms;
+    std::vector<bool> done(ready_ms.size(), false);
+    slot_of_file->assign(cost.size(), -1);
+    double end = 0;
+    for (;;) {
+        size_t w = ready_ms.size();
+        for (size_t k = 0; k < ready_ms.size(); k++)
+            if (!done[k] && (w == ready_ms.size() || t[k] < t[w])) w = k;  // the worker that asks next
+        if (w == ready_ms.size()) break;
+        const size_t f = sched.next(w);
+        if (f == FileScheduler::npos) {
+            done[w] = true;
+            continue;
+        }
+        (*slot_of_file)[f] = (int)w;
+        t[w] += ms_per_unit * (double)cost[f];
+        if (t[w] > end) end = t[w];
+    }
+    return end;
+}
+
 // main.rs:146-183 — files are independent units: one collector per file.  rayon's par_iter becomes
 // host threads pulling file indices from a shared queue, `threads_per_device` per GPU; each thread
 // owns a GPU context (stream + pinned staging), so host staging copies of one file overlap the
@@ -306,22 +374,15 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
     std::vector<std::unique_ptr<ResultCollector>> collectors(nfiles);
     std::vector<int> file_device(nfiles, -1);
     std::vector<double> file_ms(nfiles, 0.0);
-    std::atomic<size_t> next{0};
     std::vector<int> devices = opt.devices.empty() ? std::vector<int>{0} : opt.devices;
-    // tests: "0,0" = two device SLOTS on one physical GPU — each with its own workers, contexts and counter block, merged like
-    // two GPUs (the tests have one GPU; a communicator over a repeated device is refused by RCCL, which is the failure the
-    // fallback exists for)
-    if (const char *list = getenv("PCQ_TEST_DEVICE_SLOTS")) {
-        devices.clear();
-        for (const char *p = list; *p;) {
-            char *end = nullptr;
-            const long v = strtol(p, &end, 10);
-            if (end == p) break;
-            devices.push_back((int)v);
-            p = *end == ',' ? end + 1 : end;
-        }
-        if (devices.empty()) devices.push_back(0);
-    }
+    if (!opt.test_device_slots.empty()) devices = opt.test_device_slots;  // (tests: device slots, repeats allowed — pcq_host.hpp)
+    // file -> device slot: every slot starts with its own longest-processing-time share (by planned points: 12 B or 1 B a
+    // point all the same, the files of one query have one predicate), so a GPU whose context is still coming up keeps its
+    // files; who runs dry takes from the slot with the most left (FileScheduler)
+    std::vector<uint64_t> work_cost(work.size(), 1);
+    for (size_t w = 0; w < work.size(); w++)
+        if (plans[work[w]]) work_cost[w] = plans[work[w]]->cols.n ? plans[work[w]]->cols.n : 1;
+    FileScheduler sched(work_cost, devices.size());
     int tpd = opt.threads_per_device;
     if (tpd < 1) {  // not given: two where a second thread pays (pcq_host.hpp), one otherwise
         uint64_t planned_points = 0;
@@ -355,7 +416,10 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         for (size_t w : work)
             if (plans[w]) planned_bytes += (double)plans[w]->cols.n * (plans[w]->pred.kind == PCQ_PRED_CLASS ? 1.0 : 12.0);
         const double scan_seconds = planned_bytes / (40e9 * (double)devices.size());
-        merge_rccl = getenv("PCQ_TEST_ALLREDUCE_FAIL") != nullptr || (policy && !strcmp(policy, "rccl"));
+        merge_rccl = opt.test_allreduce_fail != 0 || (policy && !strcmp(policy, "rccl"));
+        // RCCL's NCCL_DEBUG output belongs on stderr (collective.hip); the environment is written HERE, before any other thread
+        // of this query exists — the workers read the environment (PCQ_TIMING) while the communicator is being built
+        if (merge_rccl) setenv("NCCL_DEBUG_FILE", "/dev/stderr", 0);
         if (timing)
             fprintf(stderr, "[pcq] count merge: %s (estimated scan time %.2f s on %zu GPU(s))\n", merge_rccl ? "RCCL all-reduce" : devices.size() > 1 ? "host sum of the per-GPU counts" : "one GPU, its counter is the total",
                     scan_seconds, devices.size());
@@ -398,8 +462,8 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
                 counter = dev_counter[dslot];
             }
             for (;;) {
-                const size_t w = next.fetch_add(1);
-                if (w >= work.size()) break;
+                const size_t w = sched.next(dslot);
+                if (w == FileScheduler::npos) break;
                 const size_t i = work[w];
                 if (!cst.ok()) {
                     results[i] = cst;
@@ -428,6 +492,8 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
             for (size_t i = 0; i < nfiles; i++)
                 if (collectors[i] && collectors[i]->context() == ctx) collectors[i].reset();
             if (counter && dev_ctx[dslot] == ctx) pcq_device_free(ctx, counter);
+            lk.unlock();
+            release_thread_contexts();  // here, not in the thread-exit phase (core.cpp)
         });
     }
     {
@@ -435,6 +501,9 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         cv.wait(lk, [&] { return finished == nthreads; });
     }
     if (timing) fprintf(stderr, "[pcq] all workers done %.1f ms after the search started\n", since());
+    // The communicator's thread redirects descriptor 1 while RCCL prints its banner (collective.hip): it has ended before
+    // this function prints its first line behind the scans.
+    if (comm_thread.joinable()) comm_thread.join();
     Status final_status = Status::Ok();
     for (size_t i = 0; i < nfiles; i++)
         if (logs[i].las_record_size >= 0) print("Point record size: " + std::to_string(logs[i].las_record_size));
@@ -458,9 +527,9 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         if (!ctxs.empty() && !merge_rccl && ctxs.size() > 1) {
             total = merge_counts_on_host(ctxs, sends, &final_status);  // (a short query: RCCL would take longer to load than the scans took)
         } else if (!ctxs.empty()) {
-            if (const char *inj = getenv("PCQ_TEST_ALLREDUCE_FAIL")) {  // tests: make the collective fail ("early" / "late"), through the real RCCL calls
+            if (opt.test_allreduce_fail) {  // tests: make the collective fail (1 early / 2 late), through the real RCCL calls
                 (void)pcq_set_option(ctxs[0], "allreduce_single_rank", 1);
-                (void)pcq_set_option(ctxs[0], "allreduce_fail", !strcmp(inj, "late") ? 2 : 1);
+                (void)pcq_set_option(ctxs[0], "allreduce_fail", opt.test_allreduce_fail == 2 ? 2 : 1);
             }
             Status ast = Status::FromLib(pcq_allreduce_sum_u64(ctxs.data(), sends.data(), recvs.data(), (int)ctxs.size()));
             if (ast.ok()) {
@@ -496,7 +565,7 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
 }
 
 // ---- main.rs:191-319 ---------------------------------------------------------------------------------------------
-int query_main(int argc, const char *const *argv, const PrintFn &out, const PrintFn &err) {
+int query_main(int argc, const char *const *argv, const PrintFn &out, const PrintFn &err, const RunOptions *test_hooks) {
     const auto t_start = std::chrono::steady_clock::now();  // :192
     std::optional<std::string> input, bounds_s, class_s, output, density_s, stats_json;
     std::vector<FileStat> file_stats;
@@ -504,6 +573,7 @@ int query_main(int argc, const char *const *argv, const PrintFn &out, const Prin
     RunOptions opt;
     opt.devices = {0};
     opt.collectors_yield_points = true;
+    if (test_hooks) opt.test_device_slots = test_hooks->test_device_slots, opt.test_allreduce_fail = test_hooks->test_allreduce_fail;
     for (int i = 1; i < argc; i++) {
         const std::string a = argv[i];
         std::optional<std::string> *dst = nullptr;

@@ -120,6 +120,14 @@ Status execute_plan(FilePlan &plan, ResultCollector &rc) {
         ::close(fd);
         return Status::Err(PCQ_ERR_EOF, "failed to fill whole buffer");
     }
+    // The reference opens a file once, inside its task (last.rs:51); here the header was read by the prologue and the path
+    // is opened again.  Another file under the same name — replaced, or rewritten in place — must not be scanned with the
+    // first one's offsets, scale and point count.
+    if ((uint64_t)st.st_dev != plan.file_dev || (uint64_t)st.st_ino != plan.file_ino || (uint64_t)st.st_size != plan.file_size ||
+        (int64_t)st.st_mtim.tv_sec * 1000000000ll + st.st_mtim.tv_nsec != plan.file_mtime_ns) {
+        ::close(fd);
+        return Status::Err(PCQ_ERR_IO, plan.path + ": the file changed while the query was running");
+    }
     const int r = pcq_scan_fd(rc.context(), fd, &cols, &plan.pred, rc.handle());
     ::close(fd);
     rc.next_index += cols.n;
@@ -144,6 +152,7 @@ FilePlan gpu(const std::string &path, const MappedFile &file, pcq_columns cols, 
     plan.needs_gpu = true;
     plan.path = path;
     plan.file_size = file.size();
+    plan.file_dev = file.dev(), plan.file_ino = file.ino(), plan.file_mtime_ns = file.mtime_ns();
     plan.cols = cols;
     plan.pred = pred;
     return plan;

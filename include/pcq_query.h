@@ -83,6 +83,17 @@ int pcq_query_resident_count_class(pcq_host_resident *r, uint8_t cls, uint64_t *
 /* The whole CLI in-process (main.rs:191-319); returns the exit code. */
 int pcq_query_main(int argc, const char *const *argv);
 
+/* Test entries (the `query` binary cannot reach them).
+ * pcq_query_main_with_hooks: the CLI with the parallel driver's test hooks — device_slots: a "0,0"-style device list, repeats
+ * allowed (two device SLOTS on one GPU run the N > 1 paths of main.rs:146-183's merge), or NULL; allreduce_fail: 0, or make the
+ * count merge's collective fail through the real RCCL calls, 1 = before anything is touched, 2 = after the reduction ran.
+ * pcq_query_simulate_schedule: the file -> device-slot schedule of the parallel driver (every slot starts with its own
+ * longest-processing-time share; a slot that runs dry takes from the fullest) when slot k's context is ready at ready_ms[k]
+ * and a file costs ms_per_unit x cost[i]; home_slot (may be NULL) = the share a file started in.  No GPU involved. */
+int pcq_query_main_with_hooks(int argc, const char *const *argv, const char *device_slots, int allreduce_fail);
+int pcq_query_simulate_schedule(const uint64_t *cost, size_t nfiles, const double *ready_ms, int nslots, double ms_per_unit,
+                                int *slot_of_file, int *home_slot, double *makespan_ms);
+
 #ifdef __cplusplus
 }
 #endif

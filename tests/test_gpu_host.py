@@ -317,6 +317,24 @@ QUERY = os.path.join(PKG, "host", "query")
 ORACLE_CLI = os.path.join(ROOT, "oracle", "query_oracle")
 
 
+def _cli_hooks(args, device_slots=None, allreduce_fail=0, env=None):
+    """The CLI through the test entry of the C view (pcq_query_main_with_hooks): a process of its own, like the binary, with
+    the parallel driver's test hooks — which the `query` binary cannot reach (no environment variable sets them)."""
+    code = ("import ctypes as C, sys\n"
+            "lib = C.CDLL(%r)\n"
+            "argv = ['query'] + sys.argv[3:]\n"
+            "arr = (C.c_char_p * len(argv))(*[a.encode() for a in argv])\n"
+            "slots = sys.argv[1].encode() if sys.argv[1] != '-' else None\n"
+            "rc = lib.pcq_query_main_with_hooks(len(argv), arr, slots, int(sys.argv[2]))\n"
+            "sys.stdout.flush()\n"
+            "sys.exit(rc)\n") % os.path.join(PKG, "libpcq_query.so")
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, "-c", code, device_slots or "-", str(allreduce_fail)] + args, capture_output=True, text=True, env=e)
+    lines = r.stdout.splitlines()
+    return r.returncode, [l for l in lines if not l.startswith("Searched ")], [l for l in lines if l.startswith("Searched ")], r.stderr
+
+
 @pytest.mark.parametrize("mode", [["--parallel"], []])
 @pytest.mark.parametrize("query_args", [["--bounds", "90;-250;0;120;-150;20"], ["--bounds", "0;-400;-100;200;0;100"],
                                         ["--class", "6"], ["--class", "19"], ["--bounds", "500;500;500;600;600;600"],
@@ -429,7 +447,7 @@ def test_cli_query_resolved_on_the_host_never_wakes_the_gpu(files):
         assert rc_p == rc_o == 0 and sorted(body_p) == sorted(body_o) and "context on device" not in err_p
 
 
-@pytest.mark.parametrize("when", ["early", "late"])
+@pytest.mark.parametrize("when", ["early", "late", "group"])
 def test_cli_count_merge_survives_a_failing_allreduce(files, when):
     """main.rs:164-180 on several GPUs is one RCCL all-reduce of the per-GPU counters.  When the collective fails — before
     it touched anything, or after the reduction had run on every rank (a late stream error) — the CLI sums the per-GPU
@@ -439,28 +457,28 @@ def test_cli_count_merge_survives_a_failing_allreduce(files, when):
     d = os.path.dirname(files[0])
     for query_args in (["--bounds", "0;-400;-100;200;0;100"], ["--class", "6"]):
         args = ["-i", d, "--optimized", "--parallel"] + query_args
-        rc_p, body_p, _, err_p = _cli(QUERY, args, env={"PCQ_TEST_ALLREDUCE_FAIL": when})
+        rc_p, body_p, _, err_p = _cli_hooks(args, allreduce_fail={"early": 1, "late": 2, "group": 3}[when])
         rc_o, body_o, _, _ = _cli(ORACLE_CLI, args)
         assert rc_p == rc_o == 0, err_p
         assert sorted(body_p) == sorted(body_o)
         assert "all-reduce of the per-GPU counts failed" in err_p and "injected failure" in err_p and "summing on the host" in err_p
-        assert ("before the reduction" if when == "early" else "after the reduction") in err_p
+        assert {"early": "before the reduction", "late": "after the reduction", "group": "inside the group"}[when] in err_p
 
 
 @pytest.mark.parametrize("merge", ["auto", "host", "rccl"])
 def test_cli_two_device_slots_merge_like_two_gpus(files, merge, tmp_path):
-    """The N > 1 paths of run_search_parallel on the one GPU the tests have: PCQ_TEST_DEVICE_SLOTS=0,0 gives two device slots
+    """The N > 1 paths of run_search_parallel on the one GPU the tests have: device slots "0,0" (the test entry pcq_query_main_with_hooks) give two device slots
     (own workers, own contexts, own two-word counter block each).  Count queries: the short query sums the two counter blocks on
     the host (auto, host); PCQ_MERGE=rccl asks for the all-reduce, RCCL refuses a communicator over a repeated device — a real
     failure of the real library, not an injected one — and the host sum answers with the warning.  Queries whose collectors
     yield points merge per file and need no collective.  stdout is the oracle's in every case."""
     d = os.path.dirname(files[0])
-    env = {"PCQ_TEST_DEVICE_SLOTS": "0,0", "PCQ_TIMING": "1"}
+    env = {"PCQ_TIMING": "1"}
     if merge != "auto":
         env["PCQ_MERGE"] = merge
     for query_args in (["--bounds", "0;-400;-100;200;0;100"], ["--class", "6"], ["--bounds", "0;-400;-100;200;0;100", "--density", "5"]):
         args = ["-i", d, "--optimized", "--parallel"] + query_args
-        rc_p, body_p, _, err_p = _cli(QUERY, args + ["--threads-per-gpu", "2"], env=env)
+        rc_p, body_p, _, err_p = _cli_hooks(args + ["--threads-per-gpu", "2"], device_slots="0,0", env=env)
         rc_o, body_o, _, _ = _cli(ORACLE_CLI, args)
         assert rc_p == rc_o == 0, err_p
         assert sorted(body_p) == sorted(body_o)
@@ -477,7 +495,7 @@ def test_cli_two_device_slots_merge_like_two_gpus(files, merge, tmp_path):
             out = tmp_path / ("o" + str(len(slots)))
             out.mkdir()
             args = ["-i", d, "--optimized", "--parallel", "--bounds", "0;-400;-100;200;0;100", "-o", str(out), "--threads-per-gpu", "2"]
-            rc, body, _, err = _cli(QUERY, args, env={"PCQ_TEST_DEVICE_SLOTS": slots})
+            rc, body, _, err = _cli_hooks(args, device_slots=slots)
             assert rc == 0, err
             outs.append((sorted(body), {f: open(out / f, "rb").read() for f in sorted(os.listdir(out))}))
         assert outs[0] == outs[1] and len(outs[0][1]) > 0

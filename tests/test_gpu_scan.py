@@ -573,16 +573,21 @@ def test_allreduce_single_rank_through_the_real_rccl_calls(gpu_ctx):
         assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, send, 1) == 0  # in place is allowed
         assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, recv, 2) == -8  # PCQ_ERR_ARG: both on device 0
         assert b"one rank per GPU" in gpu_ctx.lib.pcq_last_error()
-        for mode, where in ((1, b"before"), (2, b"after")):
+        for mode, where in ((1, b"before"), (2, b"after"), (3, b"inside the group")):
             gpu_ctx.to_device(d + 8, np.array([0], dtype=np.uint64))
             gpu_ctx.set_option("allreduce_fail", mode)
             assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, recv, 1) != 0
             assert b"injected failure" in gpu_ctx.lib.pcq_last_error() and where in gpu_ctx.lib.pcq_last_error()
             gpu_ctx.set_option("allreduce_fail", 0)
-            gpu_ctx.to_host(out, d)
+            gpu_ctx.to_host(out, d)  # (reads on the context's stream: a collective left half-enqueued there would hang this)
             assert int(out[0]) == 98765432109876543                      # what was sent is what the fallback reads
-            assert int(out[1]) == (0 if mode == 1 else 98765432109876543)  # the late failure comes after the reduction ran
-        assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, recv, 1) == 0  # and the next collective is not swallowed
+            if mode != 3:  # (a failure inside the group aborts the communicator: the reduction may or may not have run)
+                assert int(out[1]) == (0 if mode == 1 else 98765432109876543)  # the late failure comes after the reduction ran
+            # the next collective is not swallowed — after mode 3 on a communicator built anew (the aborted one is gone)
+            gpu_ctx.to_device(d + 8, np.array([0], dtype=np.uint64))
+            assert gpu_ctx.lib.pcq_allreduce_sum_u64(ctxs, send, recv, 1) == 0, gpu_ctx.lib.pcq_last_error()
+            gpu_ctx.to_host(out, d)
+            assert [int(v) for v in out] == [98765432109876543, 98765432109876543]
     finally:
         gpu_ctx.set_option("allreduce_fail", 0)
         gpu_ctx.set_option("allreduce_single_rank", 0)
