@@ -175,6 +175,7 @@ def load_library() -> C.CDLL:
         "pcq_scan_host": (C.c_int, [vp, P(Columns), P(Predicate), vp]),
         "pcq_scan_fd": (C.c_int, [vp, C.c_int, P(Columns), P(Predicate), vp]),
         "pcq_scan_host_nowait": (C.c_int, [vp, P(Columns), P(Predicate), vp]),
+        "pcq_scan_fd_nowait": (C.c_int, [vp, C.c_int, P(Columns), P(Predicate), vp]),
         "pcq_scan_dev_count_batch": (C.c_int, [vp, P(Columns), P(Predicate), C.c_size_t, vp, vp]),
         "pcq_allreduce_sum_u64": (C.c_int, [P(vp), P(vp), P(vp), C.c_int]),
         "pcq_allreduce_prepare": (C.c_int, [P(C.c_int), C.c_int]),
@@ -392,6 +393,10 @@ class Context:
     def scan_fd(self, fd: int, cols: Columns, pred: Predicate, coll: Collector) -> None:
         """Like scan_host, with the column pointers given as byte offsets into the open file `fd`."""
         _check(self.lib.pcq_scan_fd(self.handle, fd, C.byref(cols), C.byref(pred), coll.handle))
+
+    def scan_fd_nowait(self, fd: int, cols: Columns, pred: Predicate, coll: Collector) -> None:
+        """scan_fd that returns once the file has been read and its last kernels are enqueued; results after synchronize() / accessors."""
+        _check(self.lib.pcq_scan_fd_nowait(self.handle, fd, C.byref(cols), C.byref(pred), coll.handle))
 
     def scan_dev_count_batch(self, cols: Sequence[Columns], preds: Sequence[Predicate], device_total: int,
                              stream: Optional[int] = None) -> None:

@@ -123,10 +123,18 @@ __host__ __device__ __forceinline__ uint32_t tuple_bytes(bool wide) { return wid
 struct GridEntryDev {
     double scale[3], offset[3];
     int32_t lo[3];       // 16-byte tuples: subtracted from the coordinates (the query box's low corner; 0 for a class query)
-    uint32_t cmask[3];   // 16-byte tuples: the bits of each stored word that are coordinate (0x00ffffff on the axis that carries the class)
+    uint32_t cmask[3];   // 16-byte tuples: the bits of each stored word that are coordinate (0x00ffffff where the top byte carries something)
     uint32_t cls_const;  // 16-byte tuples without a class byte: the class of every tuple
-    uint32_t _pad;
+    uint32_t fmt;        // 16-byte tuples: what the three top bytes T = x.top | y.top << 8 | z.top << 16 carry — bits 0-7: shift of the
+                         // class byte in T (0xff: none, the class is cls_const); bits 8-15 / 16-23: shifts of the low / high byte of
+                         // the second level's selector (sel16_of; 0xff: not stored) — pass 0 has the hash at hand, and when all three
+                         // sides of the query box are below 2^24 there are two top bytes to spare
 };
+constexpr uint32_t FMT_NONE = 0xffu;
+__host__ __device__ __forceinline__ uint32_t fmt_cls_shift(uint32_t fmt) { return fmt & 0xffu; }
+__host__ __device__ __forceinline__ uint32_t fmt_sel_lo_shift(uint32_t fmt) { return (fmt >> 8) & 0xffu; }
+__host__ __device__ __forceinline__ uint32_t fmt_sel_hi_shift(uint32_t fmt) { return (fmt >> 16) & 0xffu; }
+__host__ __device__ __forceinline__ bool fmt_has_sel(uint32_t fmt) { return fmt_sel_lo_shift(fmt) != FMT_NONE; }
 
 // Tuples cut into partitions, back to back or in regions (the second level's output): partition p is the tuples
 // off[p] .. off[p] + cnt[p] — or, without cnt, .. off[p + 1] — of `tuples`, `wide` saying how long a tuple is.
@@ -309,26 +317,38 @@ struct EntryRef {
     GridEntryDev e0;
     // (written field by field with explicit global loads: as `id == 0 ? e0 : table[id]` the compiler selects between the
     // two ADDRESSES — kernel argument segment or table — and loads six doubles through flat instructions for every tuple)
+    // MULTI = false (the caller KNOWS this fold has one entry): no load at all.  Not a detail: a global load in a branch
+    // makes the compiler wait for EVERY outstanding load where the branch joins (one counter, in order), so a kernel that
+    // keeps the next chunk of tuples in flight while it computes must not contain one on its hot path — the streaming fold
+    // waited for its prefetch at the first decode until the entry lookups became compile-time (profiles/r04_grid_progress.txt).
+    template <bool MULTI = true>
     __device__ __forceinline__ GridEntryDev get(uint32_t id) const {
         GridEntryDev e = e0;
-        if (id != 0) {
+        if (MULTI && id != 0) {
             const double *src = reinterpret_cast<const double *>(table + id);
 #pragma unroll
             for (int a = 0; a < 3; a++) e.scale[a] = ldg(src + a), e.offset[a] = ldg(src + 3 + a);
         }
         return e;
     }
-    __device__ __forceinline__ uint32_t entry_of(uint32_t idx) const { return multi ? (uint32_t)ldg(tile_entry + idx / (uint32_t)P0_TILE) : 0u; }
+    template <bool MULTI = true>
+    __device__ __forceinline__ uint32_t entry_of(uint32_t idx) const {
+        if (!MULTI) return 0u;
+        return multi ? (uint32_t)ldg(tile_entry + idx / (uint32_t)P0_TILE) : 0u;
+    }
     // how entry `id` packs its 16-byte tuples
-    __device__ __forceinline__ void packing(uint32_t id, int32_t (&lo)[3], uint32_t (&cmask)[3], uint32_t *cls_const) const {
+    template <bool MULTI = true>
+    __device__ __forceinline__ void packing(uint32_t id, int32_t (&lo)[3], uint32_t (&cmask)[3], uint32_t *cls_const, uint32_t *fmt) const {
 #pragma unroll
         for (int a = 0; a < 3; a++) lo[a] = e0.lo[a], cmask[a] = e0.cmask[a];
         *cls_const = e0.cls_const;
-        if (id != 0) {
+        *fmt = e0.fmt;
+        if (MULTI && id != 0) {
             const uint32_t *src = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(table + id) + offsetof(GridEntryDev, lo));
 #pragma unroll
             for (int a = 0; a < 3; a++) lo[a] = (int32_t)ldg(src + a), cmask[a] = ldg(src + 3 + a);
             *cls_const = ldg(src + 6);
+            *fmt = ldg(src + 7);
         }
     }
 };
@@ -351,46 +371,67 @@ __device__ __forceinline__ RawTuple ld_raw(const uint8_t *p, bool wide) {
     }
     return r;
 }
+template <bool MULTI = true>
 __device__ __forceinline__ GridTuple decode16(const u32x4_a16 &a, const EntryRef &entries) {
     GridTuple t;
-    const uint32_t id = entries.entry_of(a.w);
+    const uint32_t id = entries.entry_of<MULTI>(a.w);
     int32_t lo[3];
-    uint32_t cm[3], cc;
-    entries.packing(id, lo, cm, &cc);
+    uint32_t cm[3], cc, fmt;
+    entries.packing<MULTI>(id, lo, cm, &cc, &fmt);
     t.x = (int32_t)(a.x & cm[0]) + lo[0], t.y = (int32_t)(a.y & cm[1]) + lo[1], t.z = (int32_t)(a.z & cm[2]) + lo[2];
     t.idx = a.w;
-    t.w0 = ((((a.x & ~cm[0]) | (a.y & ~cm[1]) | (a.z & ~cm[2])) >> 24) | cc) | (id << 8);
+    const uint32_t T = (a.x >> 24) | ((a.y >> 24) << 8) | ((a.z >> 24) << 16), cs = fmt_cls_shift(fmt);
+    t.w0 = (cs == FMT_NONE ? cc : (T >> cs) & 0xffu) | (id << 8);
     t.w1 = 0;
     return t;
 }
+// The second level's selector of a 16-byte tuple, when its entry stores it (fmt_has_sel): no cell, no hash.
+__device__ __forceinline__ uint32_t sel16_of_raw(const u32x4_a16 &a, uint32_t fmt) {
+    const uint32_t T = (a.x >> 24) | ((a.y >> 24) << 8) | ((a.z >> 24) << 16);
+    return ((T >> fmt_sel_lo_shift(fmt)) & 0xffu) | (((T >> fmt_sel_hi_shift(fmt)) & 0xffu) << 8);
+}
+// What goes into the top bytes of a 16-byte tuple's coordinates: V = class | sel16 << 8, byte top_shift(axis) / 8 of it.
+__host__ __device__ __forceinline__ uint32_t fmt_top_shift(uint32_t fmt, int axis) {
+    const uint32_t here = 8u * (uint32_t)axis;
+    if (fmt_cls_shift(fmt) == here) return 0u;
+    if (fmt_sel_lo_shift(fmt) == here) return 8u;
+    if (fmt_sel_hi_shift(fmt) == here) return 16u;
+    return 24u;  // (nothing: byte 3 of V is zero)
+}
+template <bool MULTI = true>
 __device__ __forceinline__ GridTuple decode_raw(const RawTuple &r, bool wide, const EntryRef &entries) {
-    if (!wide) return decode16(r.a, entries);
+    if (!wide) return decode16<MULTI>(r.a, entries);
     GridTuple t;
     t.x = (int32_t)r.a.x, t.y = (int32_t)r.a.y, t.z = (int32_t)r.a.z, t.idx = r.a.w;
-    t.w0 = (r.b.x & 0xffff00ffu) | (entries.entry_of(r.a.w) << 8), t.w1 = r.b.y;
+    t.w0 = (r.b.x & 0xffff00ffu) | (entries.entry_of<MULTI>(r.a.w) << 8), t.w1 = r.b.y;
     return t;
 }
-__device__ __forceinline__ GridTuple ld_tuple(const uint8_t *p, bool wide, const EntryRef &entries) { return decode_raw(ld_raw(p, wide), wide, entries); }
+template <bool MULTI = true>
+__device__ __forceinline__ GridTuple ld_tuple(const uint8_t *p, bool wide, const EntryRef &entries) { return decode_raw<MULTI>(ld_raw(p, wide), wide, entries); }
 // the same for a buffer known to hold 16-byte tuples only (the dense fold's input): no format test, one aligned load
+template <bool MULTI = true>
 __device__ __forceinline__ GridTuple ld_tuple16(const uint8_t *p, const EntryRef &entries) {
     const u32x4_a16 a = *(const PCQ_GLOBAL u32x4_a16 *)p;
-    return decode16(a, entries);
+    return decode16<MULTI>(a, entries);
 }
-__device__ __forceinline__ void st_tuple(uint8_t *p, const GridTuple &t, bool wide, const EntryRef &entries) {
-    if (wide) {
-        u32x4_a8 a = {(uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx};
-        u32x2_a8 b = {t.w0 & 0xffff00ffu, t.w1};
-        *(PCQ_GLOBAL u32x4_a8 *)p = a;
-        *(PCQ_GLOBAL u32x2_a8 *)(p + 16) = b;
+// A tuple as it came from memory, written again (the second level, the compaction of sparse bins): the same words when the
+// output has the input's size; a 16-byte tuple into a 24-byte output (some other run of the fold is wide) is decoded first.
+// (A 24-byte tuple never goes into a 16-byte output: the output is wide as soon as one pending run is.)
+template <bool MULTI = true>
+__device__ __forceinline__ void st_raw_as(uint8_t *p, const RawTuple &r, bool wide_in, bool wide_out, const EntryRef &entries) {
+    if (!wide_out) {
+        *(PCQ_GLOBAL u32x4_a16 *)p = r.a;
         return;
     }
-    int32_t lo[3];  // (16-byte output: every input was a 16-byte tuple of this entry, so the coordinates fit its packing)
-    uint32_t cm[3], cc;
-    entries.packing((t.w0 >> 8) & 0xff, lo, cm, &cc);
-    const uint32_t cls = (t.w0 & 0xffu) << 24;
-    u32x4_a16 a = {((uint32_t)(t.x - lo[0]) & cm[0]) | (cls & ~cm[0]), ((uint32_t)(t.y - lo[1]) & cm[1]) | (cls & ~cm[1]),
-                   ((uint32_t)(t.z - lo[2]) & cm[2]) | (cls & ~cm[2]), t.idx};
-    *(PCQ_GLOBAL u32x4_a16 *)p = a;
+    u32x4_a8 a = {r.a.x, r.a.y, r.a.z, r.a.w};
+    u32x2_a8 b = r.b;
+    if (!wide_in) {
+        const GridTuple t = decode16<MULTI>(r.a, entries);
+        a = (u32x4_a8){(uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx};
+        b = (u32x2_a8){t.w0 & 0xffff00ffu, 0u};
+    }
+    *(PCQ_GLOBAL u32x4_a8 *)p = a;
+    *(PCQ_GLOBAL u32x2_a8 *)(p + 16) = b;
 }
 
 struct TupleEval {
@@ -430,15 +471,26 @@ __device__ __forceinline__ TupleEval eval_world(const DevGrid &g, double px, dou
     r.dbits = (uint64_t)__double_as_longlong(centre_dist_fast(g, cf, px, py, pz));
     return r;
 }
-template <typename G>
+template <bool MULTI = true, typename G>
 __device__ __forceinline__ TupleEval eval_tuple(const G &g, const EntryRef &entries, const GridTuple &t) {
-    const GridEntryDev e = entries.get((t.w0 >> 8) & 0xff);
+    const GridEntryDev e = entries.get<MULTI>((t.w0 >> 8) & 0xff);
     return eval_world(g, world(t.x, e.scale[0], e.offset[0]), world(t.y, e.scale[1], e.offset[1]), world(t.z, e.scale[2], e.offset[2]));
 }
 // the second-level partition of a tuple, from its cell (a 16-byte tuple has no room for the 16 hash bits pass 0 had at hand)
-template <typename G>
+template <bool MULTI = true, typename G>
 __device__ __forceinline__ uint32_t tuple_sub(const G &g, const EntryRef &entries, const GridTuple &t, uint32_t f2) {
-    return sub_of(cell_hash(eval_tuple(g, entries, t).key), f2);
+    return sub_of(cell_hash(eval_tuple<MULTI>(g, entries, t).key), f2);
+}
+// The same for a tuple still in its memory form: the selector pass 0 left in it when its entry stores one, its cell otherwise.
+template <bool MULTI = true, typename G>
+__device__ __forceinline__ uint32_t raw_sub(const G &g, const EntryRef &entries, const RawTuple &r, bool wide, uint32_t f2) {
+    if (!wide) {
+        int32_t lo[3];
+        uint32_t cm[3], cc, fmt;
+        entries.packing<MULTI>(entries.entry_of<MULTI>(r.a.w), lo, cm, &cc, &fmt);
+        if (fmt_has_sel(fmt)) return sub_from_sel16(sel16_of_raw(r.a, fmt), f2);
+    }
+    return tuple_sub<MULTI>(g, entries, decode_raw<MULTI>(r, wide, entries), f2);
 }
 // file order among the tuples of a fold: the place in the pending stream; 0 is reserved for an earlier fold's winner
 __device__ __forceinline__ uint64_t ord_of(const GridTuple &t) { return (uint64_t)t.idx + 1; }
@@ -496,11 +548,17 @@ __device__ __forceinline__ uint32_t frag_find(const uint32_t *s_pre, uint32_t nf
     }
     return lo;
 }
+template <bool ANYWIDE = true>
 __device__ __forceinline__ RawTuple frag_ld_raw(const uint32_t *s_pre, const uint64_t *s_addr, uint32_t nfr, uint32_t j, bool *wide) {
     const uint32_t f = frag_find(s_pre, nfr, j);
     const uint64_t a = s_addr[f];
-    *wide = a & 1;
-    return ld_raw(reinterpret_cast<const uint8_t *>(a & ~1ull) + (uint64_t)(j - s_pre[f]) * tuple_bytes(*wide), *wide);
+    *wide = ANYWIDE && (a & 1);
+    const uint8_t *src = reinterpret_cast<const uint8_t *>(a & ~1ull) + (uint64_t)(j - s_pre[f]) * tuple_bytes(*wide);
+    if (ANYWIDE) return ld_raw(src, *wide);
+    RawTuple r;
+    r.a = *(const PCQ_GLOBAL u32x4_a16 *)src;
+    r.b = (u32x2_a8){0u, 0u};
+    return r;
 }
 __device__ __forceinline__ GridTuple frag_ld_tuple(const uint32_t *s_pre, const uint64_t *s_addr, uint32_t nfr, uint32_t j, const EntryRef &entries) {
     const uint32_t f = frag_find(s_pre, nfr, j);
@@ -509,7 +567,8 @@ __device__ __forceinline__ GridTuple frag_ld_tuple(const uint32_t *s_pre, const 
     return ld_tuple(reinterpret_cast<const uint8_t *>(a & ~1ull) + (uint64_t)(j - s_pre[f]) * tuple_bytes(wide), wide, entries);
 }
 
-// body(tuple) for every tuple of bin `bin`, some thread each, no particular order; whole workgroup, ends on a barrier.
+// body(tuple, its words in memory, whether those are 24 bytes) for every tuple of bin `bin`, some thread each, no particular
+// order; whole workgroup, ends on a barrier.
 template <int NT, int FB, int UNROLL, typename F>
 __device__ __forceinline__ void bin_for_each(const BinSrc &S, const EntryRef &entries, uint32_t bin, uint32_t *s_pre, uint64_t *s_addr, F &&body) {
     const uint32_t total = uni32(ldg(S.preT + (size_t)bin * S.Tp1 + S.T));
@@ -520,15 +579,16 @@ __device__ __forceinline__ void bin_for_each(const BinSrc &S, const EntryRef &en
         __syncthreads();
         const uint32_t wend = s_pre[nfr];
         for (uint32_t i0 = j0 + threadIdx.x; i0 < wend; i0 += NT * UNROLL) {  // the loads of UNROLL steps are issued together
-            GridTuple t[UNROLL];
+            RawTuple r[UNROLL];
+            bool rw[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; u++) {
                 const uint32_t j = i0 + u * NT;
-                t[u] = frag_ld_tuple(s_pre, s_addr, nfr, j < wend ? j : wend - 1, entries);
+                r[u] = frag_ld_raw(s_pre, s_addr, nfr, j < wend ? j : wend - 1, &rw[u]);
             }
 #pragma unroll
             for (int u = 0; u < UNROLL; u++)
-                if (i0 + u * NT < wend) body(t[u]);
+                if (i0 + u * NT < wend) body(decode_raw(r[u], rw[u], entries), r[u], rw[u]);
         }
         j0 = wend, f_lo += nfr;
         __syncthreads();  // the window is rewritten
@@ -554,12 +614,37 @@ __device__ __forceinline__ int lds_find_or_insert(uint64_t *s_key, uint64_t key,
 }
 
 
+// Timing stamps (a build with -DPCQ_STAMPS only; tools/patches keeps the recipe): cycles per phase, accumulated per wave
+// and added to stats[16 + i] by lane 0; stats[31] counts the waves.
+#ifdef PCQ_STAMPS
+#define ST_DECL uint64_t st_last_ = __builtin_amdgcn_s_memtime(), st_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define ST(i)                                                  \
+    do {                                                       \
+        const uint64_t st_t_ = __builtin_amdgcn_s_memtime();   \
+        st_acc_[i] += st_t_ - st_last_;                        \
+        st_last_ = st_t_;                                      \
+    } while (0)
+#define ST_FLUSH(stats)                                                                            \
+    do {                                                                                           \
+        if ((threadIdx.x & 63) == 0) {                                                             \
+            for (int i_ = 0; i_ < 12; i_++) atomicAdd(&(stats)[16 + i_], (unsigned long long)st_acc_[i_]); \
+            atomicAdd(&(stats)[31], 1ull);                                                         \
+        }                                                                                          \
+    } while (0)
+#else
+#define ST_DECL
+#define ST(i)
+#define ST_FLUSH(stats)
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------
 // parameter blocks and kernels (defined in the grid_*.hip files, launched by grid_host.hip)
 // ---------------------------------------------------------------------------------------------------------------
 struct P0Pack {
     int32_t lo[3];
     uint32_t cmask[3];
+    uint32_t top_shift[3];  // which byte of V = class | sel16 << 8 rides in each coordinate's top byte (fmt_top_shift)
+    uint32_t block_bytes;   // from one tile's block to the next
 };
 
 struct DevRun {        // one pending pass-0 run
@@ -569,6 +654,7 @@ struct DevRun {        // one pending pass-0 run
     uint32_t ntiles;
     uint32_t wide;
     uint32_t entry;    // the entry its tiles were scanned with
+    uint32_t block_bytes, _pad;  // from one tile's block to the next
 };
 
 struct Level2Params {
@@ -656,16 +742,17 @@ __global__ void k_scan_pieces(const uint64_t *__restrict__ in, uint32_t n, const
 __global__ void k_probe_distinct(BinSrc S, EntryRef entries, DevGrid g, uint64_t *__restrict__ set, uint64_t mask, unsigned long long *__restrict__ distinct);
 // grid_level2.hip
 __global__ void k_level2_direct(Level2Params P);
+template <bool ANYWIDE, bool MULTI>
 __global__ void k_level2(Level2Params P);
 __global__ void k_unpack_old_dir(const uint32_t *__restrict__ ooff2, uint32_t nparts, uint64_t *__restrict__ obase2, uint32_t *__restrict__ ocount2);
 __global__ void k_old_per_bin(const uint32_t *__restrict__ ocount, uint32_t f2old, uint32_t *__restrict__ obin);
 // grid_fold.hip
 template <int NSLOT, int NT, int FOLD_K, int LIMIT, bool BINS, bool DIRECT, int MIN_WAVES>
 __global__ void k_fold(FoldParams P, uint32_t nparts);
-template <int NSLOT, int NT, int FOLD_K, int LIMIT, int MIN_WAVES>
+template <int NSLOT, int NT, int FOLD_K, int LIMIT, int MIN_WAVES, bool WIDE, bool MULTI>
 __global__ void k_fold_dense(DenseParams P, uint32_t nparts);
 // grid_fold_stream.hip
-template <int NSLOT, int NT, int LIMIT, int U>
+template <int NSLOT, int NT, int LIMIT, int U, bool ANYWIDE, bool MULTI>
 __global__ void k_fold_stream(FoldParams P, uint32_t nparts, uint32_t surv_cap, uint4 *__restrict__ surv_scratch);
 // grid_finish.hip
 template <bool EMIT, bool BINS>

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(BLOCK) void k_dir_transpose(const DevRun *__restric
             const DevRun r = runs[lo];
             const uint32_t local = t - r.tile0;
             rowptr = reinterpret_cast<uint64_t>(r.dir + (size_t)local * DIR_STRIDE);
-            tile_addr[t] = reinterpret_cast<uint64_t>(r.tuples + (uint64_t)local * P0_TILE * tuple_bytes(r.wide)) | (r.wide ? 1u : 0u);
+            tile_addr[t] = reinterpret_cast<uint64_t>(r.tuples + (uint64_t)local * r.block_bytes) | (r.wide ? 1u : 0u);
             tile_entry[t] = (uint8_t)r.entry;
         }
         s_rowptr[threadIdx.x] = rowptr;
@@ -104,8 +104,7 @@ __global__ __launch_bounds__(BLOCK) void k_bin_compact(BinSrc S, EntryRef entrie
     const bool wide = a & 1;
     const uint8_t *src = reinterpret_cast<const uint8_t *>(a & ~1ull);
     uint8_t *dst = comp + (uint64_t)(ldg(binbase + bin) + lo) * tuple_bytes(wide_out);
-    for (uint32_t i = 0; i < hi - lo; i++)
-        st_tuple(dst + (uint64_t)i * tuple_bytes(wide_out), ld_tuple(src + (uint64_t)i * tuple_bytes(wide), wide, entries), wide_out, entries);
+    for (uint32_t i = 0; i < hi - lo; i++) st_raw_as(dst + (uint64_t)i * tuple_bytes(wide_out), ld_raw(src + (uint64_t)i * tuple_bytes(wide), wide), wide, wide_out, entries);
 }
 // the directory of the compacted bins: preT[b][t] = (t <= b ? 0 : the bin's tuples), startT = 0, tile_addr[t] = bin t's piece
 __global__ __launch_bounds__(BLOCK) void k_compact_dir(const uint32_t *__restrict__ binbase, const uint8_t *__restrict__ comp, uint32_t wide, uint32_t Tp1,

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(L2_NT) void k_alias_gather(FoldParams P, AliasItem 
     __syncthreads();
     const uint32_t na = s_n;
     uint32_t mine = 0;
-    auto visit = [&](const GridTuple &t) {
+    auto visit = [&](const GridTuple &t, const RawTuple &, bool) {
         const uint64_t key = eval_tuple(P.g, P.entries, t).key;
         bool hit = false;
         for (uint32_t q = 0; q < na && !hit; q++) hit = s_akeys[q] == key;
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(L2_NT) void k_alias_gather(FoldParams P, AliasItem 
         const GridSeg sg = P.seg;
         const bool wide = sg.wide;
         const uint32_t lo = sg.off[p], hi = lo + (sg.cnt ? sg.cnt[p] : sg.off[p + 1] - lo);
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += L2_NT) visit(ld_tuple(sg.tuples + (uint64_t)i * tuple_bytes(wide), wide, P.entries));
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += L2_NT) visit(ld_tuple(sg.tuples + (uint64_t)i * tuple_bytes(wide), wide, P.entries), RawTuple{}, wide);
     }
     if (!EMIT && mine) atomicAdd(cursor, (unsigned long long)mine);
 }

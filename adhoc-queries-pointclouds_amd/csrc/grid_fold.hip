@@ -411,7 +411,9 @@ __device__ __forceinline__ uint32_t lds_insert_dense(uint64_t *s_key, uint64_t k
     }
 }
 
-template <int NSLOT, int NT, int FOLD_K, int LIMIT, int MIN_WAVES>
+// WIDE = false: the second level's output holds 16-byte tuples (one aligned load each); MULTI = false: one entry — no
+// load in a branch anywhere between the tuples' loads and their use (EntryRef::get).  Everything else: <true, true>.
+template <int NSLOT, int NT, int FOLD_K, int LIMIT, int MIN_WAVES, bool WIDE, bool MULTI>
 __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uint32_t nparts) {
     constexpr int CHUNK = NT * FOLD_K;
     __shared__ uint64_t s_key[NSLOT];
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     __shared__ uint32_t s_ncell, s_wsum[NT / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint8_t *tuples = P.tuples;
-    const bool wide = P.wide;
+    const bool wide = WIDE && P.wide;
     const uint32_t ts = tuple_bytes(wide);
     const uint32_t *off = P.off;
     for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
@@ -429,33 +431,68 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     if (threadIdx.x == 0) s_ncell = 0;
     unsigned long long winners = 0;  // thread 0: this workgroup's winners
 
-    uint32_t cur_lo = 0, cur_cnt = 0, nxt_lo = 0, nxt_cnt = 0;
-    uint64_t cur_out = 0, nxt_out = 0;
+    // Three partitions deep: the current one (range, output base, and — 16-byte tuples — its tuples, asked for a whole
+    // partition ago), the next one (range known; its tuples are asked for at the head of this round and have arrived by
+    // the time this partition's winners are stored), and the one behind it (its range is on its way).  A partition is a
+    // chain of latencies — offsets, tuples, three barriers, the stores — and at two workgroups per CU nothing else hid the
+    // tuples' round trip.
+    uint32_t cur_lo = 0, cur_cnt = 0, nxt_lo = 0, nxt_cnt = 0, nn_lo = 0, nn_cnt = 0;
+    uint64_t cur_out = 0, nxt_out = 0, nn_out = 0;
     uint32_t p = blockIdx.x;
     // (the partition's range and output base are the same for the whole workgroup: scalar registers)
     const uint32_t *cntp = P.cnt;
-    if (p < nparts) cur_lo = uni32(off[p]), cur_cnt = cntp ? uni32(cntp[p]) : uni32(off[p + 1]) - cur_lo, cur_out = uni64(P.wbase[p]);
+    auto range_of = [&](uint32_t q, uint32_t *lo, uint32_t *cn, uint64_t *ob) {
+        *lo = uni32(off[q]), *cn = cntp ? uni32(cntp[q]) : uni32(off[q + 1]) - *lo, *ob = uni64(P.wbase[q]);
+    };
+    u32x4_a16 rcur[FOLD_K], rnxt[FOLD_K];
+    auto ask16 = [&](u32x4_a16 (&r)[FOLD_K], uint32_t lo, uint32_t cnt) {
+#pragma unroll
+        for (int k = 0; k < FOLD_K; k++) {
+            const uint32_t i = k * NT + threadIdx.x;
+            r[k] = *(const PCQ_GLOBAL u32x4_a16 *)(tuples + (uint64_t)(lo + (i < cnt ? i : (cnt ? cnt - 1 : 0))) * 16u);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < FOLD_K; k++) rcur[k] = rnxt[k] = (u32x4_a16){0u, 0u, 0u, 0u};
+    if (p < nparts) {
+        range_of(p, &cur_lo, &cur_cnt, &cur_out);
+        if (!WIDE && cur_cnt <= (uint32_t)CHUNK) ask16(rcur, cur_lo, cur_cnt);
+        if (p + gridDim.x < nparts) range_of(p + gridDim.x, &nxt_lo, &nxt_cnt, &nxt_out);
+    }
+    ST_DECL;
     for (; p < nparts; p += gridDim.x) {
-        const uint32_t pn = p + gridDim.x;
-        if (pn < nparts) nxt_lo = uni32(off[pn]), nxt_cnt = cntp ? uni32(cntp[pn]) : uni32(off[pn + 1]) - nxt_lo, nxt_out = uni64(P.wbase[pn]);
+        ST(9);  // (the tail of the round: rotating the registers)
+        const uint32_t pn = p + gridDim.x, pnn = pn + gridDim.x;
+        if (pnn < nparts) range_of(pnn, &nn_lo, &nn_cnt, &nn_out);
+        const bool ask_next = !WIDE && pn < nparts && nxt_cnt <= (uint32_t)CHUNK;
+        if (ask_next) ask16(rnxt, nxt_lo, nxt_cnt);
         const uint32_t cnt = cur_cnt;
         GridTuple tu[FOLD_K];
         if (cnt > (uint32_t)CHUNK) {  // (the same for every thread of the workgroup)
             if (threadIdx.x == 0) P.defer_list[atomicAdd(&P.stats[3], 1ull)] = p;
             cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
+            nxt_lo = nn_lo, nxt_cnt = nn_cnt, nxt_out = nn_out;
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) rcur[k] = rnxt[k];
             continue;
         }
         uint64_t key[FOLD_K], dbits[FOLD_K];
         bool alias[FOLD_K];
+        ST(0);  // ranges of the partition after next, asking for the next one's tuples
 #pragma unroll
         for (int k = 0; k < FOLD_K; k++) {
-            const uint32_t i = k * NT + threadIdx.x;
-            tu[k] = ld_tuple(tuples + (uint64_t)(cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0))) * ts, wide, P.entries);
+            if (WIDE) {
+                const uint32_t i = k * NT + threadIdx.x;
+                const uint8_t *src = tuples + (uint64_t)(cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0))) * ts;
+                tu[k] = ld_tuple<MULTI>(src, wide, P.entries);
+            } else {
+                tu[k] = decode16<MULTI>(rcur[k], P.entries);
+            }
         }
         uint32_t inexact = 0;  // bit k: tuple k is next to a cell boundary (or outside the short computation's range)
 #pragma unroll
         for (int k = 0; k < FOLD_K; k++) {
-            const GridEntryDev e = P.entries.get((tu[k].w0 >> 8) & 0xff);
+            const GridEntryDev e = P.entries.get<MULTI>((tu[k].w0 >> 8) & 0xff);
             const double px = world(tu[k].x, e.scale[0], e.offset[0]), py = world(tu[k].y, e.scale[1], e.offset[1]),
                          pz = world(tu[k].z, e.scale[2], e.offset[2]);
             const CellFast cf = cell_fast(P.g.f, px, py, pz);
@@ -472,14 +509,16 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
 #pragma unroll
                 for (int j = 1; j < FOLD_K; j++)
                     if (j == kk) x = tu[j].x, y = tu[j].y, z = tu[j].z, w0 = tu[j].w0;
-                const GridEntryDev e = P.entries.get((w0 >> 8) & 0xff);
+                const GridEntryDev e = P.entries.get<MULTI>((w0 >> 8) & 0xff);
                 const TupleEval ev = eval_exact(*P.g.full, world(x, e.scale[0], e.offset[0]), world(y, e.scale[1], e.offset[1]), world(z, e.scale[2], e.offset[2]));
 #pragma unroll
                 for (int j = 0; j < FOLD_K; j++)
                     if (j == kk) key[j] = ev.key, dbits[j] = ev.dbits, alias[j] = ev.alias;
             }
         }
+        ST(1);  // decode, cell, key, distance
         __syncthreads();  // the table is clean: the previous partition's winners have reset their slots
+        ST(2);  // barrier: table clean
         int slot[FOLD_K];
         uint32_t fresh_cells = 0;
 #pragma unroll
@@ -493,6 +532,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
             if (alias[k]) atomicOr(&s_aliasbits[sl >> 5], 1u << (sl & 31));
             atomicMin((unsigned long long *)&s_dist[sl], (unsigned long long)dbits[k]);
         }
+        ST(3);  // phase 1: insert, minimum distance
         bool over = false;
         {  // cells of the partition so far, counted per wave; beyond LIMIT the partition is given up (like k_fold: the same fan-out rule)
 #pragma unroll
@@ -508,8 +548,12 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
                 atomicAdd(&P.stats[1], 1ull);
             }
             cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
+            nxt_lo = nn_lo, nxt_cnt = nn_cnt, nxt_out = nn_out;
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) rcur[k] = rnxt[k];
             continue;
         }
+        ST(4);  // cell count + barrier
         bool cand[FOLD_K];
 #pragma unroll
         for (int k = 0; k < FOLD_K; k++) {  // phase 2: among the tuples at the minimum, the earliest in file order
@@ -522,6 +566,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
         // instruction then write one contiguous run of keys (8 bytes each) and of records — with a per-thread order the same
         // instruction wrote every second or third record of a 4 KiB span, and the 8-byte key stores reached the memory side as
         // partial writes (counted: 6.7 GB written and 1.9 GB fetched beyond the tuples for 4.9 GB of winners).
+        ST(5);  // phase 2 + barrier
         uint32_t cnt_k[FOLD_K], rank_k[FOLD_K], wave_total = 0;
 #pragma unroll
         for (int k = 0; k < FOLD_K; k++) {
@@ -539,6 +584,13 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
             before += w < wave ? s_wsum[w] : 0;
             total += s_wsum[w];
         }
+        ST(6);  // ranks + barrier
+        if (ask_next) {  // the next partition's tuples have arrived (asked for three barriers ago) — BEFORE this one's stores are issued:
+                         // loads and stores share one in-order counter, a wait behind the stores would wait for them too
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) asm volatile("" ::"v"(rnxt[k].x), "v"(rnxt[k].y), "v"(rnxt[k].z), "v"(rnxt[k].w));
+        }
+        ST(7);  // the next partition's tuples have arrived
         uint64_t run_base = cur_out + before;  // the first place of this wave's winners of tuple slot k
 #pragma unroll
         for (int k = 0; k < FOLD_K; k++) {
@@ -560,7 +612,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
                 int32_t x = tu[k].x, y = tu[k].y, z = tu[k].z;
                 uint32_t w0 = tu[k].w0;
                 asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w0));
-                st_record(P.wrecs, o, P.entries.get((w0 >> 8) & 0xff), x, y, z, w0, tu[k].w1, R_HAS);
+                st_record(P.wrecs, o, P.entries.get<MULTI>((w0 >> 8) & 0xff), x, y, z, w0, tu[k].w1, R_HAS);
             }
             s_key[sl] = PCQ_EMPTY_KEY, s_dist[sl] = ~0ull, s_ord[sl] = ~0ull;
         }
@@ -569,14 +621,20 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
             P.wcount[p] = total;
             winners += total;
         }
+        ST(8);  // the winners' stores, slots reset
         cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
+        nxt_lo = nn_lo, nxt_cnt = nn_cnt, nxt_out = nn_out;
+#pragma unroll
+        for (int k = 0; k < FOLD_K; k++) rcur[k] = rnxt[k];
     }
     if (threadIdx.x == 0 && winners) atomicAdd(&P.stats[0], winners);
+    ST_FLUSH(P.stats);
 }
 
 // the shapes grid_host.hip launches
 template __global__ void k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, true, false, 4>(FoldParams, uint32_t);
 template __global__ void k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, true, 3>(FoldParams, uint32_t);
-template __global__ void k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, 4>(DenseParams, uint32_t);
+template __global__ void k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, 4, false, false>(DenseParams, uint32_t);
+template __global__ void k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, 4, true, true>(DenseParams, uint32_t);
 
 }  // namespace pcqgrid

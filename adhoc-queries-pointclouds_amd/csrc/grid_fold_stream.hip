@@ -24,6 +24,8 @@ namespace pcqgrid {
 // bin); it finds the fragment its range starts in by a 64-ary search of the bin's prefix row, then takes the fragments 64
 // at a time — lane L holds fragment L's prefix and address — and turns "tuple g of the bin" into an address by a binary
 // search across the lanes (six bpermutes): no window in LDS, nothing shared with the other waves.
+// ANYWIDE = false: every pending run has 16-byte tuples (one aligned load per tuple, four registers in flight); MULTI = false:
+// one entry (EntryRef::get) — the common fold of one file; anything else takes the <true, true> form.
 struct Survivor {   // 32 bytes, two 16-byte words
     int32_t x, y, z;
     uint32_t idx;
@@ -32,12 +34,46 @@ struct Survivor {   // 32 bytes, two 16-byte words
     uint32_t _pad;
 };
 
-template <int NSLOT, int NT, int LIMIT, int U>
+// The table of the streaming fold: key and best distance side by side (one LDS access brings both: a probe that finds its
+// key has the cell's minimum with it), probed with DOUBLE hashing.  With linear probing the 64 lanes of a wave leave the
+// loop together, after the longest cluster any of them ran into — at 3657 cells in 6400 slots that were 8.6 probe rounds
+// per 64 tuples (counted: SQ_INSTS_LDS), a third of the kernel's vector instructions; a second hash gives every key its
+// own sequence (the step is odd and no multiple of 5: coprime with 6400 = 2^8 x 5^2, so a sequence visits every slot).
+struct KeyDist {
+    uint64_t key, dist;
+};
+template <int NSLOT, int LIMIT>
+__device__ __forceinline__ int stream_find_or_insert(KeyDist *s_kd, uint64_t key, uint64_t h, uint32_t *s_ncell, uint64_t *seen) {
+    static_assert(NSLOT == 6400, "the probe step below is chosen coprime with 6400");
+    uint32_t s = slot_of<NSLOT>(h);
+    uint32_t step = ((((uint32_t)(h >> 38)) & 1023u) << 1) | 1u;
+    if (step % 5u == 0) step += 2;
+    for (int probes = 0; probes < NSLOT; probes++) {
+        const uint64_t k = __hip_atomic_load(&s_kd[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const uint64_t d = __hip_atomic_load(&s_kd[s].dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a stale value is only too large)
+        if (k == key) {
+            *seen = d;
+            return (int)s;
+        }
+        if (k == PCQ_EMPTY_KEY) {
+            const uint64_t prev = atomicCAS((unsigned long long *)&s_kd[s].key, (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key);
+            if (prev == PCQ_EMPTY_KEY || prev == key) {
+                *seen = ~0ull;  // (somebody may have been faster: too large is safe)
+                if (prev == PCQ_EMPTY_KEY && atomicAdd(s_ncell, 1u) >= (uint32_t)LIMIT) return -1;
+                return (int)s;
+            }
+        }
+        s += step;
+        if (s >= (uint32_t)NSLOT) s -= NSLOT;
+    }
+    return -1;
+}
+
+template <int NSLOT, int NT, int LIMIT, int U, bool ANYWIDE, bool MULTI>
 __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t nparts, uint32_t surv_cap, uint4 *__restrict__ surv_scratch) {
     constexpr int SPT = (NSLOT + NT - 1) / NT;  // slots per thread in the compaction
     constexpr int NW = NT / 64;
-    __shared__ uint64_t s_key[NSLOT];
-    __shared__ uint64_t s_dist[NSLOT];   // f64 bits of the best squared distance (monotone for d >= 0)
+    __shared__ __attribute__((aligned(16))) KeyDist s_kd[NSLOT];  // key; f64 bits of the best squared distance (monotone for d >= 0)
     __shared__ uint32_t s_ord[NSLOT];    // file order (+ 1) of the winner: 0 = an earlier fold's winner, ~0 = none yet
     __shared__ uint32_t s_widx[NSLOT];   // the winner's place in the survivor list (an earlier fold's winner: its index among the partition's old winners)
     __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32];
@@ -45,12 +81,13 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const BinSrc &S = P.src;
     uint4 *surv = surv_scratch + (size_t)blockIdx.x * surv_cap * 2;
+    ST_DECL;
     for (uint32_t it = blockIdx.x; it < nparts; it += gridDim.x) {
         const uint32_t p = xcd_order(it, nparts);
         const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
         const uint64_t old_base = P.okeys ? P.obase[p] : 0;
         const uint64_t out_base = P.wbase[p];
-        for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0u;
+        for (int t = threadIdx.x; t < NSLOT; t += NT) s_kd[t].key = PCQ_EMPTY_KEY, s_kd[t].dist = ~0ull, s_ord[t] = ~0u;
         for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
         if (threadIdx.x == 0) s_ncell = 0, s_over = 0, s_nsurv = 0;
         __syncthreads();
@@ -58,7 +95,8 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
         // earlier winners first: their distance is recomputed from the record (same f64 expressions, same bits)
         for (uint32_t i = threadIdx.x; i < n_old; i += NT) {
             const uint64_t key = P.okeys[old_base + i];
-            const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, key, cell_hash(key), &s_ncell);
+            uint64_t unused;
+            const int s = stream_find_or_insert<NSLOT, LIMIT>(s_kd, key, cell_hash(key), &s_ncell, &unused);
             if (s < 0) {
                 s_over = 1;
                 continue;
@@ -76,12 +114,20 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                 const DevGrid &gf = *P.g.full;
 #pragma unroll
                 for (int a = 0; a < 3; a++) cell[a] = (key >> gf.shift[a]) & gf.mask[a];  // not aliased: unmasked == masked
-                s_dist[s] = (uint64_t)__double_as_longlong(centre_dist(gf, cell, ox, oy, oz));
+                s_kd[s].dist = (uint64_t)__double_as_longlong(centre_dist(gf, cell, ox, oy, oz));
             }
         }
         if (n_old) __syncthreads();
+        ST(0);  // clear + earlier winners
 
         // ---- 1. the stream: this wave's tuples g_lo .. g_hi of the bin ----
+        // Two stages, one chunk (U x 64 tuples) apart: ISSUE turns the chunk's tuple numbers into addresses and asks for the
+        // tuples; PROCESS folds the chunk asked for a round earlier — so a wave always has a chunk in flight while it computes
+        // (as one stage, its waves waited 58 % of their cycles: search chain, memory round trip and arithmetic one after the
+        // other; profiles/r04_grid_progress.txt).  The issue side carries its own batch — fragments f0 .. f0 + 63, lane L
+        // holds fragment f0 + L: the bin's tuples in front of it, and the address its tuple 0 WOULD have (fragment address -
+        // prefix x tuple size, | 1 for 24-byte tuples: the address of tuple q is that + q x size) — and the next batch's,
+        // asked for when the current one is entered.
         {
             const uint32_t *pre = S.preT + (size_t)p * S.Tp1;
             const uint32_t total = uni32(ldg(pre + S.T));
@@ -98,62 +144,105 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                     f_n = f_lo + f_n - nf < step ? f_lo + f_n - nf : step;
                     f_lo = nf;
                 }
-                uint32_t f0 = uni32(f_lo);
-                uint32_t g = g_lo;  // the next tuple of the wave's share
-                while (g < g_hi) {
-                    // a batch: fragments f0 .. f0 + 63, lane L holds fragment f0 + L: its prefix, its address | wide
+                struct Batch {
+                    uint32_t myp, vb_lo, vb_hi;  // per lane
+                    uint32_t b_end;              // tuples of the bin in front of the next batch (the same in every lane)
+                };
+                auto load_batch = [&](uint32_t f0) {
+                    Batch B;
                     const uint32_t f = f0 + lane;
                     const bool fv = f < S.T;
-                    const uint32_t myp = ldg(pre + (fv ? f : S.T));
-                    const uint32_t b_end = uni32(ldg(pre + (f0 + 64 < S.T ? f0 + 64 : S.T)));  // tuples of the bin in front of the next batch
-                    uint64_t faddr = 0;
-                    if (fv) faddr = frag_addr(S, p, f);
-                    const uint32_t fa_lo = (uint32_t)faddr, fa_hi = (uint32_t)(faddr >> 32);
-                    const uint32_t stop = b_end < g_hi ? b_end : g_hi;
-                    while (g < stop) {
-                        RawTuple raw[U];
-                        bool wd[U], act[U];
+                    B.myp = ldg(pre + (fv ? f : S.T));
+                    B.b_end = ldg(pre + (f0 + 64 < S.T ? f0 + 64 : S.T));
+                    uint64_t fa = 0;
+                    if (fv) fa = frag_addr(S, p, f);
+                    const uint64_t vb = ((fa & ~1ull) - (uint64_t)B.myp * tuple_bytes(fa & 1)) | (fa & 1);
+                    B.vb_lo = (uint32_t)vb, B.vb_hi = (uint32_t)(vb >> 32);
+                    return B;
+                };
+                uint32_t f0 = uni32(f_lo);
+                Batch cb = load_batch(f0), nb = load_batch(f0 + 64);
+                uint32_t g = g_lo;  // the next tuple to ask for
+                RawTuple cur[U], nxt[U];
+                uint32_t cur_wide = 0, nxt_wide = 0;  // bit u: tuple u of the chunk is 24 bytes
+                uint32_t cur_n = 0, nxt_n = 0;        // tuples in the chunk
+                ST(1);  // search of the first fragment, first batches
+                for (;;) {  // (every condition below is the same for the whole wave)
+                    nxt_n = 0;
+                    if (g < g_hi) {
+                        uint32_t stop = uni32(cb.b_end) < g_hi ? uni32(cb.b_end) : g_hi;
+                        while (g >= stop) {  // the batch is used up: the next one (asked for when this one was entered) takes over
+                            f0 += 64;
+                            cb = nb;
+                            nb = load_batch(f0 + 64);
+                            stop = uni32(cb.b_end) < g_hi ? uni32(cb.b_end) : g_hi;
+                        }
+                        nxt_n = stop - g < (uint32_t)(64 * U) ? stop - g : (uint32_t)(64 * U);
+                        // tuple number -> lane of the batch: the last lane whose prefix is <= q (empty fragments repeat their
+                        // neighbour's and are never it); the U binary searches step together, U bpermutes in flight per step
+                        uint32_t qq[U], lo[U];
 #pragma unroll
                         for (int u = 0; u < U; u++) {
                             const uint32_t q = g + (uint32_t)u * 64 + lane;
-                            act[u] = q < stop;
-                            const uint32_t qq = act[u] ? q : stop - 1;
-                            uint32_t lo = 0;  // the last lane whose prefix is <= qq (empty fragments repeat their neighbour's and are never it)
-#pragma unroll
-                            for (int st = 32; st >= 1; st >>= 1) {
-                                const uint32_t cand = lo + st;
-                                const uint32_t pc = (uint32_t)__shfl((int)myp, (int)cand, 64);
-                                const bool fin = f0 + cand < S.T;
-                                if (fin && pc <= qq) lo = cand;
-                            }
-                            const uint32_t pb = (uint32_t)__shfl((int)myp, (int)lo, 64);
-                            const uint32_t al = (uint32_t)__shfl((int)fa_lo, (int)lo, 64), ah = (uint32_t)__shfl((int)fa_hi, (int)lo, 64);
-                            const uint64_t a = (uint64_t)al | ((uint64_t)ah << 32);
-                            wd[u] = a & 1;
-                            raw[u] = ld_raw(reinterpret_cast<const uint8_t *>(a & ~1ull) + (uint64_t)(qq - pb) * tuple_bytes(wd[u]), wd[u]);
+                            qq[u] = q < stop ? q : stop - 1;
+                            lo[u] = 0;
                         }
 #pragma unroll
+                        for (int st = 32; st >= 1; st >>= 1) {
+                            uint32_t pc[U];
+#pragma unroll
+                            for (int u = 0; u < U; u++) pc[u] = (uint32_t)__shfl((int)cb.myp, (int)(lo[u] + st), 64);
+#pragma unroll
+                            for (int u = 0; u < U; u++)
+                                if (f0 + lo[u] + st < S.T && pc[u] <= qq[u]) lo[u] += st;
+                        }
+                        uint32_t al[U], ah[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) al[u] = (uint32_t)__shfl((int)cb.vb_lo, (int)lo[u], 64), ah[u] = (uint32_t)__shfl((int)cb.vb_hi, (int)lo[u], 64);
+                        nxt_wide = 0;
+#pragma unroll
                         for (int u = 0; u < U; u++) {
-                            const GridTuple t = decode_raw(raw[u], wd[u], P.entries);
+                            const uint64_t vb = (uint64_t)al[u] | ((uint64_t)ah[u] << 32);
+                            const bool w = ANYWIDE && (vb & 1);
+                            const uint8_t *src = reinterpret_cast<const uint8_t *>(vb & ~1ull) + (uint64_t)qq[u] * tuple_bytes(w);
+                            if (ANYWIDE) {
+                                nxt[u] = ld_raw(src, w);
+                                nxt_wide |= w ? 1u << u : 0u;
+                            } else {
+                                nxt[u].a = *(const PCQ_GLOBAL u32x4_a16 *)src;
+                            }
+                        }
+                        g += nxt_n;
+                    }
+                    ST(2);  // issue stage
+                    if (cur_n) {
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const bool act = (uint32_t)u * 64 + lane < cur_n;
+                            const GridTuple t = ANYWIDE ? decode_raw<MULTI>(cur[u], (cur_wide >> u) & 1, P.entries) : decode16<MULTI>(cur[u].a, P.entries);
                             bool surv_me = false;
                             int s = -1;
-                            if (act[u]) {
-                                const TupleEval ev = eval_tuple(P.g, P.entries, t);
-                                s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, cell_hash(ev.key), &s_ncell);
+                            ST(3);  // decode (the first one of a chunk: + whatever the chunk's tuples still took to arrive)
+                            if (act) {
+                                const TupleEval ev = eval_tuple<MULTI>(P.g, P.entries, t);
+                                ST(4);  // cell, key, distance
+                                uint64_t seen;
+                                s = stream_find_or_insert<NSLOT, LIMIT>(s_kd, ev.key, cell_hash(ev.key), &s_ncell, &seen);
+                                ST(5);  // hash + probe
                                 if (s < 0) {
                                     s_over = 1;
                                 } else {
                                     if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
-                                    const uint64_t seen = __hip_atomic_load(&s_dist[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a stale value is only too large)
                                     if (ev.dbits <= seen) {
                                         if (ev.dbits < seen) {
-                                            const uint64_t old = atomicMin((unsigned long long *)&s_dist[s], (unsigned long long)ev.dbits);
+                                            const uint64_t old = atomicMin((unsigned long long *)&s_kd[s].dist, (unsigned long long)ev.dbits);
                                             if (ev.dbits < old) s_ord[s] = ~0u;  // a new minimum: an earlier fold's winner is out (racing writers store the same value)
                                         }
                                         surv_me = true;
                                     }
                                 }
                             }
+                            ST(6);  // compare, lower the minimum
                             const unsigned long long m = __ballot(surv_me);
                             if (m) {  // (the same for the whole wave)
                                 uint32_t base = 0;
@@ -165,11 +254,17 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                                     surv[2 * (size_t)pos + 1] = make_uint4(t.w0, t.w1, (uint32_t)s, 0u);
                                 }
                             }
+                            ST(7);  // survivor append
                         }
-                        g += 64 * U;
                     }
-                    g = stop;
-                    f0 += 64;
+                    if (!nxt_n) break;
+#pragma unroll
+                    for (int u = 0; u < U; u++) cur[u] = nxt[u];
+                    cur_wide = nxt_wide, cur_n = nxt_n;
+#ifdef PCQ_STAMPS
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                    ST(8);  // hand-over: the next chunk's tuples have arrived
                 }
             }
         }
@@ -177,6 +272,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
         // left the wave; all waves of a workgroup share one L1), as k_fold does for its parked payloads.
         __threadfence_block();
         __syncthreads();
+        ST(9);  // waiting for the workgroup's other waves
         const uint32_t nsurv = s_nsurv;
         if (s_over) {  // more cells than the table holds: the host repeats the fold with more partitions
             if (threadIdx.x == 0) {
@@ -194,14 +290,14 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                 const uint4 ra = surv[2 * (size_t)i], rb = surv[2 * (size_t)i + 1];
                 GridTuple t{(int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, ra.w, rb.x, rb.y};
                 const uint32_t s = rb.z;
-                if (eval_tuple(P.g, P.entries, t).dbits == s_dist[s]) atomicMin(&s_ord[s], (uint32_t)ord_of(t));
+                if (eval_tuple(P.g, P.entries, t).dbits == s_kd[s].dist) atomicMin(&s_ord[s], (uint32_t)ord_of(t));
             }
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < nsurv; i += NT) {
                 const uint4 ra = surv[2 * (size_t)i], rb = surv[2 * (size_t)i + 1];
                 GridTuple t{(int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, ra.w, rb.x, rb.y};
                 const uint32_t s = rb.z;
-                if (s_ord[s] == (uint32_t)ord_of(t) && eval_tuple(P.g, P.entries, t).dbits == s_dist[s]) s_widx[s] = i;
+                if (s_ord[s] == (uint32_t)ord_of(t) && eval_tuple(P.g, P.entries, t).dbits == s_kd[s].dist) s_widx[s] = i;
             }
             __syncthreads();
             // compaction: thread t owns slots [t * SPT, ...): the cells leave in slot order
@@ -210,7 +306,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
             uint64_t keys[SPT];
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
-                keys[j] = s0 + j < NSLOT ? s_key[s0 + j] : PCQ_EMPTY_KEY;
+                keys[j] = s0 + j < NSLOT ? s_kd[s0 + j].key : PCQ_EMPTY_KEY;
                 mine += keys[j] != PCQ_EMPTY_KEY ? 1 : 0;
             }
             uint32_t incl = mine;
@@ -267,9 +363,12 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
             }
         }
         __syncthreads();  // the table is cleared for the next partition
+        ST(10);  // exact phase + output
     }
+    ST_FLUSH(P.stats);
 }
 
-template __global__ void k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 4>(FoldParams, uint32_t, uint32_t, uint4 *);
+template __global__ void k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 4, false, false>(FoldParams, uint32_t, uint32_t, uint4 *);
+template __global__ void k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 2, true, true>(FoldParams, uint32_t, uint32_t, uint4 *);
 
 }  // namespace pcqgrid

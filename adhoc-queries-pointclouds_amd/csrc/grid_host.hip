@@ -11,6 +11,7 @@ struct GridRun {       // the output of one pass-0 launch
     uint32_t ntiles;
     uint32_t wide;     // 24-byte tuples (a colour column, or a scan whose 16-byte tuples had no room for the class byte)
     uint32_t entry;    // the entry (scale / offset / packing) the run was scanned with
+    uint32_t block_bytes;  // from one tile's block to the next
 };
 
 struct GridState {
@@ -132,6 +133,7 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         // in that coordinate's top byte): the narrowest side of the integer query box; a class query stores no class at all.
         GridEntryDev e{};
         for (int a = 0; a < 3; a++) e.scale[a] = cols.scale[a], e.offset[a] = cols.offset[a], e.lo[a] = 0, e.cmask[a] = 0xffffffffu;
+        e.fmt = FMT_NONE | FMT_NONE << 8 | FMT_NONE << 16;
         bool narrow = !wide && ctx->grid_tuple16 != 0;
         if (narrow && pred.kind == PCQ_PRED_CLASS) {
             e.cls_const = pred.cls & 0xffu;
@@ -144,6 +146,14 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
             } else if (pred.width[axis] < (1u << 24)) {
                 for (int a = 0; a < 3; a++) e.lo[a] = pred.lo[a];
                 e.cmask[axis] = 0x00ffffffu;
+                uint32_t fmt = (uint32_t)(8 * axis) | FMT_NONE << 8 | FMT_NONE << 16;
+                // all three sides below 2^24: the other two top bytes carry the second level's selector (pass 0 has the hash at hand)
+                if (pred.width[0] < (1u << 24) && pred.width[1] < (1u << 24) && pred.width[2] < (1u << 24) && ctx->grid_tuple16 != 2) {
+                    const int l = axis == 0 ? 1 : 0, h = axis == 2 ? 1 : 2;
+                    e.cmask[l] = e.cmask[h] = 0x00ffffffu;
+                    fmt = (uint32_t)(8 * axis) | (uint32_t)(8 * l) << 8 | (uint32_t)(8 * h) << 16;
+                }
+                e.fmt = fmt;
             } else {
                 narrow = false;
             }
@@ -151,7 +161,9 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
             narrow = false;  // a world-space predicate (LAZER): the integer range of the matches is not known
         }
         const bool wide_t = !narrow;
-        const size_t tuple_room = (size_t)ntiles * P0_TILE * tuple_bytes(wide_t) + 64;
+        // (a block's room: its 5120 tuples, plus the padding option — 16-byte units — that moves the blocks' phase in memory)
+        const uint32_t block_bytes = P0_TILE * tuple_bytes(wide_t) + 16u * (uint32_t)ctx->grid_block_pad;
+        const size_t tuple_room = (size_t)ntiles * block_bytes + 64;
         // the entry: consecutive scans that agree in scale, offset and packing share it
         auto needs_entry = [&]() {
             if (gs->entries.empty()) return true;
@@ -163,7 +175,7 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
             if (frc) return frc;
         }
         GridRun run{};
-        run.ntiles = ntiles, run.wide = wide_t;
+        run.ntiles = ntiles, run.wide = wide_t, run.block_bytes = block_bytes;
         auto alloc_run = [&]() {
             void *pt = nullptr, *pd = nullptr;
             int arc = grid_room(ctx, gs, tuple_room, &pt);
@@ -188,7 +200,8 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         gs->pending_tiles += ntiles;
         gs->any_wide |= wide_t;
         P0Pack pk16{};
-        for (int a = 0; a < 3; a++) pk16.lo[a] = e.lo[a], pk16.cmask[a] = e.cmask[a];
+        for (int a = 0; a < 3; a++) pk16.lo[a] = e.lo[a], pk16.cmask[a] = e.cmask[a], pk16.top_shift[a] = fmt_top_shift(e.fmt, a);
+        pk16.block_bytes = block_bytes;
 
         const DevGrid &g = c->grid;
         const unsigned nblocks = ntiles < (uint32_t)ctx->num_cus ? ntiles : (unsigned)ctx->num_cus;  // one workgroup per CU is resident (LDS)
@@ -235,7 +248,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     {
         uint32_t tile0 = 0;
         for (int r = 0; r < nruns; r++) {
-            hruns[r] = DevRun{gs->runs[r].tuples, gs->runs[r].dir, tile0, gs->runs[r].ntiles, gs->runs[r].wide, gs->runs[r].entry};
+            hruns[r] = DevRun{gs->runs[r].tuples, gs->runs[r].dir, tile0, gs->runs[r].ntiles, gs->runs[r].wide, gs->runs[r].entry, gs->runs[r].block_bytes, 0};
             tile0 += gs->runs[r].ntiles;
         }
     }
@@ -252,7 +265,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     if (!rc) rc = tmp.get(256, &d_entries);
     if (!rc) rc = tmp.get(F1, &d_bintot);
     if (!rc) rc = tmp.get(F1 + 1, &d_binbase);
-    if (!rc) rc = tmp.get(8, &d_stats);
+    if (!rc) rc = tmp.get(32, &d_stats);
     if (!rc) rc = tmp.get(1, &d_grid);
     if (!rc) rc = tmp.get((size_t)F1 * Tp, &d_startT);
     if (!rc) rc = tmp.get((size_t)F1 * Tp1, &d_preT);
@@ -284,7 +297,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
     // set is sized for eight times the mean bin; its probing is bounded).  Not when the bins cannot be large anyway.
     const double old_per_bin = (double)gs->wtotal / F1;
     const bool probed = ctx->grid_f2 <= 0 && (double)gs->pending_cap / F1 + old_per_bin > BIG_DIRECT;
-    PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
+    PCQ_HIP(hipMemsetAsync(d_stats, 0, 256, s));
     if (probed) {
         uint64_t cap = 1024;
         while (cap < 16ull * (gs->pending_cap / F1 + 1) * PROBE_BINS) cap <<= 1;
@@ -388,7 +401,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 L.obinbase = d_obinbase, L.okeys2 = d_okeys2, L.orecs2 = RecArr{d_orecs2, w_old}, L.ooff2 = d_ooff2;
             }
             PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
-            if (staged) hipLaunchKernelGGL(k_level2, dim3(F1), dim3(L2S_NT), 0, s, L);
+            if (staged && (any_wide || eref.multi)) hipLaunchKernelGGL((k_level2<true, true>), dim3(F1), dim3(L2S_NT), 0, s, L);
+            else if (staged) hipLaunchKernelGGL((k_level2<false, false>), dim3(F1), dim3(L2S_NT), 0, s, L);
             else hipLaunchKernelGGL(k_level2_direct, dim3(F1), dim3(L2_NT), 0, s, L);
             PCQ_HIP(hipGetLastError());
             if (f2 > 1) {
@@ -457,11 +471,13 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 // spilled 92 bytes per lane and partition, 4.8 GB of scratch each way per file: 2.58 against 2.20 ms in one process
                 uint32_t dense_wgs = (uint32_t)ctx->num_cus * 2u;
                 if (dense_wgs > nparts) dense_wgs = nparts;
-                hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, 4>), dim3(dense_wgs), dim3(DENSE_NT), 0, s, D, nparts);
+                if (any_wide || eref.multi) hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, 4, true, true>), dim3(dense_wgs), dim3(DENSE_NT), 0, s, D, nparts);
+                else hipLaunchKernelGGL((k_fold_dense<SMALL_SLOTS, DENSE_NT, DENSE_K, SMALL_LIMIT, 4, false, false>), dim3(dense_wgs), dim3(DENSE_NT), 0, s, D, nparts);
             }
             if (big && stream) {  // the bins as streams; a bin with more running minima than its survivor list holds is left to k_fold<BIG>
                 F.defer_list = d_defer;
-                hipLaunchKernelGGL((k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts, surv_cap, d_surv);
+                if (any_wide || eref.multi) hipLaunchKernelGGL((k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 2, true, true>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts, surv_cap, d_surv);
+                else hipLaunchKernelGGL((k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 4, false, false>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts, surv_cap, d_surv);
             }
             if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, true, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
             else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, true, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);
@@ -476,6 +492,18 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
             attempt--;
             continue;
         }
+#ifdef PCQ_STAMPS
+        {
+            unsigned long long sx[16] = {0};
+            PCQ_HIP(hipMemcpy(sx, d_stats + 16, sizeof sx, hipMemcpyDeviceToHost));
+            if (sx[15]) {
+                fprintf(stderr, "[pcq] stamps (cycles per wave, %llu waves):", sx[15]);
+                for (int i = 0; i < 12; i++) fprintf(stderr, " [%d] %.0f", i, (double)sx[i] / (double)sx[15]);
+                fprintf(stderr, "\n");
+            }
+            PCQ_HIP(hipMemsetAsync(d_stats + 16, 0, 128, s));
+        }
+#endif
         if (f2 > 1) ctx->grid_level2++;
         if (big && stream) ctx->grid_deferred += (int64_t)st[3];
         if (st[1]) {  // a partition held more cells than the LDS table: more partitions

@@ -17,8 +17,8 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
     for (uint32_t t = threadIdx.x; t < F2_MAX; t += L2_NT) s_hist[t] = 0, s_ohist[t] = 0;
     __syncthreads();
     if (P.binbase)
-        bin_for_each<L2_NT, L2_FB, L2_UNROLL>(P.src, P.entries, bin, s_pre, s_addr, [&](const GridTuple &t) {
-            atomicAdd(&s_hist[tuple_sub(P.g, P.entries, t, f2)], 1u);
+        bin_for_each<L2_NT, L2_FB, L2_UNROLL>(P.src, P.entries, bin, s_pre, s_addr, [&](const GridTuple &, const RawTuple &r, bool rw) {
+            atomicAdd(&s_hist[raw_sub(P.g, P.entries, r, rw, f2)], 1u);
         });
     if (P.okeys)
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
@@ -45,9 +45,9 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
     __syncthreads();
     if (P.binbase) {
         const bool wide = P.wide;
-        bin_for_each<L2_NT, L2_FB, L2_UNROLL>(P.src, P.entries, bin, s_pre, s_addr, [&](const GridTuple &t) {
-            const uint32_t pos = atomicAdd(&s_cur[tuple_sub(P.g, P.entries, t, f2)], 1u);
-            st_tuple(P.out + (uint64_t)pos * tuple_bytes(wide), t, wide, P.entries);
+        bin_for_each<L2_NT, L2_FB, L2_UNROLL>(P.src, P.entries, bin, s_pre, s_addr, [&](const GridTuple &, const RawTuple &r, bool rw) {
+            const uint32_t pos = atomicAdd(&s_cur[raw_sub(P.g, P.entries, r, rw, f2)], 1u);
+            st_raw_as(P.out + (uint64_t)pos * tuple_bytes(wide), r, rw, wide, P.entries);
         });
     }
     if (P.okeys)
@@ -72,6 +72,10 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
 // the host then takes the exact form (k_level2_direct), which counts first.
 // The bin arrives through the fragment reader: a window of 2048 fragments (about five tiles' worth of tuples) in LDS,
 // whole tiles out of it — the next window starts at the fragment the last whole tile ended in.
+// ANYWIDE = false: every pending run has 16-byte tuples, and so has the output (four registers per tuple in flight, one aligned
+// load, one aligned store); MULTI = false: one entry — no load in a branch between the prefetch of the next tile and its use
+// (EntryRef::get).  Everything else: <true, true>.
+template <bool ANYWIDE, bool MULTI>
 __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
     constexpr int BPT = L2_STAGED_F2 / L2S_NT;  // sub-partitions per thread when the cursors move on
     static_assert(BPT >= 1 && BPT * L2S_NT == L2_STAGED_F2, "whole sub-partitions per thread");
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
     __syncthreads();
     if (P.out) {
         const BinSrc &S = P.src;
-        const bool wide_out = P.wide;
+        const bool wide_out = ANYWIDE && P.wide;
         const uint32_t ts_out = tuple_bytes(wide_out);
         const uint64_t region0 = (uint64_t)bin * f2 * cap;  // this bin's sub-partition s: out[region0 + s * cap ...)
         const uint32_t total_in = uni32(ldg(S.preT + (size_t)bin * S.Tp1 + S.T));
@@ -129,18 +133,19 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
 #pragma unroll
                 for (int j = 0; j < L2S_ITEMS; j++) {
                     const uint32_t i = j0 + j * L2S_NT + threadIdx.x;
-                    t[j] = frag_ld_raw(s_pre, s_addr, nfr, i < hi ? i : hi - 1, &tw[j]);
+                    t[j] = frag_ld_raw<ANYWIDE>(s_pre, s_addr, nfr, i < hi ? i : hi - 1, &tw[j]);
                     tn[j] = t[j], tnw[j] = tw[j];
                 }
 #pragma unroll
                 for (int j = 0; j < L2S_ITEMS; j++)  // (arrived: see k_p0_part on the one counter for loads and stores)
-                    asm volatile("" ::"v"(t[j].a.x), "v"(t[j].a.w), "v"(t[j].b.x), "v"(t[j].b.y));
+                    if (ANYWIDE) asm volatile("" ::"v"(t[j].a.x), "v"(t[j].a.w), "v"(t[j].b.x), "v"(t[j].b.y));
+                    else asm volatile("" ::"v"(t[j].a.x), "v"(t[j].a.w));
                 for (uint32_t base = j0; base < hi; base += L2S_TILE) {
                     if (base + L2S_TILE < hi) {  // the next tile is on its way while this one is sorted
 #pragma unroll
                         for (int j = 0; j < L2S_ITEMS; j++) {
                             const uint32_t i = base + L2S_TILE + j * L2S_NT + threadIdx.x;
-                            tn[j] = frag_ld_raw(s_pre, s_addr, nfr, i < hi ? i : hi - 1, &tnw[j]);
+                            tn[j] = frag_ld_raw<ANYWIDE>(s_pre, s_addr, nfr, i < hi ? i : hi - 1, &tnw[j]);
                         }
                     }
                     uint32_t subs[L2S_ITEMS], ranks[L2S_ITEMS];
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
 #pragma unroll
                     for (int j = 0; j < L2S_ITEMS; j++) {
                         valid[j] = base + j * L2S_NT + threadIdx.x < hi;
-                        subs[j] = tuple_sub(P.g, P.entries, decode_raw(t[j], tw[j], P.entries), f2);
+                        subs[j] = raw_sub<MULTI>(P.g, P.entries, t[j], tw[j], f2);
                         ranks[j] = 0;
                         if (valid[j]) ranks[j] = atomicAdd(&s_cnt[subs[j]], 1u);
                     }
@@ -179,7 +184,7 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
                         if (!valid[j]) continue;
                         const uint32_t at = s_base[subs[j]] + ranks[j];
                         if (wide_out && !tw[j]) {  // a 16-byte tuple into a 24-byte output (some other run is wide): decoded
-                            const GridTuple d = decode_raw(t[j], false, P.entries);
+                            const GridTuple d = decode_raw<MULTI>(t[j], false, P.entries);
                             s_xyzi[at] = make_uint4((uint32_t)d.x, (uint32_t)d.y, (uint32_t)d.z, d.idx);
                             s_attr[at] = make_uint2(d.w0 & 0xffff00ffu, 0u);
                         } else {
@@ -192,7 +197,8 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
 #pragma unroll
                     for (int j = 0; j < L2S_ITEMS; j++) {  // the next tile has arrived — before this tile's stores are issued
                         t[j] = tn[j], tw[j] = tnw[j];
-                        asm volatile("" ::"v"(t[j].a.x), "v"(t[j].a.w), "v"(t[j].b.x), "v"(t[j].b.y));
+                        if (ANYWIDE) asm volatile("" ::"v"(t[j].a.x), "v"(t[j].a.w), "v"(t[j].b.x), "v"(t[j].b.y));
+                    else asm volatile("" ::"v"(t[j].a.x), "v"(t[j].a.w));
                     }
                     __syncthreads();
                     {  // the cursors move on (a thread's sub-partitions: their tile counts are s_base differences)
@@ -268,5 +274,8 @@ __global__ __launch_bounds__(BLOCK) void k_old_per_bin(const uint32_t *__restric
     for (uint32_t q = b * f2old; q < (b + 1) * f2old; q++) t += ocount[q];
     obin[b] = t;
 }
+
+template __global__ void k_level2<false, false>(Level2Params);
+template __global__ void k_level2<true, true>(Level2Params);
 
 }  // namespace pcqgrid

@@ -170,11 +170,11 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
                 s_akey[place] = ev.key;
                 const bool through = ev.alias || ev.dbits >= 0x7ff0000000000000ull;
                 pk[j] = (through ? 0ull : ((ev.dbits >> AGG_POS_BITS) + 1) << AGG_POS_BITS) | place;
-                metas[j] = bin_of(h);
+                metas[j] = bin_of(h) | (sel16_of(h) << 16);  // (the bin, and the second level's selector for the spare top bytes of a 16-byte tuple)
                 ranks[j] = (uint32_t)(h >> 24) & (AGG_SLOTS - 1);  // the table slot, until the tile's fold is over
             } else {
                 const uint64_t h = cell_hash(key_only(g, px, py, pz));
-                metas[j] = bin_of(h);
+                metas[j] = bin_of(h) | (sel16_of(h) << 16);  // (the bin, and the second level's selector for the spare top bytes of a 16-byte tuple)
             }
         }
         if (agg) {
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
         }
 #pragma unroll
         for (int j = 0; j < ITEMS; j++)
-            if (passes[j]) ranks[j] = atomicAdd(&s_cnt[metas[j]], 1u);
+            if (passes[j]) ranks[j] = atomicAdd(&s_cnt[metas[j] & (F1 - 1)], 1u);
         {
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) npass += __shfl_xor(npass, o, 64);
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
             if (!passes[j]) continue;
-            const uint32_t at = s_base[metas[j]] + ranks[j];
+            const uint32_t at = s_base[metas[j] & (F1 - 1)] + ranks[j];
             uint32_t *q = s_img + at * (TS / 4);
             const uint32_t ord = (tile0 + tile) * (uint32_t)P0_TILE + (uint32_t)j * NT + tid;  // the tuple's place in the pending stream
             if (WIDE) {
@@ -239,10 +239,15 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
                 q2[1] = make_uint2((uint32_t)cur[j].rp.z, ord);
                 q2[2] = make_uint2(cl[j] | (RGB ? rg[j] << 16 : 0u), RGB ? (rg[j] >> 16) | (bb[j] << 16) : 0u);
             } else {
-                const uint32_t cb = cl[j] << 24;
-                *reinterpret_cast<uint4 *>(q) = make_uint4(((uint32_t)(cur[j].rp.x - pk16.lo[0]) & pk16.cmask[0]) | (cb & ~pk16.cmask[0]),
-                                                           ((uint32_t)(cur[j].rp.y - pk16.lo[1]) & pk16.cmask[1]) | (cb & ~pk16.cmask[1]),
-                                                           ((uint32_t)(cur[j].rp.z - pk16.lo[2]) & pk16.cmask[2]) | (cb & ~pk16.cmask[2]), ord);
+                // (the class byte is used as it was loaded, HERE: when the shift could move up to the load, the compiler kept one
+                // register for the five bytes and waited for each load on the spot — five serial round trips per tile, each of
+                // them also waiting for the next tile's positions: 1.1 -> 1.55 ms)
+                uint32_t cbyte = cl[j];
+                asm volatile("" : "+v"(cbyte));
+                const uint32_t V = cbyte | ((metas[j] >> 16) << 8);  // class | sel16 << 8: a byte of it per coordinate top byte that is free
+                *reinterpret_cast<uint4 *>(q) = make_uint4(((uint32_t)(cur[j].rp.x - pk16.lo[0]) & pk16.cmask[0]) | (((V >> pk16.top_shift[0]) << 24) & ~pk16.cmask[0]),
+                                                           ((uint32_t)(cur[j].rp.y - pk16.lo[1]) & pk16.cmask[1]) | (((V >> pk16.top_shift[1]) << 24) & ~pk16.cmask[1]),
+                                                           ((uint32_t)(cur[j].rp.z - pk16.lo[2]) & pk16.cmask[2]) | (((V >> pk16.top_shift[2]) << 24) & ~pk16.cmask[2]), ord);
             }
         }
 #pragma unroll
@@ -256,7 +261,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
         // The block, front to back, as whole 16-byte words of the image (a block starts 16-byte aligned and has room for whole
         // words): every store instruction of a wave is 1 KiB without a gap.  (Stored tuple by tuple — 16 + 4 bytes at a stride
         // of 20 — the same bytes left as twice the instructions with holes for the other one to fill.)
-        uint4 *blk = reinterpret_cast<uint4 *>(out + (uint64_t)tile * P0_TILE * TS);
+        uint4 *blk = reinterpret_cast<uint4 *>(out + (uint64_t)tile * pk16.block_bytes);
         const uint32_t nq = (total * TS + 15) / 16;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         for (uint32_t t = tid; t < nq; t += NT) *(PCQ_GLOBAL u32x4 *)(blk + t) = reinterpret_cast<const u32x4 *>(s_img)[t];

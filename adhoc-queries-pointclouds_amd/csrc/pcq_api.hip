@@ -326,11 +326,14 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "grid_agg")) {
         if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "grid_agg must be 0 (adaptive), 1 (always) or 2 (never)");
         ctx->grid_agg = (int)value;
+    } else if (!strcmp(key, "grid_block_pad")) {
+        if (value < 0 || value > 65536) return pcq_fail(PCQ_ERR_ARG, "grid_block_pad must be 0..65536");
+        ctx->grid_block_pad = (int)value;
     } else if (!strcmp(key, "grid_stream")) {
         if (value < 0 || value > 1) return pcq_fail(PCQ_ERR_ARG, "grid_stream must be 0 or 1");
         ctx->grid_stream = (int)value;
     } else if (!strcmp(key, "grid_tuple16")) {
-        if (value < 0 || value > 1) return pcq_fail(PCQ_ERR_ARG, "grid_tuple16 must be 0 or 1");
+        if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "grid_tuple16 must be 0, 1 or 2");
         ctx->grid_tuple16 = (int)value;
     } else if (!strcmp(key, "grid_f2")) {
         if (value < 0 || value > 4096) return pcq_fail(PCQ_ERR_ARG, "grid_f2 must be 0..4096");
@@ -382,6 +385,7 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     else if (!strcmp(key, "grid_agg")) *value = ctx->grid_agg;
     else if (!strcmp(key, "grid_tuple16")) *value = ctx->grid_tuple16;
     else if (!strcmp(key, "grid_stream")) *value = ctx->grid_stream;
+    else if (!strcmp(key, "grid_block_pad")) *value = ctx->grid_block_pad;
     else if (!strcmp(key, "grid_deferred")) *value = ctx->grid_deferred;
     else if (!strcmp(key, "grid_last_tuples")) *value = ctx->grid_last_tuples;
     else if (!strcmp(key, "grid_folds")) *value = ctx->grid_folds;
@@ -856,30 +860,44 @@ extern "C" int pcq_scan_dev(pcq_ctx *ctx, const pcq_columns *cols, const pcq_pre
 // ---------------------------------------------------------------------------------------------
 // scan over host-resident columns: pinned double buffers + hipMemcpyAsync overlapped with kernels
 // ---------------------------------------------------------------------------------------------
-static int ensure_stage(pcq_ctx *ctx, size_t bytes) {
-    if (ctx->stage_bytes >= bytes) return PCQ_OK;
-    PCQ_HIP(hipStreamSynchronize(ctx->stream));
-    PCQ_HIP(hipStreamSynchronize(ctx->copy_stream));
-    ctx->stage_busy[0] = ctx->stage_busy[1] = false;
-    for (int i = 0; i < 2; i++) {
-        if (ctx->h_stage[i]) PCQ_HIP(hipHostFree(ctx->h_stage[i]));
-        if (ctx->d_stage[i]) PCQ_HIP(hipFree(ctx->d_stage[i]));
-        ctx->h_stage[i] = nullptr;
-        ctx->d_stage[i] = nullptr;
+// The staging ring: two pinned host buffers and their device twins.  `upto` = how many of the pairs the caller needs NOW: a
+// scan asks for the first pair, issues its first chunk, and only then for the second — pinning 24 MB is 5 ms
+// (profiles/r03_hip_startup.log: 11 ms for the ring), and the second pair's 5 ms then run under the first chunk's transfer
+// instead of in front of it (the first file of a process cost 15-24 ms where the others cost 1: profiles/r03_cli_e2e.log).
+static int ensure_stage(pcq_ctx *ctx, size_t bytes, int upto = 2) {
+    if (ctx->stage_bytes < bytes && (ctx->h_stage[0] || ctx->h_stage[1])) {  // too small: drop what there is
+        PCQ_HIP(hipStreamSynchronize(ctx->stream));
+        PCQ_HIP(hipStreamSynchronize(ctx->copy_stream));
+        ctx->stage_busy[0] = ctx->stage_busy[1] = false;
+        for (int i = 0; i < 2; i++) {
+            if (ctx->h_stage[i]) PCQ_HIP(hipHostFree(ctx->h_stage[i]));
+            if (ctx->d_stage[i]) PCQ_HIP(hipFree(ctx->d_stage[i]));
+            ctx->h_stage[i] = nullptr;
+            ctx->d_stage[i] = nullptr;
+        }
+        ctx->stage_bytes = 0;
     }
-    ctx->stage_bytes = 0;
+    if (ctx->stage_bytes < bytes) ctx->stage_bytes = bytes;  // (the size the pairs are allocated with from here on)
+    bool need = false;
+    for (int i = 0; i < upto; i++) need |= !ctx->h_stage[i];
+    if (!need) return PCQ_OK;
+    const auto t0 = std::chrono::steady_clock::now();
     // pinned pages are allocated where the allocating thread runs (default "local" policy): run on the GPU's node for it
     cpu_set_t saved;
     const bool rebind = ctx->numa_local && ctx->numa_node >= 0 && sched_getaffinity(0, sizeof saved, &saved) == 0 &&
                         sched_setaffinity(0, sizeof ctx->node_cpus, &ctx->node_cpus) == 0;
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 2 && e == hipSuccess; i++) {
-        e = hipHostMalloc((void **)&ctx->h_stage[i], bytes, hipHostMallocDefault);  // (pinned = resident: the pages exist when this returns)
-        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stage[i], bytes);
+    for (int i = 0; i < upto && e == hipSuccess; i++) {
+        if (ctx->h_stage[i]) continue;
+        e = hipHostMalloc((void **)&ctx->h_stage[i], ctx->stage_bytes, hipHostMallocDefault);  // (pinned = resident: the pages exist when this returns)
+        if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_stage[i], ctx->stage_bytes);
     }
     if (rebind) (void)sched_setaffinity(0, sizeof saved, &saved);
     if (e != hipSuccess) return pcq_fail(PCQ_ERR_HIP, "staging allocation failed: %s", hipGetErrorString(e));
-    ctx->stage_bytes = bytes;
+    static const bool timing = getenv("PCQ_TIMING") && getenv("PCQ_TIMING")[0] == '1';
+    if (timing)
+        fprintf(stderr, "[pcq] staging pair(s) up to %d of %zu MB pinned + device in %.1f ms\n", upto, ctx->stage_bytes >> 20,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     return PCQ_OK;
 }
 
@@ -1000,8 +1018,15 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
     if (chunk < 1) chunk = 1;
     chunk = (chunk + 3) & ~3ull;  // multiples of 4 points keep 12-byte blocks 16-byte aligned per chunk
     const size_t stage_need = (size_t)(chunk * pl.bytes_per_point) + 64;
-    rc = ensure_stage(ctx, stage_need);
+    rc = ensure_stage(ctx, stage_need, 1);  // (the second pair: behind the first chunk, below)
     if (rc) return rc;
+    static const bool timing = getenv("PCQ_TIMING") && getenv("PCQ_TIMING")[0] == '1';
+    const bool first_scan = timing && !ctx->scanned_before;
+    ctx->scanned_before = true;
+    const auto t_scan = std::chrono::steady_clock::now();
+    auto stamp = [&](const char *what) {
+        if (first_scan) fprintf(stderr, "[pcq] first scan of the context: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scan).count());
+    };
 
     hipStream_t s = ctx->stream, cs = ctx->copy_stream;
     const uint64_t nchunks = (cols->n + chunk - 1) / chunk;
@@ -1058,6 +1083,11 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
     };
     rc = stage(0);
     if (rc) return fail(rc);
+    stamp("first chunk read and its transfer issued");
+    if (nchunks > 1) {
+        rc = ensure_stage(ctx, stage_need, 2);
+        if (rc) return fail(rc);
+    }
     for (uint64_t k = 0; k < nchunks; k++) {
         const int b = (int)(k & 1);
         if (k + 1 < nchunks) {  // stage the next chunk while this one is scanned
@@ -1084,11 +1114,13 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
         if (rc) return fail(rc);
         PCQ_HIP_OR_FAIL(hipEventRecord(ctx->consumed[b], s));
         ctx->stage_busy[b] = true;
+        if (k == 0) stamp("first chunk's kernels launched");
     }
     if (wait) {
         PCQ_HIP_OR_FAIL(hipStreamSynchronize(s));
         ctx->stage_busy[0] = ctx->stage_busy[1] = false;
     }
+    stamp(wait ? "last chunk done" : "last chunk's kernels launched (not waited for)");
     return PCQ_OK;
 #undef PCQ_HIP_OR_FAIL
 }
@@ -1107,4 +1139,10 @@ extern "C" int pcq_scan_fd(pcq_ctx *ctx, int fd, const pcq_columns *cols, const 
     PCQ_ON_DEVICE_OF_CTX(ctx);
     if (fd < 0) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_fd: bad file descriptor");
     return scan_host_impl(ctx, fd, cols, pred, c, true);
+}
+
+extern "C" int pcq_scan_fd_nowait(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
+    if (fd < 0) return pcq_fail(PCQ_ERR_ARG, "pcq_scan_fd_nowait: bad file descriptor");
+    return scan_host_impl(ctx, fd, cols, pred, c, false);
 }

@@ -527,9 +527,9 @@ Status run_search_parallel(const std::vector<std::string> &files, const Searcher
         if (!ctxs.empty() && !merge_rccl && ctxs.size() > 1) {
             total = merge_counts_on_host(ctxs, sends, &final_status);  // (a short query: RCCL would take longer to load than the scans took)
         } else if (!ctxs.empty()) {
-            if (opt.test_allreduce_fail) {  // tests: make the collective fail (1 early / 2 late), through the real RCCL calls
+            if (opt.test_allreduce_fail) {  // tests: make the collective fail (1 early, 2 late, 3 inside the group), through the real RCCL calls
                 (void)pcq_set_option(ctxs[0], "allreduce_single_rank", 1);
-                (void)pcq_set_option(ctxs[0], "allreduce_fail", opt.test_allreduce_fail == 2 ? 2 : 1);
+                (void)pcq_set_option(ctxs[0], "allreduce_fail", opt.test_allreduce_fail);
             }
             Status ast = Status::FromLib(pcq_allreduce_sum_u64(ctxs.data(), sends.data(), recvs.data(), (int)ctxs.size()));
             if (ast.ok()) {

@@ -128,7 +128,9 @@ Status execute_plan(FilePlan &plan, ResultCollector &rc) {
         ::close(fd);
         return Status::Err(PCQ_ERR_IO, plan.path + ": the file changed while the query was running");
     }
-    const int r = pcq_scan_fd(rc.context(), fd, &cols, &plan.pred, rc.handle());
+    // (not waited for: the bytes have been read when this returns, the collector's accessors — or the driver's
+    // synchronisation of the context before it merges — wait for the kernels; the next file's first read overlaps them)
+    const int r = pcq_scan_fd_nowait(rc.context(), fd, &cols, &plan.pred, rc.handle());
     ::close(fd);
     rc.next_index += cols.n;
     return Status::FromLib(r);

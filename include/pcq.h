@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PCQ_ABI_VERSION 4
+#define PCQ_ABI_VERSION 5
 
 typedef enum pcq_status {
     PCQ_OK = 0,
@@ -137,14 +137,17 @@ int pcq_box_to_local(const double bmin[3], const double bmax[3], const double sc
  * Collectors — device-resident counterparts of query/src/collect_points.rs.
  *   count  : CountCollector        (:72-98)   a u64 counter in HBM
  *   buffer : BufferCollector       (:14-44)   matches appended in file order (stable compaction)
- *   grid   : GridSampledCollector  (:100-127) SparseGrid (grid_sampling.rs:9-114) as an HBM hash
- *            table; per cell the point closest to the cell centre, first seen wins ties.
+ *   grid   : GridSampledCollector  (:100-127) SparseGrid (grid_sampling.rs:9-114): per cell the point closest to
+ *            the cell centre, first seen wins ties.  No hash table in HBM: a scan leaves its matches as 16-byte tuples
+ *            sorted by a hash bin of their cell, and a fold — when a result is asked for, or pcq_collector_flush —
+ *            resolves every bin in an LDS table (csrc/grid_*.hip).
  * A collector may be fed by several scans (sequential mode feeds all files into one collector,
  * main.rs:129-133); scans into one collector must be issued in file order.
  * ------------------------------------------------------------------------------------------- */
 int pcq_collector_new_count(pcq_ctx *ctx, pcq_collector **out);
 /* Count collector whose counter lives in caller-owned device memory (8 bytes, zeroed by the
- * caller) — lets the caller all-reduce it in place with RCCL (main.rs:164-180). */
+ * caller) — so that the caller can all-reduce it with RCCL (main.rs:164-180); pcq_allreduce_sum_u64 does that OUT OF
+ * PLACE (the per-GPU counts stay what they were, whatever happens to the collective). */
 int pcq_collector_new_count_at(pcq_ctx *ctx, uint64_t *device_counter, pcq_collector **out);
 int pcq_collector_new_buffer(pcq_ctx *ctx, pcq_collector **out);
 int pcq_collector_new_grid(pcq_ctx *ctx, const double bmin[3], const double bmax[3],
@@ -194,6 +197,10 @@ int pcq_scan_fd(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predica
  * the caller may overwrite its columns at once and issue the next scan, whose staging copy then overlaps this
  * scan's transfer and kernels.  Results are complete after pcq_ctx_synchronize or any collector accessor. */
 int pcq_scan_host_nowait(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c);
+/* The same for pcq_scan_fd: returns when the file's last chunk has been read and its kernels are enqueued — the descriptor may
+ * be closed at once, and the next file's first chunk is read while this one's last transfer and kernels run (a per-file
+ * synchronisation drained the pipeline for about a chunk's read + transfer at every file boundary of main.rs:153-161). */
+int pcq_scan_fd_nowait(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c);
 
 /* Count-only scan of many device-resident LAST files in ONE launch (files = independent units,
  * main.rs:153-161): segment i is scanned with preds[i] (all bounds, over 16-byte aligned positions

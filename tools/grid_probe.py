@@ -34,6 +34,9 @@ with pkg.Context(0) as ctx:
     bmin, bmax = specs.box(q)
     lmin, lmax = pkg.box_to_local(bmin, bmax, list(spec.scale), list(spec.offset))
     ctx.set_option("grid_f2", int(os.environ.get("GRID_F2", "0")))
+    for opt_name in ("grid_block_pad", "grid_stream", "grid_tuple16"):  # GRID_BLOCK_PAD / GRID_STREAM / GRID_TUPLE16
+        if os.environ.get(opt_name.upper()) is not None:
+            ctx.set_option(opt_name, int(os.environ[opt_name.upper()]))
     aggs = [int(v) for v in os.environ.get("GRID_AGG", "").split(",") if v]  # several: one after the other, same buffers
     for it in range(int(sys.argv[4]) if len(sys.argv) > 4 else 2):
         if aggs:
