@@ -740,6 +740,8 @@ __global__ void k_winner_room(const uint32_t *__restrict__ tot, const uint32_t *
 __global__ void k_scan_piece_sums(const uint64_t *__restrict__ in, uint32_t n, uint64_t *__restrict__ sums);
 __global__ void k_scan_pieces(const uint64_t *__restrict__ in, uint32_t n, const uint64_t *__restrict__ piece_prefix, uint64_t *__restrict__ out);
 __global__ void k_probe_distinct(BinSrc S, EntryRef entries, DevGrid g, uint64_t *__restrict__ set, uint64_t mask, unsigned long long *__restrict__ distinct);
+__global__ void k_fold_numbers(const uint32_t *__restrict__ tuples, const unsigned long long *__restrict__ stats, uint64_t *__restrict__ h_out);
+__global__ void k_words_out(const uint64_t *__restrict__ src, uint64_t *__restrict__ h_out, uint32_t n);
 // grid_level2.hip
 __global__ void k_level2_direct(Level2Params P);
 template <bool ANYWIDE, bool MULTI>

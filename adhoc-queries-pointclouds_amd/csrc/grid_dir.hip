@@ -283,4 +283,14 @@ __global__ __launch_bounds__(BLOCK) void k_probe_distinct(BinSrc S, EntryRef ent
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(distinct, (unsigned long long)mine);
 }
 
+// What the host decides on, into pinned host memory: the pending tuples (binbase[F1]) and the probe's distinct cells (stats[0]).
+__global__ void k_fold_numbers(const uint32_t *__restrict__ tuples, const unsigned long long *__restrict__ stats, uint64_t *__restrict__ h_out) {
+    if (threadIdx.x == 0) h_out[0] = *tuples;
+    if (threadIdx.x == 1) h_out[1] = stats[0];
+}
+// n 64-bit words into pinned host memory
+__global__ void k_words_out(const uint64_t *__restrict__ src, uint64_t *__restrict__ h_out, uint32_t n) {
+    if (threadIdx.x < n) h_out[threadIdx.x] = src[threadIdx.x];
+}
+
 }  // namespace pcqgrid

@@ -436,13 +436,24 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     // the time this partition's winners are stored), and the one behind it (its range is on its way).  A partition is a
     // chain of latencies — offsets, tuples, three barriers, the stores — and at two workgroups per CU nothing else hid the
     // tuples' round trip.
-    uint32_t cur_lo = 0, cur_cnt = 0, nxt_lo = 0, nxt_cnt = 0, nn_lo = 0, nn_cnt = 0;
-    uint64_t cur_out = 0, nxt_out = 0, nn_out = 0;
+    uint32_t cur_lo = 0, cur_cnt = 0, nxt_lo = 0, nxt_cnt = 0;
+    uint64_t cur_out = 0, nxt_out = 0;
     uint32_t p = blockIdx.x;
     // (the partition's range and output base are the same for the whole workgroup: scalar registers)
     const uint32_t *cntp = P.cnt;
     auto range_of = [&](uint32_t q, uint32_t *lo, uint32_t *cn, uint64_t *ob) {
         *lo = uni32(off[q]), *cn = cntp ? uni32(cntp[q]) : uni32(off[q + 1]) - *lo, *ob = uni64(P.wbase[q]);
+    };
+    // The same in two halves: asked for at the head of a round (plain loads into vector registers: nothing waits), made
+    // scalar at its end.  As one step the round stood still for the loads' round trip — readfirstlane needs the value — with
+    // the next partition's tuples queued behind them: 13 % of the kernel (profiles/r04_grid_progress.txt, stamps).
+    uint32_t v_lo = 0, v_cn = 0;
+    uint64_t v_ob = 0;
+    auto range_ask = [&](uint32_t q) {
+        v_lo = ldg(off + q), v_cn = cntp ? ldg(cntp + q) : ldg(off + q + 1), v_ob = ldg(P.wbase + q);
+    };
+    auto range_take = [&](uint32_t *lo, uint32_t *cn, uint64_t *ob) {
+        *lo = uni32(v_lo), *cn = cntp ? uni32(v_cn) : uni32(v_cn) - *lo, *ob = uni64(v_ob);
     };
     u32x4_a16 rcur[FOLD_K], rnxt[FOLD_K];
     auto ask16 = [&](u32x4_a16 (&r)[FOLD_K], uint32_t lo, uint32_t cnt) {
@@ -463,7 +474,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     for (; p < nparts; p += gridDim.x) {
         ST(9);  // (the tail of the round: rotating the registers)
         const uint32_t pn = p + gridDim.x, pnn = pn + gridDim.x;
-        if (pnn < nparts) range_of(pnn, &nn_lo, &nn_cnt, &nn_out);
+        if (pnn < nparts) range_ask(pnn);
         const bool ask_next = !WIDE && pn < nparts && nxt_cnt <= (uint32_t)CHUNK;
         if (ask_next) ask16(rnxt, nxt_lo, nxt_cnt);
         const uint32_t cnt = cur_cnt;
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
         if (cnt > (uint32_t)CHUNK) {  // (the same for every thread of the workgroup)
             if (threadIdx.x == 0) P.defer_list[atomicAdd(&P.stats[3], 1ull)] = p;
             cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
-            nxt_lo = nn_lo, nxt_cnt = nn_cnt, nxt_out = nn_out;
+            if (pnn < nparts) range_take(&nxt_lo, &nxt_cnt, &nxt_out);
 #pragma unroll
             for (int k = 0; k < FOLD_K; k++) rcur[k] = rnxt[k];
             continue;
@@ -519,18 +530,49 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
         ST(1);  // decode, cell, key, distance
         __syncthreads();  // the table is clean: the previous partition's winners have reset their slots
         ST(2);  // barrier: table clean
+        // phase 1: cells and their minimum distance.  The thread's tuples probe TOGETHER: a round issues the compare-and-swap of
+        // every tuple that has no slot yet and only then looks at the answers — one LDS round trip per round instead of one
+        // per tuple and round (inserting them one after the other was a fifth of the kernel: three dependent chains).
         int slot[FOLD_K];
         uint32_t fresh_cells = 0;
+        {
+            uint32_t ps[FOLD_K], pstep[FOLD_K];
+            bool todo[FOLD_K];
+            bool any = false;
 #pragma unroll
-        for (int k = 0; k < FOLD_K; k++) {  // phase 1: cells and their minimum distance
-            slot[k] = -1;
-            if ((uint32_t)(k * NT) + threadIdx.x >= cnt) continue;
-            bool fresh;
-            const uint32_t sl = lds_insert_dense<NSLOT>(s_key, key[k], cell_hash(key[k]), &fresh);
-            fresh_cells += fresh ? 1 : 0;
-            slot[k] = (int)sl;
-            if (alias[k]) atomicOr(&s_aliasbits[sl >> 5], 1u << (sl & 31));
-            atomicMin((unsigned long long *)&s_dist[sl], (unsigned long long)dbits[k]);
+            for (int k = 0; k < FOLD_K; k++) {
+                const uint64_t h = cell_hash(key[k]);
+                ps[k] = slot_of<NSLOT>(h);
+                pstep[k] = ((uint32_t)(h >> 15) & (NSLOT - 1)) | 1u;  // (lds_insert_dense's sequence)
+                todo[k] = (uint32_t)(k * NT) + threadIdx.x < cnt;
+                slot[k] = -1;
+                any |= todo[k];
+            }
+            while (any) {
+                uint64_t prev[FOLD_K];
+#pragma unroll
+                for (int k = 0; k < FOLD_K; k++)
+                    if (todo[k]) prev[k] = atomicCAS((unsigned long long *)&s_key[ps[k]], (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key[k]);
+                any = false;
+#pragma unroll
+                for (int k = 0; k < FOLD_K; k++) {
+                    if (!todo[k]) continue;
+                    if (prev[k] == PCQ_EMPTY_KEY || prev[k] == key[k]) {
+                        fresh_cells += prev[k] == PCQ_EMPTY_KEY ? 1 : 0;
+                        slot[k] = (int)ps[k];
+                        todo[k] = false;
+                    } else {
+                        ps[k] = (ps[k] + pstep[k]) & (NSLOT - 1);
+                        any = true;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) {
+                if (slot[k] < 0) continue;
+                if (alias[k]) atomicOr(&s_aliasbits[slot[k] >> 5], 1u << (slot[k] & 31));
+                atomicMin((unsigned long long *)&s_dist[slot[k]], (unsigned long long)dbits[k]);
+            }
         }
         ST(3);  // phase 1: insert, minimum distance
         bool over = false;
@@ -548,7 +590,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
                 atomicAdd(&P.stats[1], 1ull);
             }
             cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
-            nxt_lo = nn_lo, nxt_cnt = nn_cnt, nxt_out = nn_out;
+            if (pnn < nparts) range_take(&nxt_lo, &nxt_cnt, &nxt_out);
 #pragma unroll
             for (int k = 0; k < FOLD_K; k++) rcur[k] = rnxt[k];
             continue;
@@ -623,7 +665,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
         }
         ST(8);  // the winners' stores, slots reset
         cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
-        nxt_lo = nn_lo, nxt_cnt = nn_cnt, nxt_out = nn_out;
+        if (pnn < nparts) range_take(&nxt_lo, &nxt_cnt, &nxt_out);
 #pragma unroll
         for (int k = 0; k < FOLD_K; k++) rcur[k] = rnxt[k];
     }

@@ -26,13 +26,9 @@ namespace pcqgrid {
 // search across the lanes (six bpermutes): no window in LDS, nothing shared with the other waves.
 // ANYWIDE = false: every pending run has 16-byte tuples (one aligned load per tuple, four registers in flight); MULTI = false:
 // one entry (EntryRef::get) — the common fold of one file; anything else takes the <true, true> form.
-struct Survivor {   // 32 bytes, two 16-byte words
-    int32_t x, y, z;
-    uint32_t idx;
-    uint32_t w0, w1;  // as GridTuple (w0 carries the entry)
-    uint32_t slot;
-    uint32_t _pad;
-};
+// A survivor is three 16-byte words: {x, y, z, place in the pending stream} {w0 (with the entry), w1, slot, 0} {distance bits, 0, 0}
+// — the distance travels with it: recomputed in both exact passes, cell and distance of 8 M survivors were a seventh of the kernel.
+constexpr int SURV_WORDS = 3;
 
 // The table of the streaming fold: key and best distance side by side (one LDS access brings both: a probe that finds its
 // key has the cell's minimum with it), probed with DOUBLE hashing.  With linear probing the 64 lanes of a wave leave the
@@ -77,10 +73,10 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
     __shared__ uint32_t s_ord[NSLOT];    // file order (+ 1) of the winner: 0 = an earlier fold's winner, ~0 = none yet
     __shared__ uint32_t s_widx[NSLOT];   // the winner's place in the survivor list (an earlier fold's winner: its index among the partition's old winners)
     __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32];
-    __shared__ uint32_t s_ncell, s_over, s_nsurv, s_wsum[NW];
+    __shared__ uint32_t s_ncell, s_over, s_nsurv, s_next_batch, s_wsum[NW];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const BinSrc &S = P.src;
-    uint4 *surv = surv_scratch + (size_t)blockIdx.x * surv_cap * 2;
+    uint4 *surv = surv_scratch + (size_t)blockIdx.x * surv_cap * SURV_WORDS;
     ST_DECL;
     for (uint32_t it = blockIdx.x; it < nparts; it += gridDim.x) {
         const uint32_t p = xcd_order(it, nparts);
@@ -89,7 +85,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
         const uint64_t out_base = P.wbase[p];
         for (int t = threadIdx.x; t < NSLOT; t += NT) s_kd[t].key = PCQ_EMPTY_KEY, s_kd[t].dist = ~0ull, s_ord[t] = ~0u;
         for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
-        if (threadIdx.x == 0) s_ncell = 0, s_over = 0, s_nsurv = 0;
+        if (threadIdx.x == 0) s_ncell = 0, s_over = 0, s_nsurv = 0, s_next_batch = 0;
         __syncthreads();
 
         // earlier winners first: their distance is recomputed from the record (same f64 expressions, same bits)
@@ -130,53 +126,70 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
         // asked for when the current one is entered.
         {
             const uint32_t *pre = S.preT + (size_t)p * S.Tp1;
-            const uint32_t total = uni32(ldg(pre + S.T));
-            const uint32_t g_lo = (uint32_t)((uint64_t)total * wave / NW), g_hi = (uint32_t)((uint64_t)total * (wave + 1) / NW);
-            if (g_lo < g_hi) {
-                // the fragment tuple g_lo lies in: the last f with pre[f] <= g_lo — 64-ary search (lane L probes lo + L * step)
-                uint32_t f_lo = 0, f_n = S.T;  // the answer is in [f_lo, f_lo + f_n)
-                while (f_n > 1) {
-                    const uint32_t step = (f_n + 63) / 64;
-                    const uint32_t f = f_lo + lane * step;
-                    const bool le = f < f_lo + f_n && ldg(pre + f) <= g_lo;
-                    const uint32_t k = (uint32_t)__popcll(__ballot(le));  // lanes 0 .. k - 1 say yes (pre is monotone; lane 0 always does)
-                    const uint32_t nf = f_lo + (k - 1) * step;
-                    f_n = f_lo + f_n - nf < step ? f_lo + f_n - nf : step;
-                    f_lo = nf;
-                }
+            const uint32_t nbatches = (S.T + 63) / 64;
+            {
                 struct Batch {
-                    uint32_t myp, vb_lo, vb_hi;  // per lane
-                    uint32_t b_end;              // tuples of the bin in front of the next batch (the same in every lane)
+                    uint32_t myp, vb_lo, vb_hi;  // per lane (until settled vb_lo / vb_hi hold the tile's address as loaded, st its start in the block)
+                    uint32_t st;
+                    uint32_t b_end_v;            // tuples of the bin in front of the next batch (the same in every lane)
+                    uint32_t f0;                 // its first fragment (scalar); >= S.T: there is no such batch
+                    uint32_t first, end;         // scalar copies of lane 0's prefix and of b_end_v — valid once SETTLED
+                    bool settled;
                 };
-                auto load_batch = [&](uint32_t f0) {
+                // A batch's loads are asked for when the batch before it is entered; its two scalars are read out of the loaded
+                // registers where waiting costs nothing — behind the hand-over of the chunk, which waits for the memory anyway.
+                // (Read in the loop's header they made every round wait for EVERYTHING in flight: the compiler cannot count
+                // loads across the loop's back edge.)
+                auto settle = [&](Batch &B) {
+                    if (!B.settled) {
+                        B.first = uni32(B.myp), B.end = uni32(B.b_end_v);
+                        const uint64_t ta = (uint64_t)B.vb_lo | ((uint64_t)B.vb_hi << 32);
+                        const bool fv = B.f0 + lane < S.T;
+                        const uint64_t fa = fv ? (ta & ~1ull) + (uint64_t)B.st * tuple_bytes(ta & 1) : 0ull;  // (frag_addr)
+                        const uint64_t vb = (fa - (uint64_t)B.myp * tuple_bytes(ta & 1)) | (fv ? ta & 1 : 0ull);
+                        B.vb_lo = (uint32_t)vb, B.vb_hi = (uint32_t)(vb >> 32);
+                        B.settled = true;
+                    }
+                };
+                // The bin's fragments in batches of 64, handed out through a counter in LDS: a wave takes the next batch when it
+                // has used one up.  (Equal shares fixed in advance left the workgroup waiting a sixth of its time for its slowest
+                // wave at the end of every bin: survivors, probe lengths and memory luck differ from wave to wave.)
+                auto take_batch = [&]() {
+                    uint32_t id = 0;
+                    if (lane == 0) id = atomicAdd(&s_next_batch, 1u);
+                    id = uni32(id);
                     Batch B;
-                    const uint32_t f = f0 + lane;
+                    B.f0 = id < nbatches ? id * 64u : S.T;
+                    const uint32_t f = B.f0 + lane;
                     const bool fv = f < S.T;
                     B.myp = ldg(pre + (fv ? f : S.T));
-                    B.b_end = ldg(pre + (f0 + 64 < S.T ? f0 + 64 : S.T));
-                    uint64_t fa = 0;
-                    if (fv) fa = frag_addr(S, p, f);
-                    const uint64_t vb = ((fa & ~1ull) - (uint64_t)B.myp * tuple_bytes(fa & 1)) | (fa & 1);
-                    B.vb_lo = (uint32_t)vb, B.vb_hi = (uint32_t)(vb >> 32);
+                    B.b_end_v = ldg(pre + (B.f0 + 64 < S.T ? B.f0 + 64 : S.T));
+                    B.first = B.end = 0, B.settled = false;
+                    // (no load in a branch, and nothing computed on a loaded value here: this only ASKS — a lane behind the last
+                    // fragment for the last one's entries —, settle() computes)
+                    const uint32_t fc = fv ? f : S.T - 1;
+                    const uint64_t ta = ldg(S.tile_addr + fc);
+                    B.vb_lo = (uint32_t)ta, B.vb_hi = (uint32_t)(ta >> 32);
+                    B.st = ldg(S.startT + (size_t)p * S.Tp + fc);
                     return B;
                 };
-                uint32_t f0 = uni32(f_lo);
-                Batch cb = load_batch(f0), nb = load_batch(f0 + 64);
-                uint32_t g = g_lo;  // the next tuple to ask for
+                Batch cb = take_batch(), nb = take_batch();
+                settle(cb), settle(nb);
+                uint32_t g = cb.first;  // the next tuple to ask for
                 RawTuple cur[U], nxt[U];
                 uint32_t cur_wide = 0, nxt_wide = 0;  // bit u: tuple u of the chunk is 24 bytes
                 uint32_t cur_n = 0, nxt_n = 0;        // tuples in the chunk
                 ST(1);  // search of the first fragment, first batches
                 for (;;) {  // (every condition below is the same for the whole wave)
                     nxt_n = 0;
-                    if (g < g_hi) {
-                        uint32_t stop = uni32(cb.b_end) < g_hi ? uni32(cb.b_end) : g_hi;
-                        while (g >= stop) {  // the batch is used up: the next one (asked for when this one was entered) takes over
-                            f0 += 64;
-                            cb = nb;
-                            nb = load_batch(f0 + 64);
-                            stop = uni32(cb.b_end) < g_hi ? uni32(cb.b_end) : g_hi;
-                        }
+                    while (cb.f0 < S.T && g >= cb.end) {  // the batch is used up (or empty): the next one — asked for when this one was entered — takes over
+                        cb = nb;
+                        settle(cb);  // (settled already, unless the batch before it was empty)
+                        g = cb.first;
+                        nb = take_batch();
+                    }
+                    if (cb.f0 < S.T) {
+                        const uint32_t stop = cb.end, f0 = cb.f0;
                         nxt_n = stop - g < (uint32_t)(64 * U) ? stop - g : (uint32_t)(64 * U);
                         // tuple number -> lane of the batch: the last lane whose prefix is <= q (empty fragments repeat their
                         // neighbour's and are never it); the U binary searches step together, U bpermutes in flight per step
@@ -222,9 +235,11 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                             const GridTuple t = ANYWIDE ? decode_raw<MULTI>(cur[u], (cur_wide >> u) & 1, P.entries) : decode16<MULTI>(cur[u].a, P.entries);
                             bool surv_me = false;
                             int s = -1;
+                            uint64_t my_d = 0;
                             ST(3);  // decode (the first one of a chunk: + whatever the chunk's tuples still took to arrive)
                             if (act) {
                                 const TupleEval ev = eval_tuple<MULTI>(P.g, P.entries, t);
+                                my_d = ev.dbits;
                                 ST(4);  // cell, key, distance
                                 uint64_t seen;
                                 s = stream_find_or_insert<NSLOT, LIMIT>(s_kd, ev.key, cell_hash(ev.key), &s_ncell, &seen);
@@ -250,8 +265,9 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                                 base = uni32(base);
                                 const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                                 if (surv_me && pos < surv_cap) {
-                                    surv[2 * (size_t)pos] = make_uint4((uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx);
-                                    surv[2 * (size_t)pos + 1] = make_uint4(t.w0, t.w1, (uint32_t)s, 0u);
+                                    surv[SURV_WORDS * (size_t)pos] = make_uint4((uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx);
+                                    surv[SURV_WORDS * (size_t)pos + 1] = make_uint4(t.w0, t.w1, (uint32_t)s, 0u);
+                                    surv[SURV_WORDS * (size_t)pos + 2] = make_uint4((uint32_t)my_d, (uint32_t)(my_d >> 32), 0u, 0u);
                                 }
                             }
                             ST(7);  // survivor append
@@ -264,6 +280,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
 #ifdef PCQ_STAMPS
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
+                    settle(nb);
                     ST(8);  // hand-over: the next chunk's tuples have arrived
                 }
             }
@@ -287,17 +304,15 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
         } else {
             // ---- 2. exact: (distance, file order) among the survivors ----
             for (uint32_t i = threadIdx.x; i < nsurv; i += NT) {
-                const uint4 ra = surv[2 * (size_t)i], rb = surv[2 * (size_t)i + 1];
-                GridTuple t{(int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, ra.w, rb.x, rb.y};
+                const uint4 ra = surv[SURV_WORDS * (size_t)i], rb = surv[SURV_WORDS * (size_t)i + 1], rc = surv[SURV_WORDS * (size_t)i + 2];
                 const uint32_t s = rb.z;
-                if (eval_tuple(P.g, P.entries, t).dbits == s_kd[s].dist) atomicMin(&s_ord[s], (uint32_t)ord_of(t));
+                if (((uint64_t)rc.x | ((uint64_t)rc.y << 32)) == s_kd[s].dist) atomicMin(&s_ord[s], ra.w + 1u);  // (ord_of: the place + 1)
             }
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < nsurv; i += NT) {
-                const uint4 ra = surv[2 * (size_t)i], rb = surv[2 * (size_t)i + 1];
-                GridTuple t{(int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, ra.w, rb.x, rb.y};
+                const uint4 ra = surv[SURV_WORDS * (size_t)i], rb = surv[SURV_WORDS * (size_t)i + 1], rc = surv[SURV_WORDS * (size_t)i + 2];
                 const uint32_t s = rb.z;
-                if (s_ord[s] == (uint32_t)ord_of(t) && eval_tuple(P.g, P.entries, t).dbits == s_kd[s].dist) s_widx[s] = i;
+                if (s_ord[s] == ra.w + 1u && ((uint64_t)rc.x | ((uint64_t)rc.y << 32)) == s_kd[s].dist) s_widx[s] = i;
             }
             __syncthreads();
             // compaction: thread t owns slots [t * SPT, ...): the cells leave in slot order
@@ -348,7 +363,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                     *P.wrecs.b(o) = *P.orecs.b(oi);
                 } else {
                     const uint32_t wi = s_widx[s];
-                    const uint4 ra = surv[2 * (size_t)wi], rb = surv[2 * (size_t)wi + 1];
+                    const uint4 ra = surv[SURV_WORDS * (size_t)wi], rb = surv[SURV_WORDS * (size_t)wi + 1];
                     st_record(P.wrecs, o, P.entries.get((rb.x >> 8) & 0xff), (int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, rb.x, rb.y, R_HAS);
                 }
                 o++;

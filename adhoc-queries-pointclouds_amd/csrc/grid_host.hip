@@ -311,20 +311,37 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         hipLaunchKernelGGL(k_probe_distinct, dim3(probe_blocks), dim3(BLOCK), 0, s, src, eref, g, d_set, cap - 1, d_stats);
         PCQ_HIP(hipGetLastError());
     }
-    uint32_t h_tuples = 0;
-    unsigned long long distinct = 0;
-    PCQ_HIP(hipMemcpyAsync(&h_tuples, d_binbase + F1, 4, hipMemcpyDeviceToHost, s));
-    PCQ_HIP(hipMemcpyAsync(&distinct, d_stats, 8, hipMemcpyDeviceToHost, s));
+    // the two numbers the host decides on come back through the context's pinned words, stored there by a kernel: a
+    // device-to-host hipMemcpy into pageable memory is staged by the runtime (tens of microseconds each, two of them here)
+    hipLaunchKernelGGL(k_fold_numbers, dim3(1), dim3(64), 0, s, d_binbase + F1, d_stats, ctx->h_scalars + 32);
+    PCQ_HIP(hipGetLastError());
     PCQ_HIP(hipStreamSynchronize(s));  // also: the pageable sources above have been read
-    const uint32_t h_probe[2] = {0, h_tuples};
-    const uint64_t m = h_probe[1], w_old = gs->wtotal;
+    const uint64_t m = ctx->h_scalars[32], w_old = gs->wtotal;
+    const unsigned long long distinct = ctx->h_scalars[33];
     ctx->grid_last_tuples = (int64_t)m;
     if (m == 0) {
         grid_free_pending(ctx, gs);
         return PCQ_OK;
     }
     ctx->grid_folds++;
-    if (T > 2u * BIG_FB && m < 2ull * T * F1) {  // fragments of less than two tuples on average: copy the bins together first
+    // estimated cells per level-1 bin -> fold the bins directly, or cut them again first
+    uint32_t f2 = 1;
+    if (ctx->grid_f2 > 0) {
+        f2 = (uint32_t)ctx->grid_f2;
+    } else if (probed && (double)m / F1 + old_per_bin > BIG_DIRECT) {
+        const double est = (double)distinct / PROBE_BINS + old_per_bin;
+        if (est > BIG_DIRECT) {
+            f2 = (uint32_t)std::ceil(est / SMALL_TARGET);
+            if (f2 > F2_MAX) f2 = F2_MAX;
+        }
+    }
+
+    // Fragments of less than two tuples on average (a scan whose tiles shed most of their tuples, a box that few points match):
+    // the window readers would hold a handful of tuples per round, so the bins are copied together first — for the readers
+    // that have a window.  The streaming fold of a coarse grid takes the fragments 64 at a time whatever they hold: it reads
+    // the sparse run as it is (the copy was 0.25 ms of a 0.9 ms fold on the scan-ordered file).
+    const bool stream_reads_bins = f2 == 1 && ctx->grid_stream != 0 && !(w_old && gs->f2 != 1);
+    if (T > 2u * BIG_FB && m < 2ull * T * F1 && !stream_reads_bins) {
         const uint32_t Tc = F1, Tcp = F1, Tcp1 = (F1 + 1 + 63) & ~63u;
         uint8_t *d_comp = nullptr;
         uint32_t *d_cpre = nullptr;
@@ -341,18 +358,6 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         PCQ_HIP(hipGetLastError());
         src = BinSrc{d_cpre, d_cstart, d_caddr, Tc, Tcp1, Tcp};
         ctx->grid_compactions++;
-    }
-
-    // estimated cells per level-1 bin -> fold the bins directly, or cut them again first
-    uint32_t f2 = 1;
-    if (ctx->grid_f2 > 0) {
-        f2 = (uint32_t)ctx->grid_f2;
-    } else if (probed && (double)m / F1 + old_per_bin > BIG_DIRECT) {
-        const double est = (double)distinct / PROBE_BINS + old_per_bin;
-        if (est > BIG_DIRECT) {
-            f2 = (uint32_t)std::ceil(est / SMALL_TARGET);
-            if (f2 > F2_MAX) f2 = F2_MAX;
-        }
     }
 
     bool level2_exact = false;
@@ -446,7 +451,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         const uint32_t resident_wgs = (uint32_t)ctx->num_cus * (big ? 1u : 3u);  // what fits the LDS: the rest of the partitions is looped over
         if (!rc) rc = att.get((size_t)resident_wgs * (big ? BIG_SLOTS : SMALL_SLOTS) * 5, &d_pay);  // parked payloads, per resident workgroup
         if (!rc && (dense || (big && stream))) rc = att.get(nparts, &d_defer);
-        if (!rc && big && stream) rc = att.get((size_t)resident_wgs * surv_cap * 2, &d_surv);
+        if (!rc && big && stream) rc = att.get((size_t)resident_wgs * surv_cap * 3, &d_surv);  // (three 16-byte words per survivor: grid_fold_stream.hip)
         if (rc) return rc;
         hipLaunchKernelGGL(k_winner_room, dim3((nparts + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, d_tot, w_old ? ocount : nullptr, nparts, limit, d_room);
         hipLaunchKernelGGL(k_scan_piece_sums, dim3(npieces), dim3(1024), 0, s, d_room, nparts, d_pieces);
@@ -484,8 +489,10 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         }
         PCQ_HIP(hipGetLastError());
         unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        PCQ_HIP(hipMemcpyAsync(st, d_stats, sizeof st, hipMemcpyDeviceToHost, s));
+        hipLaunchKernelGGL(k_words_out, dim3(1), dim3(64), 0, s, (const uint64_t *)d_stats, ctx->h_scalars + 40, 8u);
+        PCQ_HIP(hipGetLastError());
         PCQ_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < 8; i++) st[i] = ctx->h_scalars[40 + i];
         if (staged_level2 && st[5]) {  // a sub-partition outgrew its region (cells with very many points): count first, then cut
             level2_exact = true;
             ctx->grid_level2_exact++;

@@ -326,6 +326,9 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "grid_agg")) {
         if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "grid_agg must be 0 (adaptive), 1 (always) or 2 (never)");
         ctx->grid_agg = (int)value;
+    } else if (!strcmp(key, "emit_sparse_max")) {
+        if (value < 0 || value > 2048) return pcq_fail(PCQ_ERR_ARG, "emit_sparse_max must be 0..2048");
+        ctx->emit_sparse_max = (int)value;
     } else if (!strcmp(key, "grid_block_pad")) {
         if (value < 0 || value > 65536) return pcq_fail(PCQ_ERR_ARG, "grid_block_pad must be 0..65536");
         ctx->grid_block_pad = (int)value;
@@ -386,6 +389,7 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     else if (!strcmp(key, "grid_tuple16")) *value = ctx->grid_tuple16;
     else if (!strcmp(key, "grid_stream")) *value = ctx->grid_stream;
     else if (!strcmp(key, "grid_block_pad")) *value = ctx->grid_block_pad;
+    else if (!strcmp(key, "emit_sparse_max")) *value = ctx->emit_sparse_max;
     else if (!strcmp(key, "grid_deferred")) *value = ctx->grid_deferred;
     else if (!strcmp(key, "grid_last_tuples")) *value = ctx->grid_last_tuples;
     else if (!strcmp(key, "grid_folds")) *value = ctx->grid_folds;
@@ -1081,11 +1085,22 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
         ctx->stage_busy[0] = ctx->stage_busy[1] = false;
         return code;
     };
+    // The second pair is pinned by a thread of this call WHILE the first chunk is read into the first pair (4 ms each, the
+    // first scan of a context only; joined before anything else happens).
+    int rc2 = PCQ_OK;
+    std::thread second_pair;
+    if (nchunks > 1 && !ctx->h_stage[1])
+        second_pair = std::thread([&] {
+            (void)hipSetDevice(ctx->device);
+            rc2 = ensure_stage(ctx, stage_need, 2);
+        });
     rc = stage(0);
+    if (second_pair.joinable()) second_pair.join();
     if (rc) return fail(rc);
-    stamp("first chunk read and its transfer issued");
+    if (rc2) return fail(pcq_fail(PCQ_ERR_HIP, "staging allocation failed (second pair)"));
+    stamp("first chunk read and its transfer issued, second staging pair ready");
     if (nchunks > 1) {
-        rc = ensure_stage(ctx, stage_need, 2);
+        rc = ensure_stage(ctx, stage_need, 2);  // (no-op unless the pair above was not asked for)
         if (rc) return fail(rc);
     }
     for (uint64_t k = 0; k < nchunks; k++) {

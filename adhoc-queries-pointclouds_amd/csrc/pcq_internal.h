@@ -164,6 +164,7 @@ struct pcq_ctx {
                                         // 1 = every tile, 2 = never; the results are the same, the tuples moved are not
     int grid_stream = 1;                // option (tests): 0 = a coarse grid's bins are folded by k_fold<BIG> (the fallback of the streaming fold) only
     int64_t grid_deferred = 0;          // diagnostics: bins the streaming fold left to k_fold<BIG> (survivor list outgrown)
+    int emit_sparse_max = 64;           // option: a tile of 2048 points with at most this many matches is written by k_emit_sparse (0 = never)
     bool scanned_before = false;        // (PCQ_TIMING: the first host / file scan of a context prints where its time goes)
     int grid_block_pad = 0;             // option: 16-byte units between the end of a tile's block of tuples and the next block
     int grid_tuple16 = 1;               // option (tests): 0 = every scan writes 24-byte tuples (the form a 16-byte tuple falls back to), 2 = 16-byte tuples without the second level's selector

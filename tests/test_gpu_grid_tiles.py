@@ -1,6 +1,7 @@
-"""GPU parity for round 3's grid collector (csrc/grid.hip): pass 0 writes one block of tuples per tile of 5120 points and
+"""GPU parity for the grid collector (csrc/grid_*.hip): pass 0 writes one block of tuples per tile of 5120 points and
 folds a tile's duplicate cells before they travel; the fold reads the blocks back as per-bin fragment lists; tuples are
-20 bytes without a colour column and 24 with one.  Same cells and winners as the oracle (grid_sampling.rs:49-105) in
+16 bytes (class byte — and, where two more top bytes are free, the second level's selector — inside the coordinates) or
+24 (a colour column, a box wider than 2^24 units on every axis, a world-space predicate).  Same cells and winners as the oracle (grid_sampling.rs:49-105) in
 every mode of the tile fold, on scan-ordered files with equal-distance ties that straddle tile boundaries, with aliased
 keys inside tiles, and with runs of both tuple widths in one fold."""
 import importlib
@@ -130,6 +131,56 @@ def test_grid_runs_of_both_tuple_widths_in_one_fold(oracle, cell):
     og.free()
 
 
+@pytest.mark.parametrize("stream", [1, 0])
+@pytest.mark.parametrize("tuple16", [1, 2, 0])
+def test_grid_tuple_formats_and_fold_shapes_agree(oracle, tuple16, stream):
+    """Round 4: 16-byte tuples with (1) and without (2) the second level's selector in their spare top bytes, or 24-byte
+    tuples throughout (0); a coarse grid's bins folded as a stream (1) or by k_fold<BIG> (0).  Every combination gives the
+    oracle's cells and winners — with ONE entry (the specialised kernels: no entry lookup, 16-byte loads), with TWO files of
+    different scale in one grid (several entries: the tile -> entry table, the general kernels), with a class query (no class
+    byte in the tuple), with a box wider than 2^24 units on every axis (no room for the class byte: 24 bytes), coarse and
+    dense (second level: selector or recomputed cell)."""
+    n = 300_007
+    specs_ = [small_spec(8801, n, fmt=1, scale=(0.01, 0.01, 0.01)), small_spec(8802, n, fmt=1, scale=(0.02, 0.01, 0.005), offset=(1.0, -2.0, 0.5)),
+              small_spec(8803, n, fmt=1, scale=(1e-5, 1e-5, 1e-5), lo=(-2_000_000_000, -2_000_000_000, -2_000_000_000), span=(4_000_000_000, 4_000_000_000, 4_000_000_000))]
+    images = [oracle.synth_image(sp, transposed=True) for sp in specs_]
+    hdrs = [oracle.parse_header(im[:400].tobytes()) for im in images]
+    with pkg.Context(0) as ctx:
+        ctx.set_option("grid_tuple16", tuple16)
+        ctx.set_option("grid_stream", stream)
+        files = [DevFile(ctx, im, h) for im, h in zip(images, hdrs)]
+        try:
+            cases = [("one entry, coarse", [0], 5.0, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds"),
+                     ("one entry, dense", [0], 0.2, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds"),
+                     ("two entries, coarse", [0, 1], 5.0, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds"),
+                     ("two entries, dense", [0, 1], 0.2, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds"),
+                     ("class query, coarse", [0, 1], 4.0, (-100.0, -100.0, -20.0), (120.0, 100.0, 20.0), "class"),
+                     ("class query, dense", [0], 0.3, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "class"),
+                     ("box wider than 2^24 units on every axis", [2], 2000.0, (-20000.0, -20000.0, -20000.0), (20000.0, 20000.0, 20000.0), "bounds")]
+            for name, which, cell, bmin, bmax, kind in cases:
+                og = oracle.grid_collector(bmin, bmax, cell)
+                gg = ctx.grid_collector(bmin, bmax, cell)
+                first = 0
+                for k in which:
+                    cols = files[k].columns(True)
+                    cols.first_index = first
+                    first += n
+                    if kind == "bounds":
+                        assert oracle.search_last_bounds(images[k], bmin, bmax, og) == 0
+                        lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdrs[k].scale), list(hdrs[k].offset))
+                        ctx.scan_dev(cols, pkg.Predicate.bounds(lmin, lmax), gg)
+                    else:
+                        assert oracle.search_last_class(images[k], 2, og) == 0
+                        ctx.scan_dev(cols, pkg.Predicate.classification(2), gg)
+                assert og.point_count() > 0, name
+                check_same(gg, og)
+                gg.free()
+                og.free()
+        finally:
+            for f in files:
+                f.free()
+
+
 def test_grid_flush_folds_now_and_changes_nothing(oracle):
     """pcq_collector_flush: a per-file collector kept until all files are searched (main.rs:153-161) folds when its file
     is done; more scans may follow, the result is that of one fold at the end."""
@@ -165,8 +216,9 @@ def test_grid_flush_folds_now_and_changes_nothing(oracle):
 
 @pytest.mark.parametrize("fmt", [1, 2])
 def test_grid_short_fragments_are_copied_together_first(oracle, fmt):
-    """More than 1024 tiles and fewer than two tuples per (tile, bin) fragment — a box that few points match: the fold
-    copies the bins together before it reads them (grid_compactions), coarse and dense grids alike."""
+    """More than 1024 tiles and fewer than two tuples per (tile, bin) fragment — a box that few points match: the readers that
+    keep a window of the bin's fragment list (the second level; k_fold<BIG>, the streaming fold's fallback) get the bins copied
+    together first (grid_compactions); the streaming fold of a coarse grid reads the sparse run as it is."""
     n = 1100 * TILE + 77
     spec = small_spec(6061 + fmt, n, fmt=fmt)
     image = oracle.synth_image(spec, transposed=True)
@@ -176,17 +228,20 @@ def test_grid_short_fragments_are_copied_together_first(oracle, fmt):
     with pkg.Context(0) as ctx:
         f = DevFile(ctx, image, hdr)
         try:
-            for cell, f2 in ((2.0, 0), (0.1, 7)):   # the big fold reads the copied bins directly; forced: through the second level
+            # coarse: the streaming fold on the sparse run itself / the same through k_fold<BIG> on the copied bins; dense (forced): the second level
+            for cell, f2, stream, copied in ((2.0, 0, 1, 0), (2.0, 0, 0, 1), (0.1, 7, 1, 1)):
                 ctx.set_option("grid_f2", f2)
+                ctx.set_option("grid_stream", stream)
                 og = oracle.grid_collector(bmin, bmax, cell)
                 assert oracle.search_last_bounds(image, bmin, bmax, og) == 0
                 before = ctx.get_option("grid_compactions")
                 gg = ctx.grid_collector(bmin, bmax, cell)
                 ctx.scan_dev(f.columns(True), pkg.Predicate.bounds(lmin, lmax), gg)
                 check_same(gg, og)
-                assert ctx.get_option("grid_compactions") == before + 1
+                assert ctx.get_option("grid_compactions") == before + copied
                 assert ctx.get_option("grid_last_f2") == (f2 or 1)
                 gg.free()
                 og.free()
+            ctx.set_option("grid_stream", 1)
         finally:
             f.free()

@@ -189,6 +189,46 @@ def test_buffer_collector_dev_matches_oracle(oracle, gpu_ctx, fmt, n):
         f.free()
 
 
+@pytest.mark.parametrize("fmt", [1, 2, 3])
+@pytest.mark.parametrize("sparse_max", [0, 1, 9, 256, 2048])
+def test_buffer_collector_sparse_and_dense_tiles_write_the_same_records(oracle, gpu_ctx, fmt, sparse_max):
+    """The emit has two writers per scan: k_emit_points (a tile's whole image through LDS) for tiles with more than
+    `emit_sparse_max` matches and k_emit_sparse (one wave per tile, from the match bits the count pass leaves) for the others.
+    Whatever the threshold — never, one match, a few, the default, always — the records and their order are the oracle's:
+    boxes that keep about 1 / 1000, 1 %, 10 %, a half and all of a file in random order, class queries, two scans appended
+    into one collector (a record base that is no multiple of 16), a file whose last tile is ragged."""
+    n = 2048 * 9 + 777
+    spec = small_spec(9100 + fmt, n, fmt=fmt, scale=(0.01, 0.02, 0.05), offset=(100.0, -200.0, 7.5))
+    image = oracle.synth_image(spec, transposed=True)
+    hdr = oracle.parse_header(image[:400].tobytes())
+    f = DevFile(gpu_ctx, image, hdr)
+    lo, hi = np.array(hdr.min), np.array(hdr.max)
+    gpu_ctx.set_option("emit_sparse_max", sparse_max)
+    try:
+        ob, gb = oracle.buffer_collector(), gpu_ctx.buffer_collector()
+        for frac in (0.001, 0.01, 0.1, 0.5, 1.0):
+            bmin = [float(lo[0]), float(lo[1]), float(lo[2])]
+            bmax = [float(lo[0] + (hi[0] - lo[0]) * frac), float(hi[1]), float(hi[2])]
+            lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+            one_o, one_g = oracle.buffer_collector(), gpu_ctx.buffer_collector()
+            for o, g in ((one_o, one_g), (ob, gb)):
+                assert oracle.search_last_bounds(image, bmin, bmax, o) == 0
+                gpu_ctx.scan_dev(f.columns(True), pkg.Predicate.bounds(lmin, lmax), g)
+            assert one_g.point_count() == one_o.point_count(), frac
+            assert one_g.points().tobytes() == one_o.points().tobytes(), frac
+            one_o.free(), one_g.free()
+        for cls in (2, 6, 19):
+            for o, g in ((ob, gb),):
+                assert oracle.search_last_class(image, cls, o) == 0
+                gpu_ctx.scan_dev(f.columns(True), pkg.Predicate.classification(cls), g)
+        assert gb.point_count() == ob.point_count() > n
+        assert gb.points().tobytes() == ob.points().tobytes()
+        ob.free(), gb.free()
+    finally:
+        gpu_ctx.set_option("emit_sparse_max", 64)
+        f.free()
+
+
 @pytest.mark.parametrize("fmt", [1, 2])
 @pytest.mark.parametrize("n", [2048 * 5, 50_021])
 def test_buffer_collector_skips_tiles_without_a_match(oracle, gpu_ctx, fmt, n):

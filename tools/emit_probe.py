@@ -9,6 +9,8 @@ binding = importlib.import_module("adhoc-queries-pointclouds_amd.binding")
 specs = importlib.import_module("adhoc-queries-pointclouds_amd.synth_specs")
 q, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 163_000_000
 with pkg.Context(0) as ctx:
+    if os.environ.get("EMIT_SPARSE_MAX") is not None:  # threshold of the sparse writer (0 = dense writer only)
+        ctx.set_option("emit_sparse_max", int(os.environ["EMIT_SPARSE_MAX"]))
     spec = specs.synth_ca13(points_per_file=n)[5]
     xyz, cls = ctx.alloc(12 * n), ctx.alloc(n)
     ctx.synth_fill(spec, 0, n, xyz, cls)
