@@ -85,8 +85,7 @@ constexpr int DENSE_NT = 512, DENSE_K = 3;  // k_fold_dense: the same chunk (153
 constexpr int L2_NT = 512;             // exact second level: threads per workgroup (one workgroup per level-1 bin)
 constexpr int L2_UNROLL = 4;
 constexpr int L2_FB = 1024;            // exact second level, alias gather: fragments in the reader's window
-constexpr int L2S_NT = 1024, L2S_ITEMS = 4, L2S_TILE = L2S_NT * L2S_ITEMS;  // k_level2: one workgroup per CU, tiles of 4096 tuples
-constexpr int L2S_FB = 2048;           // k_level2: fragments in the reader's window (about five tiles)
+// (k_level2: 1024 or 512 threads per workgroup, tiles of four tuples per thread, a reader's window of two fragments per thread)
 constexpr int L2_STAGED_F2 = 1024;     // largest fan-out of the staged form (its per-tile tables live in LDS)
 constexpr int PROBE_BINS = 2;          // bins whose distinct cells are counted to estimate the grid's density
 constexpr uint64_t ALIAS_QUADRATIC = 8192;  // aliased tuples up to which the replay order comes from the quadratic rank kernel
@@ -285,6 +284,26 @@ __device__ __forceinline__ uint32_t sub_of(uint64_t h, uint32_t f2) { return sub
 template <int NSLOT>
 __device__ __forceinline__ uint32_t slot_of(uint64_t h) { return (uint32_t)((((h >> 16) & 0x1fffffull) * NSLOT) >> 21); }
 
+
+// Cross-lane steps of one wave in the vector pipe itself (DPP: an operand modifier, no trip through the LDS crossbar that
+// ds_bpermute takes).
+// the value of the next lane (lane 63: `last`)
+__device__ __forceinline__ uint32_t wave_next_lane(uint32_t v, uint32_t last) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)last, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+// inclusive prefix maximum over the 64 lanes (unsigned; a lane without a source keeps 0, the maximum's identity; a
+// broadcast that reaches a row twice does no harm to a maximum)
+__device__ __forceinline__ uint32_t wave_max_scan(uint32_t v) {
+#define PCQ_DPP_MAX(ctrl) v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, 0xf, 0xf, false))
+    PCQ_DPP_MAX(0x111);  // row_shr:1
+    PCQ_DPP_MAX(0x112);  // row_shr:2
+    PCQ_DPP_MAX(0x114);  // row_shr:4
+    PCQ_DPP_MAX(0x118);  // row_shr:8
+    PCQ_DPP_MAX(0x142);  // row_bcast:15 — lane 15 of a row to the whole next row
+    PCQ_DPP_MAX(0x143);  // row_bcast:31 — lane 31 to the upper half
+#undef PCQ_DPP_MAX
+    return v;
+}
 
 // Pointers that a kernel reads out of a table in memory are "generic" to the compiler: it emits flat loads, and
 // a flat load counts on the LDS counter as well — every wait for an LDS operation (each barrier of the tile loops) would
@@ -744,7 +763,7 @@ __global__ void k_fold_numbers(const uint32_t *__restrict__ tuples, const unsign
 __global__ void k_words_out(const uint64_t *__restrict__ src, uint64_t *__restrict__ h_out, uint32_t n);
 // grid_level2.hip
 __global__ void k_level2_direct(Level2Params P);
-template <bool ANYWIDE, bool MULTI>
+template <bool ANYWIDE, bool MULTI, int NT>
 __global__ void k_level2(Level2Params P);
 __global__ void k_unpack_old_dir(const uint32_t *__restrict__ ooff2, uint32_t nparts, uint64_t *__restrict__ obase2, uint32_t *__restrict__ ocount2);
 __global__ void k_old_per_bin(const uint32_t *__restrict__ ocount, uint32_t f2old, uint32_t *__restrict__ obin);

@@ -393,23 +393,9 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
 // k_fold_dense's insert: the compare-and-swap IS the probe (a cell's first tuple — three of four in a dense grid — takes
 // one LDS round trip instead of a read and then the swap), and the probe sequence is double hashing: with linear probing
 // the 64 lanes of a wave leave the loop together, after the longest cluster any of them ran into.  The table can never
-// fill up (at most a chunk of 1536 tuples goes into 2048 slots), so the loop ends; the cells are counted per wave.
-template <int NSLOT>
-__device__ __forceinline__ uint32_t lds_insert_dense(uint64_t *s_key, uint64_t key, uint64_t h, bool *fresh) {
-    static_assert((NSLOT & (NSLOT - 1)) == 0, "the step below visits every slot of a power-of-two table");
-    uint32_t s = slot_of<NSLOT>(h);
-    const uint32_t step = ((uint32_t)(h >> 15) & (NSLOT - 1)) | 1u;
-    *fresh = false;
-    for (;;) {
-        const uint64_t prev = atomicCAS((unsigned long long *)&s_key[s], (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key);
-        if (prev == PCQ_EMPTY_KEY) {
-            *fresh = true;
-            return s;
-        }
-        if (prev == key) return s;
-        s = (s + step) & (NSLOT - 1);
-    }
-}
+// fill up (at most a chunk of 1536 tuples goes into 2048 slots), so the loop ends; the cells are counted per wave.  (The
+// loop itself is in the kernel: a thread's tuples probe together.)
+static_assert((SMALL_SLOTS & (SMALL_SLOTS - 1)) == 0, "the dense fold's probe step visits every slot of a power-of-two table");
 
 // WIDE = false: the second level's output holds 16-byte tuples (one aligned load each); MULTI = false: one entry — no
 // load in a branch anywhere between the tuples' loads and their use (EntryRef::get).  Everything else: <true, true>.
@@ -420,7 +406,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     __shared__ uint64_t s_dist[NSLOT];
     __shared__ uint64_t s_ord[NSLOT];
     __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32];
-    __shared__ uint32_t s_ncell, s_wsum[NT / 64];
+    __shared__ uint32_t s_ncell, s_tie, s_wsum[NT / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint8_t *tuples = P.tuples;
     const bool wide = WIDE && P.wide;
@@ -428,7 +414,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     const uint32_t *off = P.off;
     for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
     for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
-    if (threadIdx.x == 0) s_ncell = 0;
+    if (threadIdx.x == 0) s_ncell = 0, s_tie = 0;
     unsigned long long winners = 0;  // thread 0: this workgroup's winners
 
     // Three partitions deep: the current one (range, output base, and — 16-byte tuples — its tuples, asked for a whole
@@ -596,23 +582,26 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
             continue;
         }
         ST(4);  // cell count + barrier
+        // phase 2: among the tuples at the minimum, the earliest in file order.  Two tuples of one cell at exactly the same
+        // distance are rare (a point stored twice), so every tuple at its cell's minimum is taken for the winner and ranked at
+        // once — ONE barrier for the order and the ranks —; a tuple that finds another one's order in its slot raises s_tie,
+        // and only then the winners are told apart and ranked again.
         bool cand[FOLD_K];
+        bool tie = false;
 #pragma unroll
-        for (int k = 0; k < FOLD_K; k++) {  // phase 2: among the tuples at the minimum, the earliest in file order
+        for (int k = 0; k < FOLD_K; k++) {
             cand[k] = slot[k] >= 0 && dbits[k] == s_dist[slot[k]];
-            if (cand[k]) atomicMin((unsigned long long *)&s_ord[slot[k]], (unsigned long long)ord_of(tu[k]));
+            if (cand[k]) tie |= atomicMin((unsigned long long *)&s_ord[slot[k]], (unsigned long long)ord_of(tu[k])) != ~0ull;
         }
-        __syncthreads();
+        if (tie) s_tie = 1;
         // Every occupied slot has exactly one tuple at (minimum distance, earliest order): its thread writes the cell.  The
         // winners leave wave by wave and, inside a wave, tuple slot by tuple slot (k), in lane order: the lanes of ONE store
         // instruction then write one contiguous run of keys (8 bytes each) and of records — with a per-thread order the same
         // instruction wrote every second or third record of a 4 KiB span, and the 8-byte key stores reached the memory side as
         // partial writes (counted: 6.7 GB written and 1.9 GB fetched beyond the tuples for 4.9 GB of winners).
-        ST(5);  // phase 2 + barrier
         uint32_t cnt_k[FOLD_K], rank_k[FOLD_K], wave_total = 0;
 #pragma unroll
         for (int k = 0; k < FOLD_K; k++) {
-            cand[k] = cand[k] && s_ord[slot[k]] == ord_of(tu[k]);
             const unsigned long long m = __ballot(cand[k]);
             cnt_k[k] = (uint32_t)__popcll(m);
             rank_k[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
@@ -620,6 +609,22 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
         }
         if (lane == 0) s_wsum[wave] = wave_total;
         __syncthreads();
+        ST(5);  // phase 2, ranks + barrier
+        if (s_tie) {  // (the same for the whole workgroup) equal distances in some cell: the earliest in file order only
+            wave_total = 0;
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) {
+                cand[k] = cand[k] && s_ord[slot[k]] == ord_of(tu[k]);
+                const unsigned long long m = __ballot(cand[k]);
+                cnt_k[k] = (uint32_t)__popcll(m);
+                rank_k[k] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                wave_total += cnt_k[k];
+            }
+            __syncthreads();  // everybody has read s_tie and the first sums
+            if (lane == 0) s_wsum[wave] = wave_total;
+            if (threadIdx.x == 0) s_tie = 0;
+            __syncthreads();
+        }
         uint32_t before = 0, total = 0;
 #pragma unroll
         for (int w = 0; w < NT / 64; w++) {

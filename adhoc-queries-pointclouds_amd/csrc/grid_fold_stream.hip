@@ -26,7 +26,7 @@ namespace pcqgrid {
 // search across the lanes (six bpermutes): no window in LDS, nothing shared with the other waves.
 // ANYWIDE = false: every pending run has 16-byte tuples (one aligned load per tuple, four registers in flight); MULTI = false:
 // one entry (EntryRef::get) — the common fold of one file; anything else takes the <true, true> form.
-// A survivor is three 16-byte words: {x, y, z, place in the pending stream} {w0 (with the entry), w1, slot, 0} {distance bits, 0, 0}
+// A survivor is three 16-byte words: {x, y, z, place in the pending stream} {w0 (with the entry), w1, 0, 0} {distance bits, slot, place}
 // — the distance travels with it: recomputed in both exact passes, cell and distance of 8 M survivors were a seventh of the kernel.
 constexpr int SURV_WORDS = 3;
 
@@ -42,7 +42,7 @@ template <int NSLOT, int LIMIT>
 __device__ __forceinline__ int stream_find_or_insert(KeyDist *s_kd, uint64_t key, uint64_t h, uint32_t *s_ncell, uint64_t *seen) {
     static_assert(NSLOT == 6400, "the probe step below is chosen coprime with 6400");
     uint32_t s = slot_of<NSLOT>(h);
-    uint32_t step = ((((uint32_t)(h >> 38)) & 1023u) << 1) | 1u;
+    uint32_t step = ((((uint32_t)(h >> 38)) & 1023u) << 1) | 1u;  // (stream_probe_step)
     if (step % 5u == 0) step += 2;
     for (int probes = 0; probes < NSLOT; probes++) {
         const uint64_t k = __hip_atomic_load(&s_kd[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -65,25 +65,60 @@ __device__ __forceinline__ int stream_find_or_insert(KeyDist *s_kd, uint64_t key
     return -1;
 }
 
+__device__ __forceinline__ uint32_t stream_probe_step(uint64_t h) {
+    uint32_t step = ((((uint32_t)(h >> 38)) & 1023u) << 1) | 1u;
+    if (step % 5u == 0) step += 2;
+    return step;
+}
+// stream_find_or_insert with the first probe already made by the caller (key k and distance d found at slot s)
+template <int NSLOT, int LIMIT>
+__device__ __forceinline__ int stream_resolve(KeyDist *s_kd, uint64_t key, uint32_t s, uint32_t step, uint64_t k, uint64_t d, uint32_t *s_ncell, uint64_t *seen) {
+    for (int probes = 0; probes < NSLOT; probes++) {
+        if (k == key) {
+            *seen = d;
+            return (int)s;
+        }
+        if (k == PCQ_EMPTY_KEY) {
+            const uint64_t prev = atomicCAS((unsigned long long *)&s_kd[s].key, (unsigned long long)PCQ_EMPTY_KEY, (unsigned long long)key);
+            if (prev == PCQ_EMPTY_KEY || prev == key) {
+                *seen = ~0ull;  // (somebody may have been faster: too large is safe)
+                if (prev == PCQ_EMPTY_KEY && atomicAdd(s_ncell, 1u) >= (uint32_t)LIMIT) return -1;
+                return (int)s;
+            }
+        }
+        s += step;
+        if (s >= (uint32_t)NSLOT) s -= NSLOT;
+        k = __hip_atomic_load(&s_kd[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        d = __hip_atomic_load(&s_kd[s].dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return -1;
+}
+
 template <int NSLOT, int NT, int LIMIT, int U, bool ANYWIDE, bool MULTI>
 __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t nparts, uint32_t surv_cap, uint4 *__restrict__ surv_scratch) {
     constexpr int SPT = (NSLOT + NT - 1) / NT;  // slots per thread in the compaction
     constexpr int NW = NT / 64;
     __shared__ __attribute__((aligned(16))) KeyDist s_kd[NSLOT];  // key; f64 bits of the best squared distance (monotone for d >= 0)
-    __shared__ uint32_t s_ord[NSLOT];    // file order (+ 1) of the winner: 0 = an earlier fold's winner, ~0 = none yet
-    __shared__ uint32_t s_widx[NSLOT];   // the winner's place in the survivor list (an earlier fold's winner: its index among the partition's old winners)
+    // the winner: file order (+ 1; 0 = an earlier fold's winner) << 32 | its place in the survivor list (an earlier fold's
+    // winner: its index among the partition's old winners); ~0 = none yet.  ONE atomicMin finds the earliest survivor at
+    // the minimum and says where its record lies.
+    __shared__ uint64_t s_oi[NSLOT];
     __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32];
     __shared__ uint32_t s_ncell, s_over, s_nsurv, s_next_batch, s_wsum[NW];
+    __shared__ uint32_t s_map[NW][64 * U];  // per wave: tag << 6 | fragment lane, at the fragment's first tuple's place in the chunk
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const BinSrc &S = P.src;
     uint4 *surv = surv_scratch + (size_t)blockIdx.x * surv_cap * SURV_WORDS;
     ST_DECL;
+#pragma unroll
+    for (int u = 0; u < U; u++) s_map[wave][u * 64 + lane] = 0;  // (tag 0: never)
+    uint32_t tag = 0;                                              // chunks this wave has asked for (26 bits: 4 G tuples per wave)
     for (uint32_t it = blockIdx.x; it < nparts; it += gridDim.x) {
         const uint32_t p = xcd_order(it, nparts);
         const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
         const uint64_t old_base = P.okeys ? P.obase[p] : 0;
         const uint64_t out_base = P.wbase[p];
-        for (int t = threadIdx.x; t < NSLOT; t += NT) s_kd[t].key = PCQ_EMPTY_KEY, s_kd[t].dist = ~0ull, s_ord[t] = ~0u;
+        for (int t = threadIdx.x; t < NSLOT; t += NT) s_kd[t].key = PCQ_EMPTY_KEY, s_kd[t].dist = ~0ull, s_oi[t] = ~0ull;
         for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
         if (threadIdx.x == 0) s_ncell = 0, s_over = 0, s_nsurv = 0, s_next_batch = 0;
         __syncthreads();
@@ -98,8 +133,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                 continue;
             }
             const uint4 ra = *P.orecs.a(old_base + i), rb = *P.orecs.b(old_base + i);
-            s_widx[s] = i;
-            s_ord[s] = 0;
+            s_oi[s] = i;  // (order 0)
             if (rec_flags(rb) & R_ALIAS) {
                 atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
             } else {
@@ -176,6 +210,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                 Batch cb = take_batch(), nb = take_batch();
                 settle(cb), settle(nb);
                 uint32_t g = cb.first;  // the next tuple to ask for
+                uint32_t carry = 0;     // the lane (fragment of the batch) the last tuple asked for lies in
                 RawTuple cur[U], nxt[U];
                 uint32_t cur_wide = 0, nxt_wide = 0;  // bit u: tuple u of the chunk is 24 bytes
                 uint32_t cur_n = 0, nxt_n = 0;        // tuples in the chunk
@@ -186,28 +221,36 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                         cb = nb;
                         settle(cb);  // (settled already, unless the batch before it was empty)
                         g = cb.first;
+                        carry = 0;
                         nb = take_batch();
                     }
                     if (cb.f0 < S.T) {
-                        const uint32_t stop = cb.end, f0 = cb.f0;
+                        const uint32_t stop = cb.end;
                         nxt_n = stop - g < (uint32_t)(64 * U) ? stop - g : (uint32_t)(64 * U);
-                        // tuple number -> lane of the batch: the last lane whose prefix is <= q (empty fragments repeat their
-                        // neighbour's and are never it); the U binary searches step together, U bpermutes in flight per step
+                        // tuple number -> lane of the batch.  The fragments SAY where they start: lane f puts its number at its first
+                        // tuple's place in the wave's map (a fragment with no tuple says nothing; a start in front of the chunk is the
+                        // fragment the chunk before ended in: `carry`), and a tuple's fragment is the largest number at or in front
+                        // of its place — one prefix maximum, six DPP steps in the vector pipe.  (A binary search per tuple over the
+                        // 64 prefixes — six dependent ds_bpermute round trips and 36 instructions — was 45 of the 259 vector
+                        // instructions the kernel spent per 64 tuples, and the kernel is bound by them: profiles/r04_grid_progress.txt.)
+                        // The map is never cleared: an entry counts when it carries this chunk's tag.
+                        tag++;
+                        {
+                            const uint32_t rel = cb.myp - g;  // (a start in front of g wraps around: out of range)
+                            const uint32_t nextp = wave_next_lane(cb.myp, stop);
+                            if (nextp != cb.myp && rel < (uint32_t)(64 * U)) s_map[wave][rel] = (tag << 6) | lane;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
                         uint32_t qq[U], lo[U];
 #pragma unroll
                         for (int u = 0; u < U; u++) {
                             const uint32_t q = g + (uint32_t)u * 64 + lane;
-                            qq[u] = q < stop ? q : stop - 1;
-                            lo[u] = 0;
-                        }
-#pragma unroll
-                        for (int st = 32; st >= 1; st >>= 1) {
-                            uint32_t pc[U];
-#pragma unroll
-                            for (int u = 0; u < U; u++) pc[u] = (uint32_t)__shfl((int)cb.myp, (int)(lo[u] + st), 64);
-#pragma unroll
-                            for (int u = 0; u < U; u++)
-                                if (f0 + lo[u] + st < S.T && pc[u] <= qq[u]) lo[u] += st;
+                            qq[u] = q < stop ? q : stop - 1;  // (a place behind the batch's end holds no start: its lane re-reads the last tuple)
+                            const uint32_t m = s_map[wave][u * 64 + lane];
+                            lo[u] = wave_max_scan((m >> 6) == tag ? m & 63u : 0u);
+                            lo[u] = lo[u] > carry ? lo[u] : carry;
+                            carry = uni32((uint32_t)__builtin_amdgcn_readlane((int)lo[u], 63));
                         }
                         uint32_t al[U], ah[U];
 #pragma unroll
@@ -229,49 +272,77 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                     }
                     ST(2);  // issue stage
                     if (cur_n) {
+                        // The chunk's U tuples go through the stages TOGETHER — all evaluated, then all first probes asked for,
+                        // then resolved, compared, and ONE append for the survivors of the whole chunk: the LDS round trips of
+                        // the U tuples overlap instead of following one another (probe and append were a quarter of the
+                        // kernel's cycles as four dependent chains per chunk: profiles/r04_grid_progress.txt, stamps).
+                        uint64_t key[U], dbits[U];
+                        bool alias[U], act[U];
 #pragma unroll
                         for (int u = 0; u < U; u++) {
-                            const bool act = (uint32_t)u * 64 + lane < cur_n;
+                            act[u] = (uint32_t)u * 64 + lane < cur_n;
                             const GridTuple t = ANYWIDE ? decode_raw<MULTI>(cur[u], (cur_wide >> u) & 1, P.entries) : decode16<MULTI>(cur[u].a, P.entries);
-                            bool surv_me = false;
-                            int s = -1;
-                            uint64_t my_d = 0;
-                            ST(3);  // decode (the first one of a chunk: + whatever the chunk's tuples still took to arrive)
-                            if (act) {
-                                const TupleEval ev = eval_tuple<MULTI>(P.g, P.entries, t);
-                                my_d = ev.dbits;
-                                ST(4);  // cell, key, distance
-                                uint64_t seen;
-                                s = stream_find_or_insert<NSLOT, LIMIT>(s_kd, ev.key, cell_hash(ev.key), &s_ncell, &seen);
-                                ST(5);  // hash + probe
-                                if (s < 0) {
-                                    s_over = 1;
-                                } else {
-                                    if (ev.alias) atomicOr(&s_aliasbits[s >> 5], 1u << (s & 31));
-                                    if (ev.dbits <= seen) {
-                                        if (ev.dbits < seen) {
-                                            const uint64_t old = atomicMin((unsigned long long *)&s_kd[s].dist, (unsigned long long)ev.dbits);
-                                            if (ev.dbits < old) s_ord[s] = ~0u;  // a new minimum: an earlier fold's winner is out (racing writers store the same value)
-                                        }
-                                        surv_me = true;
-                                    }
-                                }
-                            }
-                            ST(6);  // compare, lower the minimum
-                            const unsigned long long m = __ballot(surv_me);
-                            if (m) {  // (the same for the whole wave)
-                                uint32_t base = 0;
-                                if (lane == 0) base = atomicAdd(&s_nsurv, (uint32_t)__popcll(m));
-                                base = uni32(base);
-                                const uint32_t pos = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                                if (surv_me && pos < surv_cap) {
-                                    surv[SURV_WORDS * (size_t)pos] = make_uint4((uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx);
-                                    surv[SURV_WORDS * (size_t)pos + 1] = make_uint4(t.w0, t.w1, (uint32_t)s, 0u);
-                                    surv[SURV_WORDS * (size_t)pos + 2] = make_uint4((uint32_t)my_d, (uint32_t)(my_d >> 32), 0u, 0u);
-                                }
-                            }
-                            ST(7);  // survivor append
+                            const TupleEval ev = eval_tuple<MULTI>(P.g, P.entries, t);
+                            key[u] = ev.key, dbits[u] = ev.dbits, alias[u] = ev.alias;
                         }
+                        ST(4);  // decode (+ whatever the chunk's tuples still took to arrive), cell, key, distance
+                        uint32_t ps[U], pstep[U];
+                        uint64_t k0[U], d0[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            const uint64_t h = cell_hash(key[u]);
+                            ps[u] = slot_of<NSLOT>(h);
+                            pstep[u] = stream_probe_step(h);
+                            k0[u] = __hip_atomic_load(&s_kd[ps[u]].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            d0[u] = __hip_atomic_load(&s_kd[ps[u]].dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a stale value is only too large)
+                        }
+                        int sl[U];
+                        bool surv_me[U];
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            sl[u] = -1;
+                            surv_me[u] = false;
+                            if (!act[u]) continue;
+                            uint64_t seen;
+                            sl[u] = stream_resolve<NSLOT, LIMIT>(s_kd, key[u], ps[u], pstep[u], k0[u], d0[u], &s_ncell, &seen);
+                            if (sl[u] < 0) {
+                                s_over = 1;
+                                continue;
+                            }
+                            if (alias[u]) atomicOr(&s_aliasbits[sl[u] >> 5], 1u << (sl[u] & 31));
+                            if (dbits[u] <= seen) {
+                                if (dbits[u] < seen) {
+                                    const uint64_t old = atomicMin((unsigned long long *)&s_kd[sl[u]].dist, (unsigned long long)dbits[u]);
+                                    if (dbits[u] < old) s_oi[sl[u]] = ~0ull;  // a new minimum: an earlier fold's winner is out (racing writers store the same value)
+                                }
+                                surv_me[u] = true;
+                            }
+                        }
+                        ST(5);  // hash, probe, compare, lower the minimum
+                        unsigned long long m[U];
+                        uint32_t nsv = 0;
+#pragma unroll
+                        for (int u = 0; u < U; u++) {
+                            m[u] = __ballot(surv_me[u]);
+                            nsv += (uint32_t)__popcll(m[u]);
+                        }
+                        if (nsv) {  // (the same for the whole wave)
+                            uint32_t base = 0;
+                            if (lane == 0) base = atomicAdd(&s_nsurv, nsv);
+                            base = uni32(base);
+#pragma unroll
+                            for (int u = 0; u < U; u++) {
+                                const uint32_t pos = base + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull));
+                                base += (uint32_t)__popcll(m[u]);
+                                if (surv_me[u] && pos < surv_cap) {
+                                    const GridTuple t = ANYWIDE ? decode_raw<MULTI>(cur[u], (cur_wide >> u) & 1, P.entries) : decode16<MULTI>(cur[u].a, P.entries);
+                                    surv[SURV_WORDS * (size_t)pos] = make_uint4((uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx);
+                                    surv[SURV_WORDS * (size_t)pos + 1] = make_uint4(t.w0, t.w1, 0u, 0u);
+                                    surv[SURV_WORDS * (size_t)pos + 2] = make_uint4((uint32_t)dbits[u], (uint32_t)(dbits[u] >> 32), (uint32_t)sl[u], t.idx);  // (all the exact pass reads)
+                                }
+                            }
+                        }
+                        ST(7);  // survivor append
                     }
                     if (!nxt_n) break;
 #pragma unroll
@@ -302,27 +373,39 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                 P.defer_list[atomicAdd(&P.stats[3], 1ull)] = p;
             }
         } else {
-            // ---- 2. exact: (distance, file order) among the survivors ----
-            for (uint32_t i = threadIdx.x; i < nsurv; i += NT) {
-                const uint4 ra = surv[SURV_WORDS * (size_t)i], rb = surv[SURV_WORDS * (size_t)i + 1], rc = surv[SURV_WORDS * (size_t)i + 2];
-                const uint32_t s = rb.z;
-                if (((uint64_t)rc.x | ((uint64_t)rc.y << 32)) == s_kd[s].dist) atomicMin(&s_ord[s], ra.w + 1u);  // (ord_of: the place + 1)
-            }
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < nsurv; i += NT) {
-                const uint4 ra = surv[SURV_WORDS * (size_t)i], rb = surv[SURV_WORDS * (size_t)i + 1], rc = surv[SURV_WORDS * (size_t)i + 2];
-                const uint32_t s = rb.z;
-                if (s_ord[s] == ra.w + 1u && ((uint64_t)rc.x | ((uint64_t)rc.y << 32)) == s_kd[s].dist) s_widx[s] = i;
+            // ---- 2. exact: among the survivors at their cell's minimum distance, the earliest in file order ----
+            for (uint32_t i0 = threadIdx.x; i0 < nsurv; i0 += NT * 4) {  // (four records asked for together: the list comes from the L2)
+                uint4 rc[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t i = i0 + q * NT;
+                    rc[q] = surv[SURV_WORDS * (size_t)(i < nsurv ? i : nsurv - 1) + 2];
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t i = i0 + q * NT;
+                    if (i < nsurv && ((uint64_t)rc[q].x | ((uint64_t)rc[q].y << 32)) == s_kd[rc[q].z].dist)
+                        atomicMin((unsigned long long *)&s_oi[rc[q].z], (unsigned long long)(((uint64_t)rc[q].w + 1) << 32 | i));  // (ord_of: the place + 1)
+                }
             }
             __syncthreads();
             // compaction: thread t owns slots [t * SPT, ...): the cells leave in slot order
             uint32_t mine = 0;
             const int s0 = threadIdx.x * SPT;
-            uint64_t keys[SPT];
+            uint64_t keys[SPT], oi[SPT];
+            // the winners' records are asked for ALL TOGETHER, before anything waits for one of them: the list lies in HBM,
+            // the rest of the chip is streaming, and a round trip takes ~10 us then — one after the other the thread's seven
+            // slots were a sixth of the kernel (a slot without a survivor record reads record 0; nothing is done with it)
+            uint4 wra[SPT], wrb[SPT];
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
-                keys[j] = s0 + j < NSLOT ? s_kd[s0 + j].key : PCQ_EMPTY_KEY;
+                const bool in = s0 + j < NSLOT;
+                keys[j] = in ? s_kd[s0 + j].key : PCQ_EMPTY_KEY;
+                oi[j] = in ? s_oi[s0 + j] : ~0ull;
                 mine += keys[j] != PCQ_EMPTY_KEY ? 1 : 0;
+                const bool from_list = keys[j] != PCQ_EMPTY_KEY && (oi[j] >> 32) != 0 && oi[j] != ~0ull;
+                const size_t wi = from_list ? (uint32_t)oi[j] : 0u;
+                wra[j] = surv[SURV_WORDS * wi], wrb[j] = surv[SURV_WORDS * wi + 1];
             }
             uint32_t incl = mine;
 #pragma unroll
@@ -357,14 +440,13 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                         }
                     *P.wrecs.a(o) = a;
                     *P.wrecs.b(o) = b;
-                } else if (s_ord[s] == 0) {  // the earlier winner stays
-                    const uint64_t oi = old_base + s_widx[s];
-                    *P.wrecs.a(o) = *P.orecs.a(oi);
-                    *P.wrecs.b(o) = *P.orecs.b(oi);
+                } else if ((oi[j] >> 32) == 0) {  // the earlier winner stays
+                    const uint64_t at = old_base + (uint32_t)oi[j];
+                    *P.wrecs.a(o) = *P.orecs.a(at);
+                    *P.wrecs.b(o) = *P.orecs.b(at);
                 } else {
-                    const uint32_t wi = s_widx[s];
-                    const uint4 ra = surv[SURV_WORDS * (size_t)wi], rb = surv[SURV_WORDS * (size_t)wi + 1];
-                    st_record(P.wrecs, o, P.entries.get((rb.x >> 8) & 0xff), (int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, rb.x, rb.y, R_HAS);
+                    const uint4 ra = wra[j], rb = wrb[j];
+                    st_record(P.wrecs, o, P.entries.get<MULTI>((rb.x >> 8) & 0xff), (int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, rb.x, rb.y, R_HAS);
                 }
                 o++;
             }
@@ -383,7 +465,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
     ST_FLUSH(P.stats);
 }
 
-template __global__ void k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 4, false, false>(FoldParams, uint32_t, uint32_t, uint4 *);
+template __global__ void k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 2, false, false>(FoldParams, uint32_t, uint32_t, uint4 *);
 template __global__ void k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 2, true, true>(FoldParams, uint32_t, uint32_t, uint4 *);
 
 }  // namespace pcqgrid

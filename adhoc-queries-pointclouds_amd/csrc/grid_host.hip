@@ -406,8 +406,8 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
                 L.obinbase = d_obinbase, L.okeys2 = d_okeys2, L.orecs2 = RecArr{d_orecs2, w_old}, L.ooff2 = d_ooff2;
             }
             PCQ_HIP(hipMemsetAsync(d_stats, 0, 64, s));
-            if (staged && (any_wide || eref.multi)) hipLaunchKernelGGL((k_level2<true, true>), dim3(F1), dim3(L2S_NT), 0, s, L);
-            else if (staged) hipLaunchKernelGGL((k_level2<false, false>), dim3(F1), dim3(L2S_NT), 0, s, L);
+            if (staged && (any_wide || eref.multi)) hipLaunchKernelGGL((k_level2<true, true, 1024>), dim3(F1), dim3(1024), 0, s, L);
+            else if (staged) hipLaunchKernelGGL((k_level2<false, false, 1024>), dim3(F1), dim3(1024), 0, s, L);
             else hipLaunchKernelGGL(k_level2_direct, dim3(F1), dim3(L2_NT), 0, s, L);
             PCQ_HIP(hipGetLastError());
             if (f2 > 1) {
@@ -435,8 +435,11 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         uint8_t *n_wrecs = nullptr;
         uint32_t *n_wcount = nullptr, *d_palias = nullptr, *d_pay = nullptr, *d_defer = nullptr;
         uint4 *d_surv = nullptr;
-        // the streaming fold's survivor list per resident workgroup: a quarter of the mean bin (beyond that the filter does not pay)
-        uint32_t surv_cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(4096, m / F1 / 4));
+        // The streaming fold's survivor list per resident workgroup: twice the mean bin, at most 65536 records (3 MB) — for the
+        // large bins of a whole file that is a fifth of the bin (beyond that the filter does not pay: the bin goes to
+        // k_fold<BIG>), while a sparse run — tiles that folded their own duplicates hand on what IS, mostly, a running minimum —
+        // keeps all of its tuples if it must (a quarter of the mean bin sent every bin of the scan-ordered file to the fallback).
+        uint32_t surv_cap = (uint32_t)std::min<uint64_t>(65536, std::max<uint64_t>(4096, 2 * (m / F1)));
         const bool stream = ctx->grid_stream != 0;
         const bool dense = !big && !w_old;  // k_fold_dense first, k_fold for what it leaves
         const uint32_t npieces = (nparts + SCAN_PIECE - 1) / SCAN_PIECE;
@@ -482,7 +485,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
             if (big && stream) {  // the bins as streams; a bin with more running minima than its survivor list holds is left to k_fold<BIG>
                 F.defer_list = d_defer;
                 if (any_wide || eref.multi) hipLaunchKernelGGL((k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 2, true, true>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts, surv_cap, d_surv);
-                else hipLaunchKernelGGL((k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 4, false, false>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts, surv_cap, d_surv);
+                else hipLaunchKernelGGL((k_fold_stream<BIG_SLOTS, BIG_NT, BIG_LIMIT, 2, false, false>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts, surv_cap, d_surv);
             }
             if (big) hipLaunchKernelGGL((k_fold<BIG_SLOTS, BIG_NT, BIG_K, BIG_LIMIT, true, false, 4>), dim3(resident), dim3(BIG_NT), 0, s, F, nparts);
             else hipLaunchKernelGGL((k_fold<SMALL_SLOTS, SMALL_NT, SMALL_K, SMALL_LIMIT, false, true, 3>), dim3(resident), dim3(SMALL_NT), 0, s, F, nparts);

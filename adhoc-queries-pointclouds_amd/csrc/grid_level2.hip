@@ -75,8 +75,12 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
 // ANYWIDE = false: every pending run has 16-byte tuples, and so has the output (four registers per tuple in flight, one aligned
 // load, one aligned store); MULTI = false: one entry — no load in a branch between the prefetch of the next tile and its use
 // (EntryRef::get).  Everything else: <true, true>.
-template <bool ANYWIDE, bool MULTI>
-__global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
+// NT: threads per workgroup — 1024: one workgroup per CU, tiles of 4096 tuples.  (512 — TWO workgroups per CU, tiles of 2048,
+// one's barriers and one-wave scan under the other's loads and stores — was measured 0.3 ms SLOWER on ca13 XL at 10 m:
+// DESIGN.md section 10.)
+template <bool ANYWIDE, bool MULTI, int NT>
+__global__ __launch_bounds__(NT, NT == 1024 ? 4 : 4) void k_level2(Level2Params P) {
+    constexpr int L2S_NT = NT, L2S_ITEMS = 4, L2S_TILE = NT * 4, L2S_FB = NT * 2;
     constexpr int BPT = L2_STAGED_F2 / L2S_NT;  // sub-partitions per thread when the cursors move on
     static_assert(BPT >= 1 && BPT * L2S_NT == L2_STAGED_F2, "whole sub-partitions per thread");
     __shared__ uint32_t s_cur[L2_STAGED_F2], s_ohist[L2_STAGED_F2], s_ocur[L2_STAGED_F2];
@@ -162,7 +166,7 @@ __global__ __launch_bounds__(L2S_NT) void k_level2(Level2Params P) {
                         constexpr int BPL = L2_STAGED_F2 / 64;
                         uint32_t v[BPL], mine = 0;
 #pragma unroll
-                        for (int q = 0; q < BPL; q++) v[q] = s_cnt[lane * BPL + q], mine += v[q];
+                        for (int q = 0; q < BPL; q++) v[q] = (uint32_t)(lane * BPL + q) < f2 ? s_cnt[lane * BPL + q] : 0u, mine += v[q];  // (nothing counts beyond f2)
                         uint32_t incl = mine;
 #pragma unroll
                         for (int off = 1; off < 64; off <<= 1) {
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(BLOCK) void k_old_per_bin(const uint32_t *__restric
     obin[b] = t;
 }
 
-template __global__ void k_level2<false, false>(Level2Params);
-template __global__ void k_level2<true, true>(Level2Params);
+template __global__ void k_level2<false, false, 1024>(Level2Params);
+template __global__ void k_level2<true, true, 1024>(Level2Params);
 
 }  // namespace pcqgrid

@@ -392,3 +392,43 @@ def test_every_entry_point_runs_on_the_context_device():
             assert "PCQ_ON_DEVICE_OF_" in head, f"{f}: {name} does not open with the device guard"
             checked += 1
     assert checked >= 25
+
+
+def _kernel_asm(hip_file):
+    """gfx950 assembly of one translation unit of the library (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+                          "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(PKG, "csrc"), "-S", "--cuda-device-only", "-o", "-",
+                          os.path.join(PKG, "csrc", hip_file)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return out.stdout.split("\n")
+
+
+def _kernel_bodies(lines, name_part):
+    for i, l in enumerate(lines):
+        if l.startswith("_Z") and name_part in l and l.rstrip().split(":")[0].endswith(l.split(":")[0]) and ":" in l:
+            j = i
+            while not lines[j].startswith(".Lfunc_end"):
+                j += 1
+            yield l.split(":")[0], lines[i:j]
+
+
+def test_hot_loops_keep_their_loads_in_flight():
+    """Two properties of the compiled gfx950 code that decide the grid collector's speed and that a source edit can lose
+    without any test noticing (both were lost once in round 4): pass 0 must not wait for a class byte
+    right behind its load — that wait also covers the next tile's positions, the kernel's prefetch — and the streaming fold's
+    main loop (between its third and fourth barrier) must hold no scratch access."""
+    for name, body in _kernel_bodies(_kernel_asm("grid_pass0.hip"), "k_p0_part"):
+        for n, l in enumerate(body):
+            if "global_load_ubyte" in l or "global_load_ushort" in l:
+                assert not any("vmcnt(0)" in x for x in body[n + 1:n + 3]), (name, n, l.strip())
+    found = 0
+    for name, body in _kernel_bodies(_kernel_asm("grid_fold_stream.hip"), "k_fold_stream"):
+        if "ELb0ELb0E" not in name:  # the single-entry, 16-byte form: the one that runs on a file's own grid
+            continue
+        found += 1
+        barriers = [n for n, l in enumerate(body) if l.strip().startswith("s_barrier")]
+        assert len(barriers) >= 4, name
+        loop = body[barriers[2]:barriers[3]]
+        assert len(loop) > 500  # (the loop is there)
+        assert not [l for l in loop if l.strip().startswith("scratch_")], name
+    assert found == 1
