@@ -285,6 +285,31 @@ template <int NSLOT>
 __device__ __forceinline__ uint32_t slot_of(uint64_t h) { return (uint32_t)((((h >> 16) & 0x1fffffull) * NSLOT) >> 21); }
 
 
+// A kernel's by-value arguments, read again where they are used.  The arguments arrive in scalar registers at the
+// kernel's start, and a fold kernel has more of them (grid, entry, pointers: 150 dwords) than the 102 scalar registers: the
+// compiler parks the surplus in the lanes of a vector register and fetches every scalar back with a v_readlane — a VECTOR
+// instruction — each time it is used: 27 of them per tuple in the streaming fold, a quarter of its vector instructions,
+// in a kernel bound by exactly those (profiles/r04_grid_progress.txt).  The argument segment is ordinary constant memory:
+// karg<T>(offset) loads a T out of it through the scalar cache, and the empty asm hides from the compiler that the
+// address is the same in every round of the loop, so the load stays where it is written and its registers are free again
+// behind the last use.
+typedef const __attribute__((address_space(4))) uint32_t *KArgPtr;
+__device__ __forceinline__ KArgPtr karg_base() {
+    KArgPtr p = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+template <typename T>
+__device__ __forceinline__ T karg(KArgPtr base, size_t offset) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    uint32_t w[sizeof(T) / 4];
+#pragma unroll
+    for (size_t i = 0; i < sizeof(T) / 4; i++) w[i] = base[offset / 4 + i];
+    T r;
+    __builtin_memcpy(&r, w, sizeof(T));
+    return r;
+}
+
 // Cross-lane steps of one wave in the vector pipe itself (DPP: an operand modifier, no trip through the LDS crossbar that
 // ds_bpermute takes).
 // the value of the next lane (lane 63: `last`)

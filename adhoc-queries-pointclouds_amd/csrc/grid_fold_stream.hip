@@ -278,11 +278,15 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                         // kernel's cycles as four dependent chains per chunk: profiles/r04_grid_progress.txt, stamps).
                         uint64_t key[U], dbits[U];
                         bool alias[U], act[U];
+                        // (grid and entry out of the argument segment, here: see karg())
+                        const KArgPtr ka = karg_base();
+                        const GridRef G = {karg<DevGridFast>(ka, offsetof(FoldParams, g) + offsetof(GridRef, f)), P.g.full};
+                        const EntryRef E = karg<EntryRef>(ka, offsetof(FoldParams, entries));
 #pragma unroll
                         for (int u = 0; u < U; u++) {
                             act[u] = (uint32_t)u * 64 + lane < cur_n;
-                            const GridTuple t = ANYWIDE ? decode_raw<MULTI>(cur[u], (cur_wide >> u) & 1, P.entries) : decode16<MULTI>(cur[u].a, P.entries);
-                            const TupleEval ev = eval_tuple<MULTI>(P.g, P.entries, t);
+                            const GridTuple t = ANYWIDE ? decode_raw<MULTI>(cur[u], (cur_wide >> u) & 1, E) : decode16<MULTI>(cur[u].a, E);
+                            const TupleEval ev = eval_tuple<MULTI>(G, E, t);
                             key[u] = ev.key, dbits[u] = ev.dbits, alias[u] = ev.alias;
                         }
                         ST(4);  // decode (+ whatever the chunk's tuples still took to arrive), cell, key, distance
@@ -335,7 +339,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                                 const uint32_t pos = base + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull));
                                 base += (uint32_t)__popcll(m[u]);
                                 if (surv_me[u] && pos < surv_cap) {
-                                    const GridTuple t = ANYWIDE ? decode_raw<MULTI>(cur[u], (cur_wide >> u) & 1, P.entries) : decode16<MULTI>(cur[u].a, P.entries);
+                                    const GridTuple t = ANYWIDE ? decode_raw<MULTI>(cur[u], (cur_wide >> u) & 1, E) : decode16<MULTI>(cur[u].a, E);
                                     surv[SURV_WORDS * (size_t)pos] = make_uint4((uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx);
                                     surv[SURV_WORDS * (size_t)pos + 1] = make_uint4(t.w0, t.w1, 0u, 0u);
                                     surv[SURV_WORDS * (size_t)pos + 2] = make_uint4((uint32_t)dbits[u], (uint32_t)(dbits[u] >> 32), (uint32_t)sl[u], t.idx);  // (all the exact pass reads)
