@@ -228,6 +228,7 @@ struct DevGridFast {
     double bmin[3], qk[3], qmax[3], guard[3];
     double cell_size;
     uint32_t mask[3], shift[3];
+    uint32_t keys_wide, _pad;
 };
 template <typename G>
 __device__ __forceinline__ CellFast cell_fast(const G &g, double px, double py, double pz) {
@@ -268,13 +269,24 @@ __device__ __forceinline__ double centre_dist_fast(const G &g, const CellFast &c
     return (a + b) + c;
 }
 
-// The partition hash of a cell key: one 64-bit multiply (Fibonacci hashing; the murmur finaliser costs two and three
-// shifts, a third of what is left of a point's instructions).  Bits 63..55 pick the level-1 bin, bits 52..37 the
-// second-level partition, bits 36..16 the first LDS slot; the fold of the upper half in front makes every key bit count
-// in the slot bits too.
-__device__ __forceinline__ uint64_t cell_hash(uint64_t k) {
-    k ^= k >> 32;
-    return k * 0x9e3779b97f4a7c15ull;
+// The partition hash of a cell key.  Bits 63..55 pick the level-1 bin, bits 52..37 the second-level partition, bits 35..18
+// the first LDS slot.  Two 32-bit multiplies of the key as a 32-bit word (Fibonacci hashing, twice): the upper word for bin
+// and partition — its lower bits, which a product leaves poor, stirred with its upper ones —, the lower word's upper half for
+// the slot.  (One 64-bit multiply is four 32-bit ones, each a quarter-rate instruction — 16 of a fold's ~200 vector issue
+// slots per tuple, in kernels bound by those; the murmur finaliser it replaced in round 3 cost two of them and three shifts.)
+// `wide` (DevGrid::keys_wide, the same for the whole launch): the grid's keys can have more than 32 bits — their upper word
+// goes through a multiply of its own first.  (Folded onto the lower word as it is, the few values a narrow z range leaves
+// in the upper word met the low bits of x: whole groups of keys with ONE hash, 1.9 probes per insert instead of 1.3.)
+// Keys that come out as the same word share bin, partition and probe sequence; the tables compare whole keys, so that
+// costs probes, never results.  Probes per insert, simulated on ca13's cells at 10 m (second level of 240) and 100 m:
+// 1.28 / 1.49 — the 64-bit multiply's 1.27 / 1.50, random hashing 1.36 / 1.53.
+__device__ __forceinline__ uint64_t cell_hash(uint64_t k, uint32_t wide) {
+    uint32_t k32 = (uint32_t)k;
+    if (wide) k32 ^= (uint32_t)(k >> 32) * 0x27d4eb2fu;
+    uint32_t hi = k32 * 0x9e3779b9u;
+    const uint32_t lo = k32 * 0x85ebca6bu;
+    hi ^= hi >> 15;
+    return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ uint32_t bin_of(uint64_t h) { return (uint32_t)(h >> (64 - F1_BITS)); }
 // the second-level partition comes from the 16 bits under the bin bits
@@ -282,7 +294,13 @@ __device__ __forceinline__ uint32_t sel16_of(uint64_t h) { return (uint32_t)(h >
 __device__ __forceinline__ uint32_t sub_from_sel16(uint32_t sel16, uint32_t f2) { return (sel16 * f2) >> 16; }
 __device__ __forceinline__ uint32_t sub_of(uint64_t h, uint32_t f2) { return sub_from_sel16(sel16_of(h), f2); }
 template <int NSLOT>
-__device__ __forceinline__ uint32_t slot_of(uint64_t h) { return (uint32_t)((((h >> 16) & 0x1fffffull) * NSLOT) >> 21); }
+__device__ __forceinline__ uint32_t slot_of(uint64_t h) {
+    // 18 bits x 13 bits: one full-rate 24-bit multiply.  The product stays below 2^31 on purpose: the compiler takes the
+    // 24-bit multiply's result for a signed number that did not overflow (with 19 bits it shifted it arithmetically, and
+    // a slot came out negative).
+    static_assert(NSLOT < (1 << 13), "the product must fit 31 bits");
+    return __umul24((uint32_t)(h >> 18) & 0x3ffffu, (uint32_t)NSLOT) >> 18;
+}
 
 
 // A kernel's by-value arguments, read again where they are used.  The arguments arrive in scalar registers at the
@@ -497,6 +515,9 @@ struct GridRef {
     DevGridFast f;
     const DevGrid *full;
 };
+__device__ __forceinline__ uint32_t keys_wide_of(const GridRef &g) { return g.f.keys_wide; }
+__device__ __forceinline__ uint32_t keys_wide_of(const DevGrid &g) { return g.keys_wide; }
+__device__ __forceinline__ uint32_t keys_wide_of(const DevGridFast &g) { return g.keys_wide; }
 // key, alias flag and distance bits of a world position: THE definition every pass uses (pass 0's duplicate fold must see
 // the bits the fold will see).
 __device__ __forceinline__ TupleEval eval_world(const GridRef &g, double px, double py, double pz) {
@@ -523,7 +544,7 @@ __device__ __forceinline__ TupleEval eval_tuple(const G &g, const EntryRef &entr
 // the second-level partition of a tuple, from its cell (a 16-byte tuple has no room for the 16 hash bits pass 0 had at hand)
 template <bool MULTI = true, typename G>
 __device__ __forceinline__ uint32_t tuple_sub(const G &g, const EntryRef &entries, const GridTuple &t, uint32_t f2) {
-    return sub_of(cell_hash(eval_tuple<MULTI>(g, entries, t).key), f2);
+    return sub_of(cell_hash(eval_tuple<MULTI>(g, entries, t).key, keys_wide_of(g)), f2);
 }
 // The same for a tuple still in its memory form: the selector pass 0 left in it when its entry stores one, its cell otherwise.
 template <bool MULTI = true, typename G>
@@ -690,6 +711,17 @@ struct P0Pack {
     uint32_t top_shift[3];  // which byte of V = class | sel16 << 8 rides in each coordinate's top byte (fmt_top_shift)
     uint32_t block_bytes;   // from one tile's block to the next
 };
+// pass 0's arguments (one struct: the kernel reads its parts out of the argument segment by offset — karg())
+struct P0Args {
+    DevCols c;
+    DevPred pr;
+    DevGrid g;
+    P0Pack pk16;
+    uint8_t *out;      // the tile blocks
+    uint16_t *dir;     // the directory rows
+    uint32_t ntiles, tile0;
+    int agg_mode;
+};
 
 struct DevRun {        // one pending pass-0 run
     const uint8_t *tuples;
@@ -767,8 +799,7 @@ constexpr int SCAN_PIECE = 4096;
 
 // grid_pass0.hip
 template <int KIND, bool RGB, bool PACKED, bool WIDE>
-__global__ void k_p0_part(DevCols c, DevPred pr, DevGrid g, uint32_t ntiles, uint8_t *__restrict__ out, uint16_t *__restrict__ dir, uint32_t tile0,
-                          P0Pack pk16, int agg_mode);
+__global__ void k_p0_part(P0Args A);
 // grid_dir.hip
 __global__ void k_dir_transpose(const DevRun *__restrict__ runs, int nruns, uint32_t T, uint32_t Tp, uint32_t Tp1, uint16_t *__restrict__ startT,
                                 uint32_t *__restrict__ preT, uint64_t *__restrict__ tile_addr, uint8_t *__restrict__ tile_entry);

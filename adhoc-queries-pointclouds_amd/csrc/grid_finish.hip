@@ -69,7 +69,7 @@ __global__ __launch_bounds__(BLOCK) void k_alias_replay(const AliasItem *__restr
     if (e >= n) return;
     const uint64_t key = sorted[e].key;
     if (e > 0 && sorted[e - 1].key == key) return;
-    const uint64_t h = cell_hash(key);
+    const uint64_t h = cell_hash(key, keys_wide_of(P.g));
     const uint32_t p = bin_of(h) * f2 + sub_of(h, f2);
     const uint64_t wb = P.wbase[p];
     const uint32_t wn = P.wcount[p];

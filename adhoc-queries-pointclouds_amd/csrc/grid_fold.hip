@@ -27,7 +27,7 @@ __device__ __forceinline__ void fold_chunk(const FoldParams &P, const GridTuple 
         if (i >= cnt) continue;
         const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
         dbits[k] = ev.dbits;
-        const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, cell_hash(ev.key), s_ncell);
+        const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, cell_hash(ev.key, keys_wide_of(P.g)), s_ncell);
         if (s < 0) {
             *s_over = 1;
             continue;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
         // earlier winners first: their distance is recomputed from the record (same f64 expressions, same bits)
         for (uint32_t i = threadIdx.x; i < n_old; i += NT) {
             const uint64_t key = P.okeys[old_base + i];
-            const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, key, cell_hash(key), &s_ncell);
+            const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, key, cell_hash(key, keys_wide_of(P.g)), &s_ncell);
             if (s < 0) {
                 s_over = 1;
                 continue;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold(FoldParams P, uint32_t n
                 if (i >= cnt) continue;
                 const TupleEval ev = eval_tuple(P.g, P.entries, tu[k]);
                 dbits[k] = ev.dbits;
-                const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, cell_hash(ev.key), &s_ncell);
+                const int s = lds_find_or_insert<NSLOT, LIMIT>(s_key, ev.key, cell_hash(ev.key, keys_wide_of(P.g)), &s_ncell);
                 if (s < 0) {
                     s_over = 1;
                     continue;
@@ -476,26 +476,32 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
         uint64_t key[FOLD_K], dbits[FOLD_K];
         bool alias[FOLD_K];
         ST(0);  // ranges of the partition after next, asking for the next one's tuples
-#pragma unroll
-        for (int k = 0; k < FOLD_K; k++) {
-            if (WIDE) {
-                const uint32_t i = k * NT + threadIdx.x;
-                const uint8_t *src = tuples + (uint64_t)(cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0))) * ts;
-                tu[k] = ld_tuple<MULTI>(src, wide, P.entries);
-            } else {
-                tu[k] = decode16<MULTI>(rcur[k], P.entries);
-            }
-        }
         uint32_t inexact = 0;  // bit k: tuple k is next to a cell boundary (or outside the short computation's range)
+        {
+            // (grid and entry out of the argument segment, here: see karg())
+            const KArgPtr ka = karg_base();
+            const DevGridFast GF = karg<DevGridFast>(ka, offsetof(DenseParams, g) + offsetof(GridRef, f));
+            const EntryRef E = karg<EntryRef>(ka, offsetof(DenseParams, entries));
 #pragma unroll
-        for (int k = 0; k < FOLD_K; k++) {
-            const GridEntryDev e = P.entries.get<MULTI>((tu[k].w0 >> 8) & 0xff);
-            const double px = world(tu[k].x, e.scale[0], e.offset[0]), py = world(tu[k].y, e.scale[1], e.offset[1]),
-                         pz = world(tu[k].z, e.scale[2], e.offset[2]);
-            const CellFast cf = cell_fast(P.g.f, px, py, pz);
-            key[k] = key_fast(P.g.f, cf, &alias[k]);
-            dbits[k] = (uint64_t)__double_as_longlong(centre_dist_fast(P.g.f, cf, px, py, pz));
-            inexact |= cf.ok ? 0u : 1u << k;
+            for (int k = 0; k < FOLD_K; k++) {
+                if (WIDE) {
+                    const uint32_t i = k * NT + threadIdx.x;
+                    const uint8_t *src = tuples + (uint64_t)(cur_lo + (i < cnt ? i : (cnt ? cnt - 1 : 0))) * ts;
+                    tu[k] = ld_tuple<MULTI>(src, wide, E);
+                } else {
+                    tu[k] = decode16<MULTI>(rcur[k], E);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < FOLD_K; k++) {
+                const GridEntryDev e = E.get<MULTI>((tu[k].w0 >> 8) & 0xff);
+                const double px = world(tu[k].x, e.scale[0], e.offset[0]), py = world(tu[k].y, e.scale[1], e.offset[1]),
+                             pz = world(tu[k].z, e.scale[2], e.offset[2]);
+                const CellFast cf = cell_fast(GF, px, py, pz);
+                key[k] = key_fast(GF, cf, &alias[k]);
+                dbits[k] = (uint64_t)__double_as_longlong(centre_dist_fast(GF, cf, px, py, pz));
+                inexact |= cf.ok ? 0u : 1u << k;
+            }
         }
         if (__any(inexact != 0)) {  // rare: one copy of the exact computation, off the common path
 #pragma unroll 1
@@ -527,7 +533,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
             bool any = false;
 #pragma unroll
             for (int k = 0; k < FOLD_K; k++) {
-                const uint64_t h = cell_hash(key[k]);
+                const uint64_t h = cell_hash(key[k], keys_wide_of(P.g));
                 ps[k] = slot_of<NSLOT>(h);
                 pstep[k] = ((uint32_t)(h >> 15) & (NSLOT - 1)) | 1u;  // (lds_insert_dense's sequence)
                 todo[k] = (uint32_t)(k * NT) + threadIdx.x < cnt;

@@ -26,8 +26,10 @@ namespace pcqgrid {
 // search across the lanes (six bpermutes): no window in LDS, nothing shared with the other waves.
 // ANYWIDE = false: every pending run has 16-byte tuples (one aligned load per tuple, four registers in flight); MULTI = false:
 // one entry (EntryRef::get) — the common fold of one file; anything else takes the <true, true> form.
-// A survivor is three 16-byte words: {x, y, z, place in the pending stream} {w0 (with the entry), w1, 0, 0} {distance bits, slot, place}
-// — the distance travels with it: recomputed in both exact passes, cell and distance of 8 M survivors were a seventh of the kernel.
+// A survivor is the tuple AS IT CAME (16 bytes: nothing is decoded for the few lanes of a wave that append one — the winner is,
+// when its record is written) and {distance bits, slot, place}: the distance travels with it (recomputed in both exact
+// passes, cell and distance of 8 M survivors were a seventh of the kernel).  ANYWIDE: a third word, the 24-byte tuple's
+// last eight bytes and whether it is one.  (The list has room for three words per survivor either way.)
 constexpr int SURV_WORDS = 3;
 
 // The table of the streaming fold: key and best distance side by side (one LDS access brings both: a probe that finds its
@@ -38,12 +40,16 @@ constexpr int SURV_WORDS = 3;
 struct KeyDist {
     uint64_t key, dist;
 };
+// the probe sequence's step: coprime with 6400 = 2^8 5^2, i.e. ending in 1, 3, 7 or 9 — ten times eight hash bits plus one of the four
+__device__ __forceinline__ uint32_t stream_probe_step(uint64_t h) {
+    const uint32_t b = (uint32_t)(h >> 38);
+    return __umul24(b & 255u, 10u) + ((0x9731u >> ((b >> 6) & 12u)) & 15u);
+}
 template <int NSLOT, int LIMIT>
 __device__ __forceinline__ int stream_find_or_insert(KeyDist *s_kd, uint64_t key, uint64_t h, uint32_t *s_ncell, uint64_t *seen) {
     static_assert(NSLOT == 6400, "the probe step below is chosen coprime with 6400");
     uint32_t s = slot_of<NSLOT>(h);
-    uint32_t step = ((((uint32_t)(h >> 38)) & 1023u) << 1) | 1u;  // (stream_probe_step)
-    if (step % 5u == 0) step += 2;
+    const uint32_t step = stream_probe_step(h);
     for (int probes = 0; probes < NSLOT; probes++) {
         const uint64_t k = __hip_atomic_load(&s_kd[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint64_t d = __hip_atomic_load(&s_kd[s].dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // (a stale value is only too large)
@@ -65,12 +71,6 @@ __device__ __forceinline__ int stream_find_or_insert(KeyDist *s_kd, uint64_t key
     return -1;
 }
 
-__device__ __forceinline__ uint32_t stream_probe_step(uint64_t h) {
-    uint32_t step = ((((uint32_t)(h >> 38)) & 1023u) << 1) | 1u;
-    if (step % 5u == 0) step += 2;
-    return step;
-}
-// stream_find_or_insert with the first probe already made by the caller (key k and distance d found at slot s)
 template <int NSLOT, int LIMIT>
 __device__ __forceinline__ int stream_resolve(KeyDist *s_kd, uint64_t key, uint32_t s, uint32_t step, uint64_t k, uint64_t d, uint32_t *s_ncell, uint64_t *seen) {
     for (int probes = 0; probes < NSLOT; probes++) {
@@ -108,6 +108,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
     __shared__ uint32_t s_map[NW][64 * U];  // per wave: tag << 6 | fragment lane, at the fragment's first tuple's place in the chunk
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const BinSrc &S = P.src;
+    constexpr int SW = ANYWIDE ? 3 : 2;
     uint4 *surv = surv_scratch + (size_t)blockIdx.x * surv_cap * SURV_WORDS;
     ST_DECL;
 #pragma unroll
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
         for (uint32_t i = threadIdx.x; i < n_old; i += NT) {
             const uint64_t key = P.okeys[old_base + i];
             uint64_t unused;
-            const int s = stream_find_or_insert<NSLOT, LIMIT>(s_kd, key, cell_hash(key), &s_ncell, &unused);
+            const int s = stream_find_or_insert<NSLOT, LIMIT>(s_kd, key, cell_hash(key, keys_wide_of(P.g)), &s_ncell, &unused);
             if (s < 0) {
                 s_over = 1;
                 continue;
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                         uint64_t k0[U], d0[U];
 #pragma unroll
                         for (int u = 0; u < U; u++) {
-                            const uint64_t h = cell_hash(key[u]);
+                            const uint64_t h = cell_hash(key[u], keys_wide_of(G));
                             ps[u] = slot_of<NSLOT>(h);
                             pstep[u] = stream_probe_step(h);
                             k0[u] = __hip_atomic_load(&s_kd[ps[u]].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -339,10 +340,9 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                                 const uint32_t pos = base + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull));
                                 base += (uint32_t)__popcll(m[u]);
                                 if (surv_me[u] && pos < surv_cap) {
-                                    const GridTuple t = ANYWIDE ? decode_raw<MULTI>(cur[u], (cur_wide >> u) & 1, E) : decode16<MULTI>(cur[u].a, E);
-                                    surv[SURV_WORDS * (size_t)pos] = make_uint4((uint32_t)t.x, (uint32_t)t.y, (uint32_t)t.z, t.idx);
-                                    surv[SURV_WORDS * (size_t)pos + 1] = make_uint4(t.w0, t.w1, 0u, 0u);
-                                    surv[SURV_WORDS * (size_t)pos + 2] = make_uint4((uint32_t)dbits[u], (uint32_t)(dbits[u] >> 32), (uint32_t)sl[u], t.idx);  // (all the exact pass reads)
+                                    surv[SW * (size_t)pos] = make_uint4(cur[u].a.x, cur[u].a.y, cur[u].a.z, cur[u].a.w);
+                                    surv[SW * (size_t)pos + 1] = make_uint4((uint32_t)dbits[u], (uint32_t)(dbits[u] >> 32), (uint32_t)sl[u], cur[u].a.w);  // (all the exact pass reads)
+                                    if (ANYWIDE) surv[SW * (size_t)pos + 2] = make_uint4(cur[u].b.x, cur[u].b.y, (cur_wide >> u) & 1, 0u);
                                 }
                             }
                         }
@@ -383,7 +383,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const uint32_t i = i0 + q * NT;
-                    rc[q] = surv[SURV_WORDS * (size_t)(i < nsurv ? i : nsurv - 1) + 2];
+                    rc[q] = surv[SW * (size_t)(i < nsurv ? i : nsurv - 1) + 1];
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
@@ -409,7 +409,8 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                 mine += keys[j] != PCQ_EMPTY_KEY ? 1 : 0;
                 const bool from_list = keys[j] != PCQ_EMPTY_KEY && (oi[j] >> 32) != 0 && oi[j] != ~0ull;
                 const size_t wi = from_list ? (uint32_t)oi[j] : 0u;
-                wra[j] = surv[SURV_WORDS * wi], wrb[j] = surv[SURV_WORDS * wi + 1];
+                wra[j] = surv[SW * wi];
+                wrb[j] = ANYWIDE ? surv[SW * wi + 2] : make_uint4(0u, 0u, 0u, 0u);
             }
             uint32_t incl = mine;
 #pragma unroll
@@ -449,8 +450,11 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                     *P.wrecs.a(o) = *P.orecs.a(at);
                     *P.wrecs.b(o) = *P.orecs.b(at);
                 } else {
-                    const uint4 ra = wra[j], rb = wrb[j];
-                    st_record(P.wrecs, o, P.entries.get<MULTI>((rb.x >> 8) & 0xff), (int32_t)ra.x, (int32_t)ra.y, (int32_t)ra.z, rb.x, rb.y, R_HAS);
+                    RawTuple r;
+                    r.a = (u32x4_a16){wra[j].x, wra[j].y, wra[j].z, wra[j].w};
+                    r.b = (u32x2_a8){wrb[j].x, wrb[j].y};
+                    const GridTuple t = ANYWIDE ? decode_raw<MULTI>(r, wrb[j].z != 0, P.entries) : decode16<MULTI>(r.a, P.entries);
+                    st_record(P.wrecs, o, P.entries.get<MULTI>((t.w0 >> 8) & 0xff), t.x, t.y, t.z, t.w0, t.w1, R_HAS);
                 }
                 o++;
             }

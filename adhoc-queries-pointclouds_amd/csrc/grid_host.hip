@@ -209,7 +209,7 @@ int pcq_grid_scan(pcq_ctx *ctx, pcq_collector *c, const DevCols &cols_in, const 
         // LAST blocks (12-byte positions at an aligned address, a class byte per point, 6-byte colours): the short index arithmetic
         const bool packed = cols.xyz_stride == 12 && ((uintptr_t)cols.xyz & 3) == 0 && (!cols.cls || cols.cls_stride == 1) && (!cols.rgb || cols.rgb_stride == 6);
 #define PCQ_P0_LAUNCH(KIND, RGB, PACKED, WIDE) \
-    hipLaunchKernelGGL((k_p0_part<KIND, RGB, PACKED, WIDE>), dim3(nblocks), dim3(P0_NT), 0, s, cols, pred, g, ntiles, run.tuples, run.dir, tile0, pk16, agg)
+    hipLaunchKernelGGL((k_p0_part<KIND, RGB, PACKED, WIDE>), dim3(nblocks), dim3(P0_NT), 0, s, (P0Args{cols, pred, g, pk16, run.tuples, run.dir, ntiles, tile0, agg}))
 #define PCQ_P0(KIND)                                                          \
     do {                                                                      \
         if (wide && packed) PCQ_P0_LAUNCH(KIND, true, true, true);            \
@@ -280,6 +280,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
         gref.f.mask[a] = (uint32_t)g.mask[a], gref.f.shift[a] = g.shift[a];
     }
     gref.f.cell_size = g.cell_size;
+    gref.f.keys_wide = g.keys_wide;
     PCQ_HIP(hipMemcpyAsync(d_runs, hruns.data(), nruns * sizeof(DevRun), hipMemcpyHostToDevice, s));
     PCQ_HIP(hipMemcpyAsync(d_entries, gs->entries.data(), gs->entries.size() * sizeof(GridEntryDev), hipMemcpyHostToDevice, s));
     EntryRef eref{};

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
             const uint64_t base = P.obase[q];
             const uint32_t n = P.ocount[q];
-            for (uint32_t i = threadIdx.x; i < n; i += L2_NT) atomicAdd(&s_ohist[sub_of(cell_hash(P.okeys[base + i]), f2)], 1u);
+            for (uint32_t i = threadIdx.x; i < n; i += L2_NT) atomicAdd(&s_ohist[sub_of(cell_hash(P.okeys[base + i], P.g.keys_wide), f2)], 1u);
         }
     __syncthreads();
     if (threadIdx.x == 0) {  // a serial prefix is a few hundred to a few thousand LDS reads
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(L2_NT) void k_level2_direct(Level2Params P) {
             const uint32_t n = P.ocount[q];
             for (uint32_t i = threadIdx.x; i < n; i += L2_NT) {
                 const uint64_t key = P.okeys[base + i];
-                const uint32_t pos = atomicAdd(&s_ocur[sub_of(cell_hash(key), f2)], 1u);
+                const uint32_t pos = atomicAdd(&s_ocur[sub_of(cell_hash(key, P.g.keys_wide), f2)], 1u);
                 P.okeys2[pos] = key;
                 *P.orecs2.a(pos) = *P.orecs.a(base + i);
                 *P.orecs2.b(pos) = *P.orecs.b(base + i);
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 4) void k_level2(Level2Params 
         for (uint32_t q = bin * P.f2old; q < (bin + 1) * P.f2old; q++) {
             const uint64_t base = P.obase[q];
             const uint32_t n = P.ocount[q];
-            for (uint32_t i = threadIdx.x; i < n; i += L2S_NT) atomicAdd(&s_ohist[sub_of(cell_hash(P.okeys[base + i]), f2)], 1u);
+            for (uint32_t i = threadIdx.x; i < n; i += L2S_NT) atomicAdd(&s_ohist[sub_of(cell_hash(P.okeys[base + i], P.g.keys_wide), f2)], 1u);
         }
     __syncthreads();
     if (threadIdx.x == 0 && P.okeys) {  // f2 <= 1024: a serial prefix is a thousand LDS reads
@@ -154,10 +154,14 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 4) void k_level2(Level2Params 
                     }
                     uint32_t subs[L2S_ITEMS], ranks[L2S_ITEMS];
                     bool valid[L2S_ITEMS];
+                    // (grid and entry out of the argument segment, here: see karg())
+                    const KArgPtr ka = karg_base();
+                    const DevGrid G = karg<DevGrid>(ka, offsetof(Level2Params, g));
+                    const EntryRef E = karg<EntryRef>(ka, offsetof(Level2Params, entries));
 #pragma unroll
                     for (int j = 0; j < L2S_ITEMS; j++) {
                         valid[j] = base + j * L2S_NT + threadIdx.x < hi;
-                        subs[j] = raw_sub<MULTI>(P.g, P.entries, t[j], tw[j], f2);
+                        subs[j] = raw_sub<MULTI>(G, E, t[j], tw[j], f2);
                         ranks[j] = 0;
                         if (valid[j]) ranks[j] = atomicAdd(&s_cnt[subs[j]], 1u);
                     }
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 4) void k_level2(Level2Params 
                         if (!valid[j]) continue;
                         const uint32_t at = s_base[subs[j]] + ranks[j];
                         if (wide_out && !tw[j]) {  // a 16-byte tuple into a 24-byte output (some other run is wide): decoded
-                            const GridTuple d = decode_raw<MULTI>(t[j], false, P.entries);
+                            const GridTuple d = decode_raw<MULTI>(t[j], false, E);
                             s_xyzi[at] = make_uint4((uint32_t)d.x, (uint32_t)d.y, (uint32_t)d.z, d.idx);
                             s_attr[at] = make_uint2(d.w0 & 0xffff00ffu, 0u);
                         } else {
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 4) void k_level2(Level2Params 
             const uint32_t n = P.ocount[q];
             for (uint32_t i = threadIdx.x; i < n; i += L2S_NT) {
                 const uint64_t key = P.okeys[base + i];
-                const uint32_t pos = atomicAdd(&s_ocur[sub_of(cell_hash(key), f2)], 1u);
+                const uint32_t pos = atomicAdd(&s_ocur[sub_of(cell_hash(key, P.g.keys_wide), f2)], 1u);
                 P.okeys2[pos] = key;
                 *P.orecs2.a(pos) = *P.orecs.a(base + i);
                 *P.orecs2.b(pos) = *P.orecs.b(base + i);

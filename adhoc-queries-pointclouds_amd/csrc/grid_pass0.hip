@@ -84,8 +84,12 @@ __device__ __forceinline__ uint64_t key_only(const DevGrid &g, double px, double
 // WIDE: the block's tuples are 24 bytes (a colour column, or no axis on which a 16-byte tuple could carry the class byte);
 // otherwise 16: {x - lo, y - lo, z - lo, place in the pending stream} with the class in the top byte of one coordinate (pk).
 template <int KIND, bool RGB, bool PACKED, bool WIDE>
-__global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, DevGrid g, uint32_t ntiles, uint8_t *__restrict__ out,
-                                                      uint16_t *__restrict__ dir, uint32_t tile0, P0Pack pk16, int agg_mode) {
+__global__ __launch_bounds__(P0_NT, 4) void k_p0_part(P0Args A) {
+    // (columns, predicate, grid and packing are read out of the argument segment where the tile loop uses them: karg())
+    const uint32_t ntiles = A.ntiles, tile0 = A.tile0;
+    const int agg_mode = A.agg_mode;
+    uint8_t *__restrict__ const out = A.out;
+    uint16_t *__restrict__ const dir = A.dir;
     static_assert(WIDE || !RGB, "a colour column needs the 24-byte tuple");
     constexpr int NT = P0_NT, ITEMS = P0_ITEMS;
     constexpr uint32_t TS = WIDE ? 24 : 16;
@@ -105,13 +109,13 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
     uint32_t tile = blockIdx.x;
     P0In<KIND> cur[ITEMS], nxt[ITEMS];
     auto tile_points = [&](uint32_t t) {  // points of tile t (the last one may be short)
-        const uint64_t left = c.n - (uint64_t)t * P0_TILE;
+        const uint64_t left = A.c.n - (uint64_t)t * P0_TILE;
         return left < (uint64_t)P0_TILE ? (uint32_t)left : (uint32_t)P0_TILE;
     };
     if (tile < ntiles) {
         const uint32_t nv = tile_points(tile);
 #pragma unroll
-        for (int j = 0; j < ITEMS; j++) cur[j] = p0_load_tile<KIND, PACKED>(c, (uint64_t)tile * P0_TILE, (uint32_t)j * NT + tid, nv);
+        for (int j = 0; j < ITEMS; j++) cur[j] = p0_load_tile<KIND, PACKED>(A.c, (uint64_t)tile * P0_TILE, (uint32_t)j * NT + tid, nv);
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; j++) {  // (arrived: inside the loop nothing is pending at its head)
@@ -119,6 +123,8 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
         else asm volatile("" ::"v"(cur[j].rp.x), "v"(cur[j].rp.y), "v"(cur[j].rp.z));
     }
     for (; tile < ntiles; tile += gridDim.x, parity ^= 1) {
+        const DevCols c = karg<DevCols>(karg_base(), offsetof(P0Args, c));
+        const DevPred pr = karg<DevPred>(karg_base(), offsetof(P0Args, pr));
         const uint64_t base = (uint64_t)tile * P0_TILE;
         const uint32_t ntile = tile + gridDim.x;
         const uint32_t nvalid = tile_points(tile);
@@ -157,6 +163,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
         if (agg)
             for (uint32_t k = tid; k < (uint32_t)AGG_SLOTS; k += NT) s_atab[k] = ~0ull;
         uint32_t npass = 0;
+        const DevGrid g = karg<DevGrid>(karg_base(), offsetof(P0Args, g));
 #pragma unroll
         for (int j = 0; j < ITEMS; j++) {
             if (!passes[j]) continue;
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
                          pz = world(cur[j].rp.z, c.scale[2], c.offset[2]);
             if (agg) {
                 const TupleEval ev = eval_world(g, px, py, pz);
-                const uint64_t h = cell_hash(ev.key);
+                const uint64_t h = cell_hash(ev.key, g.keys_wide);
                 const uint32_t place = (uint32_t)j * NT + tid;
                 s_akey[place] = ev.key;
                 const bool through = ev.alias || ev.dbits >= 0x7ff0000000000000ull;
@@ -173,7 +180,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
                 metas[j] = bin_of(h) | (sel16_of(h) << 16);  // (the bin, and the second level's selector for the spare top bytes of a 16-byte tuple)
                 ranks[j] = (uint32_t)(h >> 24) & (AGG_SLOTS - 1);  // the table slot, until the tile's fold is over
             } else {
-                const uint64_t h = cell_hash(key_only(g, px, py, pz));
+                const uint64_t h = cell_hash(key_only(g, px, py, pz), g.keys_wide);
                 metas[j] = bin_of(h) | (sel16_of(h) << 16);  // (the bin, and the second level's selector for the spare top bytes of a 16-byte tuple)
             }
         }
@@ -223,6 +230,7 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
         }
         __syncthreads();
         const uint32_t total = s_base[F1], matched = s_npass[parity];
+        const P0Pack pk16 = karg<P0Pack>(karg_base(), offsetof(P0Args, pk16));
         if (tid < (uint32_t)DIR_WORDS) {  // the directory row, two entries per word
             const uint32_t lo = s_base[2 * tid], hi = 2 * tid + 1 <= (uint32_t)F1 ? s_base[2 * tid + 1] : 0;
             *(PCQ_GLOBAL uint32_t *)(reinterpret_cast<uint32_t *>(dir + (size_t)tile * DIR_STRIDE) + tid) = lo | (hi << 16);
@@ -285,12 +293,12 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(DevCols c, DevPred pr, Dev
 
 // every shape grid_host.hip launches
 #define PCQ_P0_INST(KIND)                                                                                                                     \
-    template __global__ void k_p0_part<KIND, true, true, true>(DevCols, DevPred, DevGrid, uint32_t, uint8_t *, uint16_t *, uint32_t, P0Pack, int);   \
-    template __global__ void k_p0_part<KIND, true, false, true>(DevCols, DevPred, DevGrid, uint32_t, uint8_t *, uint16_t *, uint32_t, P0Pack, int);  \
-    template __global__ void k_p0_part<KIND, false, true, true>(DevCols, DevPred, DevGrid, uint32_t, uint8_t *, uint16_t *, uint32_t, P0Pack, int);  \
-    template __global__ void k_p0_part<KIND, false, false, true>(DevCols, DevPred, DevGrid, uint32_t, uint8_t *, uint16_t *, uint32_t, P0Pack, int); \
-    template __global__ void k_p0_part<KIND, false, true, false>(DevCols, DevPred, DevGrid, uint32_t, uint8_t *, uint16_t *, uint32_t, P0Pack, int); \
-    template __global__ void k_p0_part<KIND, false, false, false>(DevCols, DevPred, DevGrid, uint32_t, uint8_t *, uint16_t *, uint32_t, P0Pack, int);
+    template __global__ void k_p0_part<KIND, true, true, true>(P0Args);   \
+    template __global__ void k_p0_part<KIND, true, false, true>(P0Args);  \
+    template __global__ void k_p0_part<KIND, false, true, true>(P0Args);  \
+    template __global__ void k_p0_part<KIND, false, false, true>(P0Args); \
+    template __global__ void k_p0_part<KIND, false, true, false>(P0Args); \
+    template __global__ void k_p0_part<KIND, false, false, false>(P0Args);
 PCQ_P0_INST(PCQ_PRED_BOUNDS)
 PCQ_P0_INST(PCQ_PRED_CLASS)
 PCQ_P0_INST(PCQ_PRED_BOUNDS_F64)

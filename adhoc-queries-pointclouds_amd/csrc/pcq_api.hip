@@ -618,6 +618,7 @@ extern "C" int pcq_collector_new_grid(pcq_ctx *ctx, const double bmin[3], const 
     g.shift[0] = 0;
     g.shift[1] = (uint32_t)(c->bits[0] & 63);
     g.shift[2] = (uint32_t)((c->bits[0] + c->bits[1]) & 63);
+    g.keys_wide = bitsum > 32 ? 1u : 0u;
     return PCQ_OK;
 }
 

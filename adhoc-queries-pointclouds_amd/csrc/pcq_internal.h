@@ -106,6 +106,7 @@ struct DevGrid {
     double qmax[3], guard[3];
     uint64_t mask[3];     // (1 << bits) - 1
     uint32_t shift[3];    // 0, bits_x, bits_x + bits_y  (already & 63)
+    uint32_t keys_wide;   // 1: a key can have more than 32 bits (grid.hip cell_hash)
 };
 
 constexpr uint64_t PCQ_EMPTY_KEY = ~0ull;

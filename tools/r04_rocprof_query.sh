@@ -20,11 +20,11 @@ CMD="rocprofv3 --kernel-trace --memory-copy-trace -d $O/prof_query -o q --output
 {
   echo "# $CMD"
   echo "# (PCQ_TIMING=1; hard limit 150 s)"
-  START=$(date +%s.%N)
+  START=$(date +%s%N)
   PCQ_TIMING=1 timeout -k 10 150 $CMD
   RC=$?
-  END=$(date +%s.%N)
-  echo "# exit code $RC after $(echo "$END - $START" | bc) s"
+  END=$(date +%s%N)
+  echo "# exit code $RC after $(( (END - START) / 1000000 )) ms"
   ls $O/prof_query/*/ 2>/dev/null | head -20
 } > $O/rocprof_query.log 2>&1
 tail -30 $O/rocprof_query.log
