@@ -176,6 +176,7 @@ def load_library() -> C.CDLL:
         "pcq_scan_fd": (C.c_int, [vp, C.c_int, P(Columns), P(Predicate), vp]),
         "pcq_scan_host_nowait": (C.c_int, [vp, P(Columns), P(Predicate), vp]),
         "pcq_scan_fd_nowait": (C.c_int, [vp, C.c_int, P(Columns), P(Predicate), vp]),
+        "pcq_prepare_host_scans": (C.c_int, [vp]),
         "pcq_scan_dev_count_batch": (C.c_int, [vp, P(Columns), P(Predicate), C.c_size_t, vp, vp]),
         "pcq_allreduce_sum_u64": (C.c_int, [P(vp), P(vp), P(vp), C.c_int]),
         "pcq_allreduce_prepare": (C.c_int, [P(C.c_int), C.c_int]),
@@ -397,6 +398,10 @@ class Context:
     def scan_fd_nowait(self, fd: int, cols: Columns, pred: Predicate, coll: Collector) -> None:
         """scan_fd that returns once the file has been read and its last kernels are enqueued; results after synchronize() / accessors."""
         _check(self.lib.pcq_scan_fd_nowait(self.handle, fd, C.byref(cols), C.byref(pred), coll.handle))
+
+    def prepare_host_scans(self) -> None:
+        """Starts pinning the staging ring and the copy helpers on a thread of the library (returns at once)."""
+        _check(self.lib.pcq_prepare_host_scans(self.handle))
 
     def scan_dev_count_batch(self, cols: Sequence[Columns], preds: Sequence[Predicate], device_total: int,
                              stream: Optional[int] = None) -> None:

@@ -186,9 +186,18 @@ __global__ __launch_bounds__(P0_NT, 4) void k_p0_part(P0Args A) {
         }
         if (agg) {
             __syncthreads();  // the table is clear, the keys are in place
+            // Where the tile's fold pays, neighbours in the file are neighbours in space: the 64 lanes of a wave aim at a handful of
+            // slots, and an LDS atomic takes the lanes of one address one after the other.  So every eighth lane goes first; the
+            // others look at the slot afterwards and stay away when they cannot lower it (a minimum only falls: whoever is not
+            // below what it reads is not below what will be there at the end — skipping that atomicMin changes nothing in the table).
+            const bool scout = (lane & 7u) == 0;
 #pragma unroll
             for (int j = 0; j < ITEMS; j++)
-                if (passes[j]) atomicMin((unsigned long long *)&s_atab[ranks[j]], (unsigned long long)pk[j]);
+                if (passes[j] && scout) atomicMin((unsigned long long *)&s_atab[ranks[j]], (unsigned long long)pk[j]);
+#pragma unroll
+            for (int j = 0; j < ITEMS; j++)
+                if (passes[j] && !scout && (unsigned long long)pk[j] < __hip_atomic_load(&s_atab[ranks[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))
+                    atomicMin((unsigned long long *)&s_atab[ranks[j]], (unsigned long long)pk[j]);
             __syncthreads();
 #pragma unroll
             for (int j = 0; j < ITEMS; j++) {

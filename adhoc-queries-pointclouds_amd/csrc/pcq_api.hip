@@ -34,6 +34,7 @@ __global__ void k_words_to_host(const uint64_t *__restrict__ src, uint64_t *__re
 }
 
 extern "C" int pcq_abi_version(void) { return PCQ_ABI_VERSION; }
+static void join_stage_warm(pcq_ctx *ctx);
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -150,6 +151,7 @@ extern "C" int pcq_shutdown(pcq_ctx *ctx) {
     PCQ_ON_DEVICE_OF_CTX(ctx);
     if (!ctx) return PCQ_OK;
     (void)hipSetDevice(ctx->device);
+    join_stage_warm(ctx);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (int i = 0; i < 2; i++) {
@@ -869,7 +871,15 @@ extern "C" int pcq_scan_dev(pcq_ctx *ctx, const pcq_columns *cols, const pcq_pre
 // scan asks for the first pair, issues its first chunk, and only then for the second — pinning 24 MB is 5 ms
 // (profiles/r03_hip_startup.log: 11 ms for the ring), and the second pair's 5 ms then run under the first chunk's transfer
 // instead of in front of it (the first file of a process cost 15-24 ms where the others cost 1: profiles/r03_cli_e2e.log).
+static void join_stage_warm(pcq_ctx *ctx) {
+    if (ctx->stage_warm.joinable()) ctx->stage_warm.join();
+}
+static int ensure_stage_now(pcq_ctx *ctx, size_t bytes, int upto);
 static int ensure_stage(pcq_ctx *ctx, size_t bytes, int upto = 2) {
+    join_stage_warm(ctx);
+    return ensure_stage_now(ctx, bytes, upto);
+}
+static int ensure_stage_now(pcq_ctx *ctx, size_t bytes, int upto) {
     if (ctx->stage_bytes < bytes && (ctx->h_stage[0] || ctx->h_stage[1])) {  // too small: drop what there is
         PCQ_HIP(hipStreamSynchronize(ctx->stream));
         PCQ_HIP(hipStreamSynchronize(ctx->copy_stream));
@@ -958,11 +968,26 @@ static size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 // columns are given as offsets into an open file (pcq_scan_fd) — pread straight from the page cache
 // (no mmap page-table work: measured ~2x the rate of memcpy from a freshly mmapped file).
 // The copy is split over the context's helper threads (copy_pool.h).
-static int fetch(pcq_ctx *ctx, int fd, uint8_t *dst, const uint8_t *src, size_t bytes) {
+static void ensure_copy_pool(pcq_ctx *ctx) {
     if (!ctx->copy_pool || ctx->copy_pool->helpers() != ctx->copy_threads - 1) {
         delete ctx->copy_pool;
         ctx->copy_pool = new CopyPool(ctx->copy_threads - 1, ctx->numa_local && ctx->numa_node >= 0 ? &ctx->node_cpus : nullptr);
     }
+}
+extern "C" int pcq_prepare_host_scans(pcq_ctx *ctx) {
+    PCQ_ON_DEVICE_OF_CTX(ctx);
+    if (!ctx) return pcq_fail(PCQ_ERR_ARG, "pcq_prepare_host_scans: null context");
+    if (ctx->stage_warm.joinable() || ctx->h_stage[0]) return PCQ_OK;  // under way, or nothing left to prepare
+    ctx->stage_warm = std::thread([ctx] {
+        (void)hipSetDevice(ctx->device);
+        (void)ensure_stage_now(ctx, (size_t)ctx->chunk_points * 12 + 4096, 2);  // (what a scan of positions + classes asks for: scan_host_impl)
+        ensure_copy_pool(ctx);
+    });
+    return PCQ_OK;
+}
+static int fetch(pcq_ctx *ctx, int fd, uint8_t *dst, const uint8_t *src, size_t bytes) {
+    join_stage_warm(ctx);
+    ensure_copy_pool(ctx);
     const int r = ctx->copy_pool->run(fd, dst, src, bytes);
     if (r < 0) return pcq_fail(PCQ_ERR_IO, "pread failed: %s", strerror(-r));
     if (r > 0) return pcq_fail(PCQ_ERR_EOF, "failed to fill whole buffer");

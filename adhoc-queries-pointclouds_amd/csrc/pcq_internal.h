@@ -139,6 +139,7 @@ struct pcq_ctx {
     uint8_t *h_stage[2] = {nullptr, nullptr};
     uint8_t *d_stage[2] = {nullptr, nullptr};
     size_t stage_bytes = 0;
+    std::thread stage_warm;             // pcq_prepare_host_scans: joined by whoever touches the staging ring or the copy pool next
     bool stage_busy[2] = {false, false};  // kernels not yet known to be done with staging pair b (event consumed[b])
     // segment table for batched launches
     DevSegment *d_segments = nullptr;

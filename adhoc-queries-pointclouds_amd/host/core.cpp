@@ -227,6 +227,7 @@ Status thread_context(int device, pcq_ctx **out) {
         rc = pcq_init(device, &ctx);
     }
     if (rc) return Status::FromLib(rc);
+    (void)pcq_prepare_host_scans(ctx);  // (the staging ring is pinned while the worker opens its first file: 8 ms off that file)
     tc.by_device[device] = ctx;
     *out = ctx;
     return Status::Ok();

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define PCQ_ABI_VERSION 5
+#define PCQ_ABI_VERSION 6
 
 typedef enum pcq_status {
     PCQ_OK = 0,
@@ -201,6 +201,12 @@ int pcq_scan_host_nowait(pcq_ctx *ctx, const pcq_columns *cols, const pcq_predic
  * be closed at once, and the next file's first chunk is read while this one's last transfer and kernels run (a per-file
  * synchronisation drained the pipeline for about a chunk's read + transfer at every file boundary of main.rs:153-161). */
 int pcq_scan_fd_nowait(pcq_ctx *ctx, int fd, const pcq_columns *cols, const pcq_predicate *pred, pcq_collector *c);
+/* Optional, for a caller that is going to scan from host memory or files: starts — on a thread of its own, and returns at
+ * once — what the first such scan of a context otherwise does before it can move a byte: pinning the two staging buffers
+ * (4 ms each) and starting the copy helpers.  Called right behind pcq_init this runs while the caller opens its first file
+ * and creates its collector; the first scan (or pcq_shutdown) waits for whatever is left of it.  A failure here is not
+ * reported here: the first scan repeats the allocation and reports it. */
+int pcq_prepare_host_scans(pcq_ctx *ctx);
 
 /* Count-only scan of many device-resident LAST files in ONE launch (files = independent units,
  * main.rs:153-161): segment i is scanned with preds[i] (all bounds, over 16-byte aligned positions

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The `query` binary under rocprofv3 with kernel and memory-copy tracing: round 3 saw this command print its answer, write its
 # traces and not end within 200 s.  ONE run, under a hard timeout, command and log kept -> profiles/r04_rocprof_query.log
-# usage (on the GPU box): bash tools/r04_rocprof_query.sh
+# usage (on the GPU box): bash tests/manual/rocprof_query.sh   (under tests/: the files are written by the oracle's generator)
 O=$GRAFT_REPO_ROOT/gpurun_out/r04; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 D=$(mktemp -d /tmp/pcq_prof_XXXX)

@@ -38,7 +38,7 @@ def test_libpcq_exports_every_declared_symbol():
     exported = pkg.exported_symbols(pkg.lib_path())
     assert [s for s in declared if s not in exported] == []
     lib = pkg.load_library()  # dlopen resolves libamdhip64 etc.
-    assert lib.pcq_abi_version() == 5
+    assert lib.pcq_abi_version() == 6
 
 
 def test_libpcq_query_exports_every_declared_symbol():

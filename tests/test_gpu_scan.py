@@ -775,6 +775,37 @@ def test_scan_host_nowait_lets_the_caller_reuse_its_buffer(oracle, gpu_ctx):
         gpu_ctx.set_option("chunk_points", 2 << 20)
 
 
+def test_prepare_host_scans_runs_beside_the_caller_and_changes_nothing(oracle):
+    """pcq_prepare_host_scans pins the staging ring on a thread of the library: a scan issued at once waits for it, a scan
+    with larger chunks than it prepared replaces the ring, a context shut down before any scan joins it; results are the
+    oracle's either way."""
+    spec = small_spec(77, 60_000, fmt=1)
+    image = oracle.synth_image(spec, transposed=True)
+    hdr = oracle.parse_header(image[:400].tobytes())
+    n, otp = hdr.number_of_points, hdr.offset_to_point_data
+    bmin, bmax = BOXES[0]
+    oc = oracle.count_collector()
+    assert oracle.search_last_bounds(image, bmin, bmax, oc) == 0
+    want = oc.point_count()
+    oc.free()
+    assert want > 0
+    lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+    xyz = np.ascontiguousarray(image[otp:otp + 12 * n])
+    cols = binding.make_columns(xyz=xyz.ctypes.data, n=n, scale=list(hdr.scale), offset=list(hdr.offset))
+    for chunk_points in (None, 4096, 8 << 20):
+        with pkg.Context(0) as ctx:
+            ctx.prepare_host_scans()
+            ctx.prepare_host_scans()  # (a second call while the first is under way is a no-op)
+            if chunk_points:
+                ctx.set_option("chunk_points", chunk_points)
+            cc = ctx.count_collector()
+            ctx.scan_host(cols, pkg.Predicate.bounds(lmin, lmax), cc)
+            assert cc.point_count() == want
+            cc.free()
+    with pkg.Context(0) as ctx:
+        ctx.prepare_host_scans()  # and nothing else: shutdown joins the thread
+
+
 @pytest.mark.parametrize("n", [3_000, 400_003])
 def test_grid_massive_aliasing_is_replayed_exactly(oracle, gpu_ctx, n):
     """A grid box much smaller than the data it is fed: almost every matched point lands in a cell >= 2^bits, whose key
