@@ -98,8 +98,10 @@ class SynthSpec(C.Structure):
 
 def lib_path() -> str:
     """libpcq.so — or, for the measurement tools in tools/ (PCQ_LAB=1), libpcq_lab.so: the same sources plus the
-    superseded kernel shapes and read microbenchmarks of csrc/lab/ (make -C csrc lab)."""
-    return os.path.join(_HERE, "libpcq_lab.so" if os.environ.get("PCQ_LAB") == "1" else "libpcq.so")
+    superseded kernel shapes and read microbenchmarks of csrc/lab/ (make -C csrc lab); PCQ_LAB=stamps: libpcq_stamps.so,
+    the timing build of the grid folds (make -C csrc stamps)."""
+    which = os.environ.get("PCQ_LAB")
+    return os.path.join(_HERE, "libpcq_lab.so" if which == "1" else "libpcq_stamps.so" if which == "stamps" else "libpcq.so")
 
 
 _lib = None

@@ -679,7 +679,7 @@ __device__ __forceinline__ int lds_find_or_insert(uint64_t *s_key, uint64_t key,
 }
 
 
-// Timing stamps (a build with -DPCQ_STAMPS only; tools/patches keeps the recipe): cycles per phase, accumulated per wave
+// Timing stamps (libpcq_stamps.so only: make -C csrc stamps, loaded by the tools under PCQ_LAB=stamps): cycles per phase, accumulated per wave
 // and added to stats[16 + i] by lane 0; stats[31] counts the waves.
 #ifdef PCQ_STAMPS
 #define ST_DECL uint64_t st_last_ = __builtin_amdgcn_s_memtime(), st_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}

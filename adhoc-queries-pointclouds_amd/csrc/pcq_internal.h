@@ -190,7 +190,8 @@ struct pcq_ctx {
     int copy_threads = 8;         // threads filling a staging buffer (caller + helpers): 2-4 reach the PCIe rate from memory next to the
                                   // GPU, page-cache pages on the other socket need 8 (profiles/r01_cli_probe_timing.log)
     CopyPool *copy_pool = nullptr;  // created on first use by pcq_scan_host / pcq_scan_fd
-    uint64_t chunk_points = 2ull << 20;    // 24 MB of positions per staging chunk (profiles/r01_host_path_rate.json: 1-8 Mi equal)
+    uint64_t chunk_points = 1ull << 20;    // 12 MB of positions per staging chunk: the steady rate of 24 MB (profiles/r01_host_path_rate.json: 1-8 Mi equal)
+                                           // at half the pinning in front of a process's first file (profiles/r04_cli_chunks.log: 25 -> 20 ms)
 };
 
 // pcq_api.hip: [offset, offset+bytes) of fd -> device memory through the pinned staging buffers

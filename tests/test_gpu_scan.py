@@ -772,7 +772,7 @@ def test_scan_host_nowait_lets_the_caller_reuse_its_buffer(oracle, gpu_ctx):
         assert bc.points().tobytes() == want.tobytes()
         cc.free(), bc.free()
     finally:
-        gpu_ctx.set_option("chunk_points", 2 << 20)
+        gpu_ctx.set_option("chunk_points", 1 << 20)
 
 
 def test_prepare_host_scans_runs_beside_the_caller_and_changes_nothing(oracle):
