@@ -682,7 +682,7 @@ __device__ __forceinline__ int lds_find_or_insert(uint64_t *s_key, uint64_t key,
 // Timing stamps (libpcq_stamps.so only: make -C csrc stamps, loaded by the tools under PCQ_LAB=stamps): cycles per phase, accumulated per wave
 // and added to stats[16 + i] by lane 0; stats[31] counts the waves.
 #ifdef PCQ_STAMPS
-#define ST_DECL uint64_t st_last_ = __builtin_amdgcn_s_memtime(), st_acc_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define ST_DECL uint64_t st_last_ = __builtin_amdgcn_s_memtime(), st_acc_[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
 #define ST(i)                                                  \
     do {                                                       \
         const uint64_t st_t_ = __builtin_amdgcn_s_memtime();   \
@@ -692,7 +692,7 @@ __device__ __forceinline__ int lds_find_or_insert(uint64_t *s_key, uint64_t key,
 #define ST_FLUSH(stats)                                                                            \
     do {                                                                                           \
         if ((threadIdx.x & 63) == 0) {                                                             \
-            for (int i_ = 0; i_ < 12; i_++) atomicAdd(&(stats)[16 + i_], (unsigned long long)st_acc_[i_]); \
+            for (int i_ = 0; i_ < 15; i_++) atomicAdd(&(stats)[16 + i_], (unsigned long long)st_acc_[i_]); \
             atomicAdd(&(stats)[31], 1ull);                                                         \
         }                                                                                          \
     } while (0)

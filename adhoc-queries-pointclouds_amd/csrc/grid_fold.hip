@@ -567,15 +567,18 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
             }
         }
         ST(3);  // phase 1: insert, minimum distance
-        bool over = false;
-        {  // cells of the partition so far, counted per wave; beyond LIMIT the partition is given up (like k_fold: the same fan-out rule)
+        {  // cells of the partition, counted per wave; beyond LIMIT the partition is given up (like k_fold: the same fan-out rule)
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) fresh_cells += __shfl_xor(fresh_cells, o, 64);
-            if (lane == 0 && fresh_cells) over = atomicAdd(&s_ncell, fresh_cells) + fresh_cells > (uint32_t)LIMIT;
+            if (lane == 0 && fresh_cells) atomicAdd(&s_ncell, fresh_cells);
         }
-        if (__syncthreads_or(over)) {  // more cells than the table holds: the host repeats the fold with more partitions
+        // (one barrier and the sum itself: __syncthreads_or is three barriers, and computes a flat thread number out of
+        // threadIdx.y and .z, which then live — in scratch — through the whole kernel)
+        __syncthreads();
+        if (s_ncell > (uint32_t)LIMIT) {  // more cells than the table holds: the host repeats the fold with more partitions
             for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
             for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
+            __syncthreads();  // (everybody has read the count)
             if (threadIdx.x == 0) {
                 s_ncell = 0;
                 P.wcount[p] = 0;

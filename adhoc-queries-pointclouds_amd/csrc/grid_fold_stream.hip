@@ -104,7 +104,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
     // the minimum and says where its record lies.
     __shared__ uint64_t s_oi[NSLOT];
     __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32];
-    __shared__ uint32_t s_ncell, s_over, s_nsurv, s_next_batch, s_wsum[NW];
+    __shared__ uint32_t s_ncell, s_over, s_nsurv, s_next_batch, s_anyalias, s_cnt2[SPT * NW];
     __shared__ uint32_t s_map[NW][64 * U];  // per wave: tag << 6 | fragment lane, at the fragment's first tuple's place in the chunk
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const BinSrc &S = P.src;
@@ -116,16 +116,17 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
     uint32_t tag = 0;                                              // chunks this wave has asked for (26 bits: 4 G tuples per wave)
     for (uint32_t it = blockIdx.x; it < nparts; it += gridDim.x) {
         const uint32_t p = xcd_order(it, nparts);
+        // (what only the bin's end needs is read there, again: a value that lives across the stream is a register the stream
+        // does not have — it goes to scratch and comes back behind the first stores, where waiting for it waits for them)
         const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
-        const uint64_t old_base = P.okeys ? P.obase[p] : 0;
-        const uint64_t out_base = P.wbase[p];
         for (int t = threadIdx.x; t < NSLOT; t += NT) s_kd[t].key = PCQ_EMPTY_KEY, s_kd[t].dist = ~0ull, s_oi[t] = ~0ull;
         for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
-        if (threadIdx.x == 0) s_ncell = 0, s_over = 0, s_nsurv = 0, s_next_batch = 0;
+        if (threadIdx.x == 0) s_ncell = 0, s_over = 0, s_nsurv = 0, s_next_batch = 0, s_anyalias = 0;
         __syncthreads();
 
         // earlier winners first: their distance is recomputed from the record (same f64 expressions, same bits)
         for (uint32_t i = threadIdx.x; i < n_old; i += NT) {
+            const uint64_t old_base = P.obase[p];
             const uint64_t key = P.okeys[old_base + i];
             uint64_t unused;
             const int s = stream_find_or_insert<NSLOT, LIMIT>(s_kd, key, cell_hash(key, keys_wide_of(P.g)), &s_ncell, &unused);
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
         __syncthreads();
         ST(9);  // waiting for the workgroup's other waves
         const uint32_t nsurv = s_nsurv;
+        uint32_t report = ~0u;  // the bin's cells, for thread 0 to write down behind the last barrier
         if (s_over) {  // more cells than the table holds: the host repeats the fold with more partitions
             if (threadIdx.x == 0) {
                 P.wcount[p] = 0;
@@ -393,62 +395,83 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                 }
             }
             __syncthreads();
-            // compaction: thread t owns slots [t * SPT, ...): the cells leave in slot order
-            uint32_t mine = 0;
-            const int s0 = threadIdx.x * SPT;
-            uint64_t keys[SPT], oi[SPT];
-            // the winners' records are asked for ALL TOGETHER, before anything waits for one of them: the list lies in HBM,
-            // the rest of the chip is streaming, and a round trip takes ~10 us then — one after the other the thread's seven
-            // slots were a sixth of the kernel (a slot without a survivor record reads record 0; nothing is done with it)
+            ST(3);  // exact pass over the survivors
+            // ---- 3. the cells leave in slot order, a wave's 64 CONSECUTIVE slots per round ----
+            // Round j: thread t looks at slot j x NT + t; the cells of a wave's 64 slots get consecutive places, so ONE store
+            // instruction writes one contiguous run of keys and of records.  (With seven consecutive slots per thread the lanes
+            // of a store were four records apart: 64 partial writes per instruction, and the memory side took 26 us per bin to
+            // accept them — stamps in profiles/r04_grid_progress.txt; the table reads are free of bank conflicts this way, too.)
+            // Places: the cells of (round, wave) counted by a ballot, the SPT x NW counts summed in (round, wave) order by
+            // every wave for itself (two per lane, a scan across the lanes).
+            // (opaque: what depends on the thread's number is computed HERE.  The addresses of the thread's seven slots in the three
+            // tables do not change from bin to bin; computed once in front of the kernel's loop they were twenty registers that
+            // lived through the stream, i.e. in scratch, and came back between the stores below, each time waiting for them)
+            int tid = (int)threadIdx.x;
+            asm volatile("" : "+v"(tid));
+            const uint32_t n_old = P.okeys ? P.ocount[p] : 0;
+            const uint64_t old_base = P.okeys ? P.obase[p] : 0;
+            const uint64_t out_base = P.wbase[p];
+            static_assert(SPT * NW <= 128, "two counts per lane");
+            unsigned long long occ[SPT];
+#pragma unroll
+            for (int j = 0; j < SPT; j++) {
+                const int s = j * NT + tid;
+                occ[j] = __ballot(s < NSLOT && s_kd[s < NSLOT ? s : 0].key != PCQ_EMPTY_KEY);
+                if (lane == 0) s_cnt2[j * NW + wave] = (uint32_t)__popcll(occ[j]);
+            }
+            __syncthreads();
+            uint32_t base_j[SPT], total;
+            {
+                const uint32_t c0 = lane < (uint32_t)(SPT * NW) ? s_cnt2[lane] : 0u, c1 = 64 + lane < (uint32_t)(SPT * NW) ? s_cnt2[64 + lane] : 0u;
+                uint32_t i0 = c0, i1 = c1;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t u0 = __shfl_up(i0, off, 64), u1 = __shfl_up(i1, off, 64);
+                    if (lane >= (uint32_t)off) i0 += u0, i1 += u1;
+                }
+                const uint32_t t0 = __shfl(i0, 63, 64);
+                total = t0 + __shfl(i1, 63, 64);
+                const uint32_t e0 = i0 - c0, e1 = t0 + i1 - c1;  // the cells in front of entry `lane` and of entry 64 + `lane`
+#pragma unroll
+                for (int j = 0; j < SPT; j++) {
+                    const int e = j * NW + (int)wave;
+                    base_j[j] = uni32(e < 64 ? __shfl(e0, e, 64) : __shfl(e1, e - 64, 64));  // (the same in every lane: a scalar register)
+                }
+            }
+            ST(6);  // places of the cells
+            // The winners' records are asked for TOGETHER, before anything waits for one of them (the list lies in HBM, a round
+            // trip takes ~10 us while the rest of the chip streams: one after the other they were a sixth of the kernel), and
+            // written as stores only: a load behind a store waits for the store as well (loads and stores share one in-order
+            // counter, and the compiler cannot count stores that sit in branches) — so no load follows the first store.  Key and
+            // winner word of a slot are read from the table again when the slot is written: next to seven records they did
+            // not fit the registers, and what goes to scratch comes back with a memory round trip of its own.  Cells with
+            // aliased keys and cells whose earlier winner stays — both read memory — are left to a second pass that only runs
+            // where there is such a cell.  (A slot without a survivor record reads record 0; nothing is done with it.)
+            bool any_alias = false, later = false;
             uint4 wra[SPT], wrb[SPT];
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
-                const bool in = s0 + j < NSLOT;
-                keys[j] = in ? s_kd[s0 + j].key : PCQ_EMPTY_KEY;
-                oi[j] = in ? s_oi[s0 + j] : ~0ull;
-                mine += keys[j] != PCQ_EMPTY_KEY ? 1 : 0;
-                const bool from_list = keys[j] != PCQ_EMPTY_KEY && (oi[j] >> 32) != 0 && oi[j] != ~0ull;
-                const size_t wi = from_list ? (uint32_t)oi[j] : 0u;
+                const bool in = j * NT + tid < NSLOT;
+                const int s = in ? j * NT + tid : 0;
+                const uint64_t oi = s_oi[s];
+                const bool simple = !((s_aliasbits[s >> 5] >> (s & 31)) & 1) && (oi >> 32) != 0;
+                const size_t wi = in && simple && oi != ~0ull ? (uint32_t)oi : 0u;
                 wra[j] = surv[SW * wi];
                 wrb[j] = ANYWIDE ? surv[SW * wi + 2] : make_uint4(0u, 0u, 0u, 0u);
             }
-            uint32_t incl = mine;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t up = __shfl_up(incl, off, 64);
-                if (lane >= (uint32_t)off) incl += up;
-            }
-            if (lane == 63) s_wsum[wave] = incl;
-            __syncthreads();
-            uint32_t before = incl - mine, total = 0;
-            for (int w = 0; w < NW; w++) {
-                before += (uint32_t)w < wave ? s_wsum[w] : 0;
-                total += s_wsum[w];
-            }
-            bool any_alias = false;
-            uint64_t o = out_base + before;
+#ifdef PCQ_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ST(12);  // the winners' records have arrived
+#endif
 #pragma unroll
             for (int j = 0; j < SPT; j++) {
-                const int s = s0 + j;
-                const uint64_t key = keys[j];
+                const int s = j * NT + tid;
+                const uint64_t key = s < NSLOT ? s_kd[s].key : PCQ_EMPTY_KEY;
                 if (key == PCQ_EMPTY_KEY) continue;
+                const uint64_t o = out_base + base_j[j] + (uint32_t)__popcll(occ[j] & ((1ull << lane) - 1ull));
                 P.wkeys[o] = key;
-                const bool alias = (s_aliasbits[s >> 5] >> (s & 31)) & 1;
-                if (alias) {  // left to the exact replay: the state before this fold (the earlier winner, if there is one) + the flag
-                    any_alias = true;
-                    uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
-                    for (uint32_t i = 0; i < n_old; i++)
-                        if (P.okeys[old_base + i] == key) {
-                            a = *P.orecs.a(old_base + i), b = *P.orecs.b(old_base + i);
-                            b.w |= (uint32_t)R_ALIAS << 24;
-                            break;
-                        }
-                    *P.wrecs.a(o) = a;
-                    *P.wrecs.b(o) = b;
-                } else if ((oi[j] >> 32) == 0) {  // the earlier winner stays
-                    const uint64_t at = old_base + (uint32_t)oi[j];
-                    *P.wrecs.a(o) = *P.orecs.a(at);
-                    *P.wrecs.b(o) = *P.orecs.b(at);
+                if (((s_aliasbits[s >> 5] >> (s & 31)) & 1) || (s_oi[s] >> 32) == 0) {
+                    later = true;
                 } else {
                     RawTuple r;
                     r.a = (u32x4_a16){wra[j].x, wra[j].y, wra[j].z, wra[j].w};
@@ -456,18 +479,56 @@ __global__ __launch_bounds__(NT, 4) void k_fold_stream(FoldParams P, uint32_t np
                     const GridTuple t = ANYWIDE ? decode_raw<MULTI>(r, wrb[j].z != 0, P.entries) : decode16<MULTI>(r.a, P.entries);
                     st_record(P.wrecs, o, P.entries.get<MULTI>((t.w0 >> 8) & 0xff), t.x, t.y, t.z, t.w0, t.w1, R_HAS);
                 }
-                o++;
             }
-            if (__syncthreads_or(any_alias) && threadIdx.x == 0) {
+            if (later) {
+#pragma unroll 1
+                for (int j = 0; j < SPT; j++) {
+                    const int s = j * NT + tid;
+                    if (s >= NSLOT) continue;
+                    const uint64_t key = s_kd[s].key;
+                    if (key == PCQ_EMPTY_KEY) continue;
+                    uint32_t bj = base_j[0];  // (base_j[j] without a register array indexed at run time)
+#pragma unroll
+                    for (int jj = 1; jj < SPT; jj++) bj = jj == j ? base_j[jj] : bj;
+                    unsigned long long oc = occ[0];
+#pragma unroll
+                    for (int jj = 1; jj < SPT; jj++) oc = jj == j ? occ[jj] : oc;
+                    const uint64_t o = out_base + bj + (uint32_t)__popcll(oc & ((1ull << lane) - 1ull));
+                    if ((s_aliasbits[s >> 5] >> (s & 31)) & 1) {  // left to the exact replay: the state before this fold (the earlier winner, if there is one) + the flag
+                        any_alias = true;
+                        uint4 a = make_uint4(0, 0, 0, 0), b = make_uint4(0, 0, 0, (uint32_t)R_ALIAS << 24);
+                        for (uint32_t i = 0; i < n_old; i++)
+                            if (P.okeys[old_base + i] == key) {
+                                a = *P.orecs.a(old_base + i), b = *P.orecs.b(old_base + i);
+                                b.w |= (uint32_t)R_ALIAS << 24;
+                                break;
+                            }
+                        *P.wrecs.a(o) = a;
+                        *P.wrecs.b(o) = b;
+                    } else if ((s_oi[s] >> 32) == 0) {  // the earlier winner stays
+                        const uint64_t at = old_base + (uint32_t)s_oi[s];
+                        *P.wrecs.a(o) = *P.orecs.a(at);
+                        *P.wrecs.b(o) = *P.orecs.b(at);
+                    }
+                }
+            }
+            ST(11);  // the cells' keys and records written (issued)
+#ifdef PCQ_STAMPS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ST(13);  // ... and taken by the memory side
+#endif
+            if (any_alias) s_anyalias = 1;  // (read by thread 0 behind the barrier below, cleared by it at the next bin's start)
+            report = total;
+        }
+        __syncthreads();  // the table is cleared for the next partition
+        if (threadIdx.x == 0 && report != ~0u) {
+            if (s_anyalias) {
                 P.palias[p] = 1;
                 atomicAdd(&P.stats[2], 1ull);
             }
-            if (threadIdx.x == 0) {
-                P.wcount[p] = total;
-                if (total) atomicAdd(&P.stats[0], (unsigned long long)total);
-            }
+            P.wcount[p] = report;
+            if (report) atomicAdd(&P.stats[0], (unsigned long long)report);
         }
-        __syncthreads();  // the table is cleared for the next partition
         ST(10);  // exact phase + output
     }
     ST_FLUSH(P.stats);

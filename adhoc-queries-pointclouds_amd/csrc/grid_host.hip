@@ -509,7 +509,7 @@ static int grid_fold(pcq_ctx *ctx, pcq_collector *c) {
             PCQ_HIP(hipMemcpy(sx, d_stats + 16, sizeof sx, hipMemcpyDeviceToHost));
             if (sx[15]) {
                 fprintf(stderr, "[pcq] stamps (cycles per wave, %llu waves):", sx[15]);
-                for (int i = 0; i < 12; i++) fprintf(stderr, " [%d] %.0f", i, (double)sx[i] / (double)sx[15]);
+                for (int i = 0; i < 15; i++) fprintf(stderr, " [%d] %.0f", i, (double)sx[i] / (double)sx[15]);
                 fprintf(stderr, "\n");
             }
             PCQ_HIP(hipMemsetAsync(d_stats + 16, 0, 128, s));
