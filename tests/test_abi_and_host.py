@@ -416,7 +416,7 @@ def test_hot_loops_keep_their_loads_in_flight():
     """Two properties of the compiled gfx950 code that decide the grid collector's speed and that a source edit can lose
     without any test noticing (both were lost once in round 4): pass 0 must not wait for a class byte
     right behind its load — that wait also covers the next tile's positions, the kernel's prefetch — and the streaming fold's
-    main loop (between its third and fourth barrier) must hold no scratch access."""
+    main loop (its longest stretch without a barrier) must hold no scratch access."""
     for name, body in _kernel_bodies(_kernel_asm("grid_pass0.hip"), "k_p0_part"):
         for n, l in enumerate(body):
             if "global_load_ubyte" in l or "global_load_ushort" in l:
@@ -428,7 +428,8 @@ def test_hot_loops_keep_their_loads_in_flight():
         found += 1
         barriers = [n for n, l in enumerate(body) if l.strip().startswith("s_barrier")]
         assert len(barriers) >= 4, name
-        loop = body[barriers[2]:barriers[3]]
-        assert len(loop) > 500  # (the loop is there)
+        a, b = max(zip(barriers, barriers[1:]), key=lambda ab: ab[1] - ab[0])
+        loop = body[a:b]
+        assert len(loop) > 1000  # (the stream is there: no barrier inside)
         assert not [l for l in loop if l.strip().startswith("scratch_")], name
     assert found == 1
