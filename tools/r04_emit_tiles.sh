@@ -3,7 +3,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04
 O=gpurun_out/r04/emit_tiles.log; : > $O
-for sorted in "" 1; do for frac in 1.0 0.1 0.01; do for smax in 256 0 64 1024; do
+for sorted in "" 1; do for frac in 1.0 0.1 0.01; do for smax in 64 0 256; do
   echo "== SORTED=${sorted:-0} FRAC=$frac EMIT_SPARSE_MAX=$smax ==" >> $O
   EMIT_SPARSE_MAX=$smax SORTED=$sorted FRAC=$frac timeout -k 10 300 python tools/emit_probe.py ca13_XL 163000000 4 >> $O 2>&1 || exit 1
 done; done; done
