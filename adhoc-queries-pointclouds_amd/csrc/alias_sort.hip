@@ -1,7 +1,7 @@
-// alias_sort.hip — orders the tuples of aliased grid keys by (key, file order) for the exact replay of grid.hip.
+// alias_sort.hip — orders the tuples of aliased grid keys by (key, file order) for the exact replay of grid_finish.hip.
 //
 // The list is normally a handful of tuples (a point exactly on the grid's far face when dims is a power of two), and
-// grid.hip ranks those with a quadratic kernel.  Inputs that alias massively (a grid box much smaller than the data it
+// grid_finish.hip ranks those with a quadratic kernel.  Inputs that alias massively (a grid box much smaller than the data it
 // is fed) make the list as long as the scan; for those the order comes from rocPRIM's radix sort — two stable passes
 // over (file order, then key) — so the replay stays O(n log n) instead of O(n^2).  Not a hot path: library sort.
 #include <cstring>

@@ -1,7 +1,7 @@
 // pcq_api.hip — the C ABI of include/pcq.h: context, device-resident collectors, the scan entry
 // points and the host-block streaming pipeline.
 //
-// Everything here is plumbing around the kernels of scan_count.hip / scan_generic.hip / grid.hip.
+// Everything here is plumbing around the kernels of scan_count.hip / scan_generic.hip / grid_*.hip.
 // There is deliberately no CPU implementation of any scan in this library: if no HIP device is
 // usable, pcq_init fails and nothing else can be called.
 #include "pcq_internal.h"
@@ -322,7 +322,7 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
         if (value < 0 || value > 3) return pcq_fail(PCQ_ERR_ARG, "allreduce_fail must be 0, 1, 2 or 3");
         ctx->allreduce_fail = (int)value;
     } else if (!strcmp(key, "grid_pending_budget")) {
-        // (points scanned into a grid collector before it folds; a fold's tuple counts and offsets are 32-bit, grid.hip clamps to that)
+        // (points scanned into a grid collector before it folds; a fold's tuple counts and offsets are 32-bit, grid_host.hip clamps to that)
         if (value < 0 || value > (int64_t)1 << 40) return pcq_fail(PCQ_ERR_ARG, "grid_pending_budget must be 0..2^40");
         ctx->grid_pending_budget = value;
     } else if (!strcmp(key, "grid_agg")) {

@@ -101,12 +101,12 @@ struct DevGrid {
     double bmin[3], bmax[3];
     double cell_size;
     double dims_f[3];     // dims as f64 (`self.dimensions.x as f64`, grid_sampling.rs:51)
-    double inv_extent[3]; // 1 / (bmax - bmin): only to find the cell WITHOUT the division when that is provably safe (grid.hip cell_of)
-    double qk[3];         // RN(dims / (bmax - bmin)), and the range / boundary guard of the short cell computation (grid.hip cell_fast)
+    double inv_extent[3]; // 1 / (bmax - bmin): only to find the cell WITHOUT the division when that is provably safe (grid_common.h cell_of)
+    double qk[3];         // RN(dims / (bmax - bmin)), and the range / boundary guard of the short cell computation (grid_common.h cell_fast)
     double qmax[3], guard[3];
     uint64_t mask[3];     // (1 << bits) - 1
     uint32_t shift[3];    // 0, bits_x, bits_x + bits_y  (already & 63)
-    uint32_t keys_wide;   // 1: a key can have more than 32 bits (grid.hip cell_hash)
+    uint32_t keys_wide;   // 1: a key can have more than 32 bits (grid_common.h cell_hash)
 };
 
 constexpr uint64_t PCQ_EMPTY_KEY = ~0ull;
@@ -215,7 +215,7 @@ struct pcq_collector {
     double bmin[3], bmax[3], cell_size = 0;
     uint64_t dims[3], bits[3];
     DevGrid grid;
-    GridState *gs = nullptr;            // pending tuple runs + folded winners (grid.hip)
+    GridState *gs = nullptr;            // pending tuple runs + folded winners (grid_host.hip)
     uint64_t next_index = 0;            // file-order index the next scan starts at
     hipStream_t last_stream = nullptr;  // stream of the most recent scan: accessors wait on it
 };

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 pkg = importlib.import_module("adhoc-queries-pointclouds_amd")
 from test_gpu_scan import DevFile, small_spec  # noqa: E402
 
-TILE = 5120  # P0_TILE of csrc/grid.hip
+TILE = 5120  # P0_TILE of csrc/grid_common.h
 
 
 def scan_ordered_image(oracle, seed, n, fmt, snap_step=512, snap_fraction=0.5):

@@ -377,7 +377,7 @@ def test_grid_cells_on_and_next_to_cell_boundaries(oracle, gpu_ctx, cell, bmin, 
 
 
 def test_grid_fold_levels_refold_and_forced_fanout(oracle):
-    """The grid collector partitions the matches by cell key and folds each partition in LDS (csrc/grid.hip): a coarse
+    """The grid collector partitions the matches by cell key and folds each partition in LDS (csrc/grid_*.hip): a coarse
     grid folds its 512 level-1 bins directly (one 6400-slot table per workgroup), a dense one gets a second partition
     level whose fan-out comes from a measured estimate, and a fan-out that turns out too small (forced here) makes
     partitions overflow their LDS table and the fold is repeated with more partitions.  Same cells and winners as the
