@@ -980,8 +980,23 @@ extern "C" int pcq_prepare_host_scans(pcq_ctx *ctx) {
     if (ctx->stage_warm.joinable() || ctx->h_stage[0]) return PCQ_OK;  // under way, or nothing left to prepare
     ctx->stage_warm = std::thread([ctx] {
         (void)hipSetDevice(ctx->device);
+        // The first LARGE host-to-device copy of a process takes 8 ms inside the call (the runtime sets its copy path up; later
+        // ones take microseconds: profiles/r04_cli_first_file.log) — twice what pinning the ring takes, and independent of it:
+        // a copy of one pinned megabyte, on a thread of its own, beside the pinning.
+        std::thread first_copy([ctx] {
+            (void)hipSetDevice(ctx->device);
+            const size_t bytes = 1u << 20;  // (large enough to take the path the chunks take; 8 bytes did not)
+            void *h = nullptr, *d = nullptr;
+            if (hipHostMalloc(&h, bytes, hipHostMallocDefault) == hipSuccess && hipMalloc(&d, bytes) == hipSuccess &&
+                hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess)
+                (void)hipStreamSynchronize(ctx->copy_stream);
+            if (d) (void)hipFree(d);
+            if (h) (void)hipHostFree(h);
+            (void)hipGetLastError();
+        });
         (void)ensure_stage_now(ctx, (size_t)ctx->chunk_points * 12 + 4096, 2);  // (what a scan of positions + classes asks for: scan_host_impl)
         ensure_copy_pool(ctx);
+        first_copy.join();
     });
     return PCQ_OK;
 }
@@ -1048,8 +1063,6 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
     if (chunk < 1) chunk = 1;
     chunk = (chunk + 3) & ~3ull;  // multiples of 4 points keep 12-byte blocks 16-byte aligned per chunk
     const size_t stage_need = (size_t)(chunk * pl.bytes_per_point) + 64;
-    rc = ensure_stage(ctx, stage_need, 1);  // (the second pair: behind the first chunk, below)
-    if (rc) return rc;
     static const bool timing = getenv("PCQ_TIMING") && getenv("PCQ_TIMING")[0] == '1';
     const bool first_scan = timing && !ctx->scanned_before;
     ctx->scanned_before = true;
@@ -1057,6 +1070,9 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
     auto stamp = [&](const char *what) {
         if (first_scan) fprintf(stderr, "[pcq] first scan of the context: %s at %.1f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_scan).count());
     };
+    rc = ensure_stage(ctx, stage_need, 1);  // (the second pair: behind the first chunk, below)
+    if (rc) return rc;
+    stamp("first staging pair ready");
 
     hipStream_t s = ctx->stream, cs = ctx->copy_stream;
     const uint64_t nchunks = (cols->n + chunk - 1) / chunk;
@@ -1091,8 +1107,10 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
             if (!pl.need_rgb) bytes = off_cls + (pl.need_cls ? (size_t)cnt : 0);
             if (!pl.need_cls && !pl.need_rgb) bytes = (size_t)cnt * 12;
         }
+        if (k == 0) stamp("first chunk read into the staging buffer");
         PCQ_HIP(hipMemcpyAsync(ctx->d_stage[b], h, bytes, hipMemcpyHostToDevice, cs));
         PCQ_HIP(hipEventRecord(ctx->copied[b], cs));
+        if (k == 0) stamp("first transfer issued");
         return PCQ_OK;
     };
 
