@@ -150,14 +150,20 @@ def test_grid_tuple_formats_and_fold_shapes_agree(oracle, tuple16, stream):
         ctx.set_option("grid_stream", stream)
         files = [DevFile(ctx, im, h) for im, h in zip(images, hdrs)]
         try:
-            cases = [("one entry, coarse", [0], 5.0, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds"),
-                     ("one entry, dense", [0], 0.2, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds"),
-                     ("two entries, coarse", [0, 1], 5.0, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds"),
-                     ("two entries, dense", [0, 1], 0.2, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds"),
-                     ("class query, coarse", [0, 1], 4.0, (-100.0, -100.0, -20.0), (120.0, 100.0, 20.0), "class"),
-                     ("class query, dense", [0], 0.3, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "class"),
-                     ("box wider than 2^24 units on every axis", [2], 2000.0, (-20000.0, -20000.0, -20000.0), (20000.0, 20000.0, 20000.0), "bounds")]
-            for name, which, cell, bmin, bmax, kind in cases:
+            cases = [("one entry, coarse", [0], 5.0, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds", False),
+                     ("one entry, dense", [0], 0.2, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds", False),
+                     ("two entries, coarse", [0, 1], 5.0, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds", False),
+                     ("two entries, dense", [0, 1], 0.2, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds", False),
+                     ("class query, coarse", [0, 1], 4.0, (-100.0, -100.0, -20.0), (120.0, 100.0, 20.0), "class", False),
+                     ("class query, dense", [0], 0.3, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "class", False),
+                     ("box wider than 2^24 units on every axis", [2], 2000.0, (-20000.0, -20000.0, -20000.0), (20000.0, 20000.0, 20000.0), "bounds", False),
+                     # (round 4, late) 12 + 12 + 9 key bits: the hash's path for keys of more than 32 bits
+                     ("keys wider than 32 bits", [0], 0.05, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds", False),
+                     # a fold between the scans: the second fold meets the first one's winners (they stay, or lose to a closer point)
+                     ("the same file twice, coarse, folded in between", [0, 0], 5.0, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds", True),
+                     ("two entries, coarse, folded in between", [1, 0], 5.0, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds", True),
+                     ("two entries, dense, folded in between", [0, 1], 0.2, (-60.0, -60.0, -12.0), (60.0, 60.0, 12.0), "bounds", True)]
+            for name, which, cell, bmin, bmax, kind, fold_between in cases:
                 og = oracle.grid_collector(bmin, bmax, cell)
                 gg = ctx.grid_collector(bmin, bmax, cell)
                 first = 0
@@ -172,6 +178,8 @@ def test_grid_tuple_formats_and_fold_shapes_agree(oracle, tuple16, stream):
                     else:
                         assert oracle.search_last_class(images[k], 2, og) == 0
                         ctx.scan_dev(cols, pkg.Predicate.classification(2), gg)
+                    if fold_between:
+                        assert gg.point_count() == og.point_count(), name
                 assert og.point_count() > 0, name
                 check_same(gg, og)
                 gg.free()
