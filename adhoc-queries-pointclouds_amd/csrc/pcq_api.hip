@@ -35,6 +35,7 @@ __global__ void k_words_to_host(const uint64_t *__restrict__ src, uint64_t *__re
 
 extern "C" int pcq_abi_version(void) { return PCQ_ABI_VERSION; }
 static void join_stage_warm(pcq_ctx *ctx);
+static void join_copy_warm(pcq_ctx *ctx);
 
 // ---------------------------------------------------------------------------------------------
 // context
@@ -121,6 +122,10 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
         if (v >= 4) ctx->chunk_points = (uint64_t)v;
     }
     if (const char *e = getenv("PCQ_NUMA_LOCAL")) ctx->numa_local = atoi(e) != 0;
+    if (const char *e = getenv("PCQ_HOST_IN_PLACE")) {
+        const int v = atoi(e);
+        if (v >= 0 && v <= 2) ctx->host_in_place = v;
+    }
     if (const char *e = getenv("PCQ_COPY_THREADS")) {
         const int v = atoi(e);
         if (v >= 1 && v <= 64) ctx->copy_threads = v;
@@ -152,6 +157,9 @@ extern "C" int pcq_shutdown(pcq_ctx *ctx) {
     if (!ctx) return PCQ_OK;
     (void)hipSetDevice(ctx->device);
     join_stage_warm(ctx);
+    join_copy_warm(ctx);
+    if (ctx->copy_warm_h) (void)hipHostFree(ctx->copy_warm_h);
+    if (ctx->copy_warm_d) (void)hipFree(ctx->copy_warm_d);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);
     for (int i = 0; i < 2; i++) {
@@ -328,6 +336,9 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "grid_agg")) {
         if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "grid_agg must be 0 (adaptive), 1 (always) or 2 (never)");
         ctx->grid_agg = (int)value;
+    } else if (!strcmp(key, "host_in_place")) {
+        if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "host_in_place must be 0 (never), 1 (always) or 2 (until the copy path is set up)");
+        ctx->host_in_place = (int)value;
     } else if (!strcmp(key, "emit_sparse_max")) {
         if (value < 0 || value > 2048) return pcq_fail(PCQ_ERR_ARG, "emit_sparse_max must be 0..2048");
         ctx->emit_sparse_max = (int)value;
@@ -391,6 +402,7 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     else if (!strcmp(key, "grid_tuple16")) *value = ctx->grid_tuple16;
     else if (!strcmp(key, "grid_stream")) *value = ctx->grid_stream;
     else if (!strcmp(key, "grid_block_pad")) *value = ctx->grid_block_pad;
+    else if (!strcmp(key, "host_in_place")) *value = ctx->host_in_place;
     else if (!strcmp(key, "emit_sparse_max")) *value = ctx->emit_sparse_max;
     else if (!strcmp(key, "grid_deferred")) *value = ctx->grid_deferred;
     else if (!strcmp(key, "grid_last_tuples")) *value = ctx->grid_last_tuples;
@@ -874,6 +886,26 @@ extern "C" int pcq_scan_dev(pcq_ctx *ctx, const pcq_columns *cols, const pcq_pre
 static void join_stage_warm(pcq_ctx *ctx) {
     if (ctx->stage_warm.joinable()) ctx->stage_warm.join();
 }
+// The first LARGE host-to-device copy of a process takes 8 ms inside the call (the runtime sets its copy path up; the later
+// ones take microseconds; a copy of 8 bytes does not do it: profiles/r04_cli_first_file.log).  start_copy_warm() spends them
+// on a thread of its own — one pinned megabyte through hipMemcpyAsync on the copy stream — while the context's first scan
+// reads its chunks in place; whoever uses the copy stream next joins it first.
+static void join_copy_warm(pcq_ctx *ctx) {
+    if (ctx->copy_warm.joinable()) ctx->copy_warm.join();
+}
+static void start_copy_warm(pcq_ctx *ctx) {
+    int expected = 0;
+    if (!ctx->copy_warm_state.compare_exchange_strong(expected, 1)) return;
+    ctx->copy_warm = std::thread([ctx] {
+        (void)hipSetDevice(ctx->device);
+        const size_t bytes = 1u << 20;
+        if (hipHostMalloc(&ctx->copy_warm_h, bytes, hipHostMallocDefault) == hipSuccess && hipMalloc(&ctx->copy_warm_d, bytes) == hipSuccess &&
+            hipMemcpyAsync(ctx->copy_warm_d, ctx->copy_warm_h, bytes, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess)
+            (void)hipStreamSynchronize(ctx->copy_stream);
+        (void)hipGetLastError();
+        ctx->copy_warm_state.store(2);
+    });
+}
 static int ensure_stage_now(pcq_ctx *ctx, size_t bytes, int upto);
 static int ensure_stage(pcq_ctx *ctx, size_t bytes, int upto = 2) {
     join_stage_warm(ctx);
@@ -922,6 +954,7 @@ int pcq_stream_fd_to_device(pcq_ctx *ctx, int fd, uint64_t offset, uint64_t byte
     const size_t chunk = 32u << 20;
     int rc = ensure_stage(ctx, (bytes < chunk ? (size_t)bytes : chunk) + 64);
     if (rc) return rc;
+    join_copy_warm(ctx);
     if (ctx->stage_busy[0] || ctx->stage_busy[1]) {  // a nowait scan may still be reading the staging buffers
         PCQ_HIP(hipStreamSynchronize(ctx->stream));
         ctx->stage_busy[0] = ctx->stage_busy[1] = false;
@@ -980,23 +1013,8 @@ extern "C" int pcq_prepare_host_scans(pcq_ctx *ctx) {
     if (ctx->stage_warm.joinable() || ctx->h_stage[0]) return PCQ_OK;  // under way, or nothing left to prepare
     ctx->stage_warm = std::thread([ctx] {
         (void)hipSetDevice(ctx->device);
-        // The first LARGE host-to-device copy of a process takes 8 ms inside the call (the runtime sets its copy path up; later
-        // ones take microseconds: profiles/r04_cli_first_file.log) — twice what pinning the ring takes, and independent of it:
-        // a copy of one pinned megabyte, on a thread of its own, beside the pinning.
-        std::thread first_copy([ctx] {
-            (void)hipSetDevice(ctx->device);
-            const size_t bytes = 1u << 20;  // (large enough to take the path the chunks take; 8 bytes did not)
-            void *h = nullptr, *d = nullptr;
-            if (hipHostMalloc(&h, bytes, hipHostMallocDefault) == hipSuccess && hipMalloc(&d, bytes) == hipSuccess &&
-                hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->copy_stream) == hipSuccess)
-                (void)hipStreamSynchronize(ctx->copy_stream);
-            if (d) (void)hipFree(d);
-            if (h) (void)hipHostFree(h);
-            (void)hipGetLastError();
-        });
         (void)ensure_stage_now(ctx, (size_t)ctx->chunk_points * 12 + 4096, 2);  // (what a scan of positions + classes asks for: scan_host_impl)
         ensure_copy_pool(ctx);
-        first_copy.join();
     });
     return PCQ_OK;
 }
@@ -1082,6 +1100,20 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
     const size_t off_cls = pl.need_xyz ? align16((size_t)chunk * 12) : 0;
     const size_t off_rgb = off_cls + (pl.need_cls ? align16((size_t)chunk) : 0);
 
+    // A scan that reads every byte ONCE — count and grid collectors — reads the pinned ring in place: the kernels stream host
+    // memory over PCIe at the rate the copy engine moves it (59 against 54.5 GB/s for a count, 56.5 against 50.1 for a grid
+    // scan: profiles/r04_zero_copy.log), the chunk is not written to and read from HBM in between, and the process never sets
+    // up its copy path (8 ms inside the first large hipMemcpyAsync: profiles/r04_cli_first_file.log) — but on a stream of files the
+    // copy engine is a tenth faster (median file of 240 MB: 5.5 against 6.6 ms).  So, by default (host_in_place 2), the scans of
+    // a context read in place WHILE a thread sets the copy path up, and copy from then on.  The buffer collector reads the
+    // positions twice (count pass, emit pass): it always keeps the device twin.
+    bool in_place = false;
+    if (c->kind != COLL_BUFFER && ctx->host_in_place == 1) in_place = true;
+    if (c->kind != COLL_BUFFER && ctx->host_in_place == 2 && ctx->copy_warm_state.load() != 2) {
+        in_place = true;
+        start_copy_warm(ctx);  // (the NEXT scan copies: 5.5 ms per 240 MB file against 6.6 in place, once the copy path exists)
+    }
+    if (!in_place) join_copy_warm(ctx);  // (nobody else is on the copy stream)
     auto stage = [&](uint64_t k) -> int {
         const int b = (int)(k & 1);
         const uint64_t first = k * chunk;
@@ -1108,6 +1140,7 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
             if (!pl.need_cls && !pl.need_rgb) bytes = (size_t)cnt * 12;
         }
         if (k == 0) stamp("first chunk read into the staging buffer");
+        if (in_place) return PCQ_OK;  // (the kernels read it where it is)
         PCQ_HIP(hipMemcpyAsync(ctx->d_stage[b], h, bytes, hipMemcpyHostToDevice, cs));
         PCQ_HIP(hipEventRecord(ctx->copied[b], cs));
         if (k == 0) stamp("first transfer issued");
@@ -1149,15 +1182,11 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
     }
     for (uint64_t k = 0; k < nchunks; k++) {
         const int b = (int)(k & 1);
-        if (k + 1 < nchunks) {  // stage the next chunk while this one is scanned
-            rc = stage(k + 1);
-            if (rc) return fail(rc);
-        }
         const uint64_t first = k * chunk;
         const uint64_t cnt = cols->n - first < chunk ? cols->n - first : chunk;
-        PCQ_HIP_OR_FAIL(hipStreamWaitEvent(s, ctx->copied[b], 0));
+        if (!in_place) PCQ_HIP_OR_FAIL(hipStreamWaitEvent(s, ctx->copied[b], 0));
         pcq_columns dcols = *cols;
-        const uint8_t *d = ctx->d_stage[b];
+        const uint8_t *d = in_place ? ctx->h_stage[b] : ctx->d_stage[b];
         if (pl.aos) {
             dcols.xyz = pl.need_xyz ? d + (hx - pl.aos_base) : nullptr;
             dcols.cls = pl.need_cls ? d + (hc - pl.aos_base) : nullptr;
@@ -1174,6 +1203,10 @@ static int scan_host_impl(pcq_ctx *ctx, int fd, const pcq_columns *cols, const p
         PCQ_HIP_OR_FAIL(hipEventRecord(ctx->consumed[b], s));
         ctx->stage_busy[b] = true;
         if (k == 0) stamp("first chunk's kernels launched");
+        if (k + 1 < nchunks) {  // the next chunk is read while this one's kernels run (in place: while they read this one over PCIe)
+            rc = stage(k + 1);
+            if (rc) return fail(rc);
+        }
     }
     if (wait) {
         PCQ_HIP_OR_FAIL(hipStreamSynchronize(s));

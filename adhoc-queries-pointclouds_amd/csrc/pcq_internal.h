@@ -2,6 +2,8 @@
 #pragma once
 
 #include <sched.h>
+#include <atomic>
+#include <thread>
 #include "copy_pool.h"
 #include <hip/hip_runtime.h>
 
@@ -166,6 +168,12 @@ struct pcq_ctx {
                                         // 1 = every tile, 2 = never; the results are the same, the tuples moved are not
     int grid_stream = 1;                // option (tests): 0 = a coarse grid's bins are folded by k_fold<BIG> (the fallback of the streaming fold) only
     int64_t grid_deferred = 0;          // diagnostics: bins the streaming fold left to k_fold<BIG> (survivor list outgrown)
+    int host_in_place = 2;              // option: count and grid scans of host / file data read the pinned staging ring IN PLACE (over PCIe) instead of
+                                        // copying it to a device twin first: 0 never, 1 always, 2 while the process's copy path is being set up
+                                        // (pcq_api.hip scan_host_impl)
+    std::thread copy_warm;              // the thread that sets it up: one pinned megabyte through hipMemcpyAsync, beside the first file's scan
+    std::atomic<int> copy_warm_state{0};  // 0 not started, 1 under way, 2 done
+    void *copy_warm_h = nullptr, *copy_warm_d = nullptr;
     int emit_sparse_max = 64;           // option: a tile of 2048 points with at most this many matches is written by k_emit_sparse (0 = never)
     bool scanned_before = false;        // (PCQ_TIMING: the first host / file scan of a context prints where its time goes)
     int grid_block_pad = 0;             // option: 16-byte units between the end of a tile's block of tuples and the next block

@@ -270,9 +270,14 @@ int pcq_bind_thread_near_device(pcq_ctx *ctx);
 /* Options: "blocks_per_cu" (persistent blocks per CU of the strided count kernels), "chunk_points" (points per staging
  * chunk of the host paths), "copy_threads" (threads filling a staging chunk, default 8), "numa_local",
  * "allreduce_single_rank", "allreduce_fail" (tests: 1 = pcq_allreduce_sum_u64 fails before it touches anything, 2 = after the
- * reduction ran), "grid_pending_budget" (points a grid collector may hold unfolded; 0 = default), "grid_agg" (pass 0 folds a
+ * reduction ran, 3 = inside the RCCL group, behind rank 0), "grid_pending_budget" (points a grid collector may hold unfolded; 0 = default), "grid_agg" (pass 0 folds a
  * tile's duplicate cells before they travel: 0 = while it pays, 1 = every tile, 2 = never; same results in every mode),
- * "grid_f2" (tests: the second-level fan-out a fold starts from; 0 = from the measured estimate).  pcq_get_option also
+ * "grid_f2" (tests: the second-level fan-out a fold starts from; 0 = from the measured estimate), "host_in_place" (host / file
+ * scans with a count or grid collector read the pinned staging ring in place over PCIe: 0 never, 1 always, 2 = while the
+ * process's copy path is being set up — the default), "emit_sparse_max" (a 2048-point tile with at most this many matches is
+ * written by one wave from the count pass's match bits; default 64, 0 = never), "grid_tuple16" / "grid_stream" (tests: force
+ * the grid collector's tuple size — 1 = 16 bytes with the selector, 2 = without, 0 = 24 bytes — and the coarse fold's form —
+ * 1 = k_fold_stream, 0 = k_fold<BIG>; same results in every combination).  pcq_get_option also
  * reads "numa_node" and the grid diagnostics "grid_folds", "grid_level2" (folds that needed a second partition level),
  * "grid_refolds" (folds repeated with more partitions), "grid_level2_exact" (second levels repeated in the counting form),
  * "grid_compactions" (folds that copied short fragments together first), "grid_last_f2", "grid_last_tuples" (tuples the last

@@ -19,10 +19,12 @@ d = tempfile.mkdtemp(prefix="pcq_first_", dir="/tmp")
 for i, s in enumerate(specs.synth_ca13(points_per_file=20_000_000, files=16)):
     o.synth_write(s, os.path.join(d, f"tile{i:02d}.last"), threads=32)
 xl = "643431.76;3883547.565;-46194.145;736910.93;3977026.735;47285.025"
-for rep in range(3):
+for rep in range(9):
     time.sleep(1.0)
+    mode = str((2, 0, 1)[rep % 3])  # in turn: in place while the copy path is set up (2, the default) / never (0) / always (1)
     r = subprocess.run([QUERY, "-i", d, "--optimized", "--parallel", "--bounds", xl], capture_output=True, text=True,
-                       env=dict(os.environ, PCQ_TIMING="1", PCQ_EXIT="fast", **({"PCQ_COPY_THREADS": sys.argv[1]} if len(sys.argv) > 1 else {})))
+                       env=dict(os.environ, PCQ_TIMING="1", PCQ_EXIT="fast", PCQ_HOST_IN_PLACE=mode))
+    print("PCQ_HOST_IN_PLACE=" + mode)
     lines = [l for l in r.stderr.splitlines() if "first scan" in l or "staging" in l or "ready after" in l]
     files = [float(l.split(" searched in ")[1].split(" ms")[0]) for l in r.stderr.splitlines() if " searched in " in l]
     print("\n".join(lines))
