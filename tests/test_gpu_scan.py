@@ -775,6 +775,43 @@ def test_scan_host_nowait_lets_the_caller_reuse_its_buffer(oracle, gpu_ctx):
         gpu_ctx.set_option("chunk_points", 1 << 20)
 
 
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_host_scans_read_the_staging_ring_in_place_or_through_its_device_twin(oracle, mode):
+    """host_in_place: the kernels of a count or grid scan read the pinned staging ring over PCIe (1), a device copy of it (0), or
+    the one while a thread of the library sets the process's copy path up and the other from then on (2, the default) — and the
+    buffer collector always the copy.  Several chunks per call, several calls per context (mode 2 changes over between them)."""
+    spec = small_spec(4242, 90_001, fmt=1)
+    image = oracle.synth_image(spec, transposed=True)
+    hdr = oracle.parse_header(image[:400].tobytes())
+    n, otp = hdr.number_of_points, hdr.offset_to_point_data
+    bmin, bmax = BOXES[0]
+    lmin, lmax = pkg.box_to_local(bmin, bmax, list(hdr.scale), list(hdr.offset))
+    xyz = np.ascontiguousarray(image[otp:otp + 12 * n])
+    cls = np.ascontiguousarray(image[otp + 15 * n: otp + 16 * n])
+    cols = binding.make_columns(xyz=xyz.ctypes.data, cls=cls.ctypes.data, n=n, scale=list(hdr.scale), offset=list(hdr.offset))
+    oc, ob, og = oracle.count_collector(), oracle.buffer_collector(), oracle.grid_collector(bmin, bmax, 1.5)
+    for c in (oc, ob, og):
+        assert oracle.search_last_bounds(image, bmin, bmax, c) == 0
+    with pkg.Context(0) as ctx:
+        ctx.set_option("host_in_place", mode)
+        ctx.set_option("chunk_points", 8192)
+        pred = pkg.Predicate.bounds(lmin, lmax)
+        for rep in range(3):
+            cc, bc, gc = ctx.count_collector(), ctx.buffer_collector(), ctx.grid_collector(bmin, bmax, 1.5)
+            ctx.scan_host(cols, pred, cc)
+            ctx.scan_host(cols, pred, gc)
+            ctx.scan_host(cols, pred, bc)
+            assert cc.point_count() == oc.point_count() > 0
+            assert bc.points().tobytes() == ob.points().tobytes()
+            assert gc.point_count() == og.point_count()
+            gp, gk = gc.points(), gc.grid_cells()
+            order = np.argsort(gk, kind="stable")
+            assert np.array_equal(gk[order], og.grid_cells())
+            assert gp[order].tobytes() == og.points().tobytes()  # per cell: the same winner
+            cc.free(), bc.free(), gc.free()
+    oc.free(), ob.free(), og.free()
+
+
 def test_prepare_host_scans_runs_beside_the_caller_and_changes_nothing(oracle):
     """pcq_prepare_host_scans pins the staging ring on a thread of the library: a scan issued at once waits for it, a scan
     with larger chunks than it prepared replaces the ring, a context shut down before any scan joins it; results are the
