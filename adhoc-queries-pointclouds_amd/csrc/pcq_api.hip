@@ -116,6 +116,11 @@ extern "C" int pcq_init(int device, pcq_ctx **out_ctx) {
         pcq_shutdown(ctx);
         return rc;
     }
+    {  // (not more copy threads than this GPU's share of the host's hardware threads)
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int share = hw ? (int)(hw / (unsigned)ndev) : ctx->copy_threads;
+        if (ctx->copy_threads > share) ctx->copy_threads = share < 2 ? 2 : share;
+    }
     // tuning / test knobs (same meaning as pcq_set_option)
     if (const char *e = getenv("PCQ_CHUNK_POINTS")) {
         const long long v = atoll(e);

@@ -195,8 +195,10 @@ struct pcq_ctx {
     int numa_node = -1;               // NUMA node the GPU hangs off (sysfs), -1 if unknown
     cpu_set_t node_cpus;              // its CPUs (empty if unknown)
     int numa_local = 1;               // option "numa_local": staging buffers and copy helpers on that node
-    int copy_threads = 8;         // threads filling a staging buffer (caller + helpers): 2-4 reach the PCIe rate from memory next to the
-                                  // GPU, page-cache pages on the other socket need 8 (profiles/r01_cli_probe_timing.log)
+    int copy_threads = 16;        // threads filling a staging buffer (caller + helpers): 2-4 reach the PCIe rate from memory next to the
+                                  // GPU, page-cache pages on the other socket need 8 (profiles/r01_cli_probe_timing.log); a stream of
+                                  // files read with pread: 8 -> 5.5, 12 -> 5.0, 16 -> 4.9 ms per 240 MB (profiles/r04_cli_threads.log).
+                                  // pcq_init caps it at the host's hardware threads per GPU.
     CopyPool *copy_pool = nullptr;  // created on first use by pcq_scan_host / pcq_scan_fd
     uint64_t chunk_points = 1ull << 20;    // 12 MB of positions per staging chunk: the steady rate of 24 MB (profiles/r01_host_path_rate.json: 1-8 Mi equal)
                                            // at half the pinning in front of a process's first file (profiles/r04_cli_chunks.log: 25 -> 20 ms)

@@ -268,7 +268,7 @@ int pcq_read_fd_to_device(pcq_ctx *ctx, int fd, uint64_t file_offset, uint64_t b
 int pcq_bind_thread_near_device(pcq_ctx *ctx);
 
 /* Options: "blocks_per_cu" (persistent blocks per CU of the strided count kernels), "chunk_points" (points per staging
- * chunk of the host paths), "copy_threads" (threads filling a staging chunk, default 8), "numa_local",
+ * chunk of the host paths), "copy_threads" (threads filling a staging chunk, default 16), "numa_local",
  * "allreduce_single_rank", "allreduce_fail" (tests: 1 = pcq_allreduce_sum_u64 fails before it touches anything, 2 = after the
  * reduction ran, 3 = inside the RCCL group, behind rank 0), "grid_pending_budget" (points a grid collector may hold unfolded; 0 = default), "grid_agg" (pass 0 folds a
  * tile's duplicate cells before they travel: 0 = while it pays, 1 = every tile, 2 = never; same results in every mode),
