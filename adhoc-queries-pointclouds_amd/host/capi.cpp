@@ -141,6 +141,17 @@ extern "C" int pcq_query_search_file_class(const char *path, uint8_t cls, int op
     return done(ClassSearcher(cls).search_file(path, optimized ? SearchImplementation::Optimized : SearchImplementation::Regular, *c->c));
 }
 
+extern "C" int pcq_query_test_plan_replace_execute(const char *path, const char *replacement, const double bmin[3], const double bmax[3],
+                                                   pcq_host_collector *c) {
+    if (!path || !bmin || !bmax || !c) return done(Status::Err(PCQ_ERR_ARG, "null argument"));
+    AABB b;
+    Status st = AABB::from_min_max(bmin, bmax, &b);
+    if (!st.ok()) return done(st);
+    FilePlan plan = plan_last_file_by_bounds_optimized(path, b);
+    if (replacement && ::rename(replacement, path) != 0) return done(Status::Err(PCQ_ERR_IO, std::string("rename: ") + strerror(errno)));
+    return done(execute_plan(plan, *c->c));
+}
+
 extern "C" int pcq_query_main(int argc, const char *const *argv) {
     return query_main(
         argc, argv,

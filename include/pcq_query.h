@@ -93,6 +93,11 @@ int pcq_query_main(int argc, const char *const *argv);
 int pcq_query_main_with_hooks(int argc, const char *const *argv, const char *device_slots, int allreduce_fail);
 int pcq_query_simulate_schedule(const uint64_t *cost, size_t nfiles, const double *ready_ms, int nslots, double ms_per_unit,
                                 int *slot_of_file, int *home_slot, double *makespan_ms);
+/* Test entry: the two halves of a LAST bounds search with something in between — the file's plan is made (header, offsets,
+ * box: the host prologue of run_search_parallel), then, if `replacement` is not NULL, that file is renamed over `path`, then the
+ * plan is executed.  A plan must not be executed on another file under the same name. */
+int pcq_query_test_plan_replace_execute(const char *path, const char *replacement, const double bmin[3], const double bmax[3],
+                                        pcq_host_collector *c);
 
 #ifdef __cplusplus
 }

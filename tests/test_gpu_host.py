@@ -43,6 +43,7 @@ class Q:
         lib.pcq_query_collector_grid_cells.argtypes = [vp, vp, u64, P(u64)]
         lib.pcq_query_search_file_bounds.argtypes = [C.c_char_p, dd, dd, C.c_int, vp, P(C.c_int)]
         lib.pcq_query_search_file_class.argtypes = [C.c_char_p, C.c_uint8, C.c_int, vp]
+        lib.pcq_query_test_plan_replace_execute.argtypes = [C.c_char_p, C.c_char_p, dd, dd, vp]
 
     @staticmethod
     def d3(v):
@@ -545,6 +546,36 @@ def test_cli_density_over_many_small_files_takes_two_threads_per_gpu(oracle, tmp
         assert rc == 0, err
         assert sorted(body) == want[name]
         assert err.count("context on device 0 ready") == contexts, (name, flags, err)
+
+
+def test_a_plan_is_not_executed_on_another_file_under_the_same_name(oracle, q, tmp_path):
+    """run_search_parallel plans every file (header, offsets, box) before the first worker has a context, and the scan opens the
+    path again: a file replaced in between — another inode, or rewritten in place — must not be scanned with the first one's
+    offsets, scale and point count.  The test entry makes the plan, renames another file over the path, executes the plan."""
+    import shutil
+    spec_a = specs._spec(7001, 50_000, 1, (0.01, 0.01, 0.01), (0.0, 0.0, 0.0), (-5000, -5000, -1000), (10001, 10001, 2001))
+    spec_b = specs._spec(7002, 50_000, 1, (0.02, 0.02, 0.02), (5.0, 5.0, 5.0), (-5000, -5000, -1000), (10001, 10001, 2001))  # same size, other header
+    a, b = str(tmp_path / "a.last"), str(tmp_path / "b.last")
+    oracle.synth_write(spec_a, a)
+    oracle.synth_write(spec_b, b)
+    bmin, bmax = (-20.0, -20.0, -5.0), (20.0, 20.0, 5.0)
+    oc = oracle.count_collector()
+    assert oracle.search_last_bounds(np.fromfile(a, dtype=np.uint8), bmin, bmax, oc) == 0
+    want = oc.point_count()
+    oc.free()
+    assert want > 0
+    h = q.collector("count")
+    try:
+        # nothing in between: the plan's own file
+        assert q.lib.pcq_query_test_plan_replace_execute(a.encode(), None, q.d3(bmin), q.d3(bmax), h) == 0, q.lib.pcq_query_last_error()
+        assert q.count(h) == want
+        # another file renamed over the path (another inode)
+        shutil.copy(b, str(tmp_path / "b_copy.last"))
+        rc = q.lib.pcq_query_test_plan_replace_execute(a.encode(), str(tmp_path / "b_copy.last").encode(), q.d3(bmin), q.d3(bmax), h)
+        assert rc != 0 and b"changed while the query was running" in q.lib.pcq_query_last_error()
+        assert q.count(h) == want  # (nothing was added)
+    finally:
+        q.free(h)
 
 
 def test_cli_more_files_than_descriptors(oracle, tmp_path):
