@@ -15,7 +15,7 @@
 // A single-pass form (decoupled look-back over the tiles, one read of the positions) was built and measured first: on
 // this chip a look-back round is a cross-XCD round trip of several microseconds and the kernel took 2.8 ms for a
 // 163 M-point file against 1.05 ms for the same kernel with the look-back cut out — the second read of the positions
-// (0.3 ms at the streaming rate) is much cheaper than the dependency chain (profiles/r02_emit_lookback.txt).
+// (0.3 ms at the streaming rate) is much cheaper than the dependency chain (DESIGN_HISTORY.md D, profiles/r02_emit_lookback.txt).
 #include "dev_common.h"
 
 using namespace pcqdev;

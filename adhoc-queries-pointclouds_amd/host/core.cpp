@@ -191,7 +191,7 @@ ThreadContexts &this_threads_contexts() {
 // Left to the thread_local's destructor the same calls run in the thread-exit (or process-exit) phase: behind the
 // destructors of thread-locals constructed later, which is where a preloaded profiler keeps the per-thread state its HIP
 // interception uses (a `query` under rocprofv3 --memory-copy-trace printed its answer, wrote its traces and did not end:
-// DESIGN.md section 10).  The drivers call this at the end of every worker and before main() returns; the destructor stays
+// DESIGN.md section 9, profiles/r04_rocprof_query.log).  The drivers call this at the end of every worker and before main() returns; the destructor stays
 // as the net under a library user's threads.
 void release_thread_contexts() {
     if (g_process_is_ending.load()) return;

@@ -305,7 +305,7 @@ Status impossible_point_count(const LazerFile &lz) {
 // ---- columns in HBM -----------------------------------------------------------------------------------------
 // (A device-side LZ4 inflater — one wave per frame — was built and measured in round 1: 25 x slower than host
 // threads on real columns, because the lz4 crate writes linked blocks and a frame is one sequential job
-// (profiles/r01_lz4_device_rate.log).  It is not part of the product.)
+// (profiles/r01_lz4_device_rate.log, DESIGN_HISTORY.md D).  It is not part of the product.)
 struct DeviceColumns {
     pcq_ctx *ctx = nullptr;
     void *xyz = nullptr, *cls = nullptr, *rgb = nullptr;
