@@ -14,16 +14,19 @@ namespace pcqgrid {
 //      large); otherwise it lowers the minimum (atomicMin on the f64 bits) and is appended to the workgroup's SURVIVOR list
 //      in HBM scratch.  The tuple that ends up at the cell's minimum — and every tuple that ties with it — survives: when it
 //      was tested the minimum was not below it.
-//   2. EXACT, two barriers per BIN: among the survivors at their cell's final minimum the earliest in file order
-//      (atomicMin on the order), then that one survivor leaves its list index in the slot, and the slots' owners write the
-//      cells out in slot order — from the survivor records; nothing was parked.
+//   2. EXACT, one pass over the survivors: those at their cell's final minimum atomicMin a 64-bit word
+//      (order + 1) << 32 | list index — the earliest in file order wins and says where its record lies; nothing was parked.
+//   3. The cells leave in slot order, a wave's 64 consecutive slots per round (one store instruction = one contiguous run),
+//      from the survivor records, which are gathered before the first store is issued.
 // A file in random order leaves a few survivors per cell (the running minima of a random sequence: ln n, a little more
 // for what 1024 lanes see at the same time); a file sorted TOWARDS the cell centres makes every tuple a running minimum:
 // a bin whose survivors outgrow the list goes on the defer list, and k_fold<BIG> folds it the old way.
-// A wave's share of the bin is a range of the bin's TUPLES (not of its tiles: a compacted sparse run has ONE fragment per
-// bin); it finds the fragment its range starts in by a 64-ary search of the bin's prefix row, then takes the fragments 64
-// at a time — lane L holds fragment L's prefix and address — and turns "tuple g of the bin" into an address by a binary
-// search across the lanes (six bpermutes): no window in LDS, nothing shared with the other waves.
+// A wave takes the bin's fragments 64 at a time (batches handed out through a counter in LDS) — lane L holds fragment L's
+// prefix and address — and turns "tuple g of the bin" into an address without a search: the fragments write their numbers
+// at their first tuple's place in a per-wave map, and a prefix maximum over the lanes (six DPP steps) gives every tuple its
+// fragment.  No window in LDS, nothing shared with the other waves.  The kernel is bound by its vector instructions
+// (profiles/r04_grid_sq_counters.txt: 0.70 of the issue slots), so what it does per tuple is kept short: grid and entry
+// come out of the argument segment where they are used (karg), the hash is two 32-bit multiplies, the slot one 24-bit one.
 // ANYWIDE = false: every pending run has 16-byte tuples (one aligned load per tuple, four registers in flight); MULTI = false:
 // one entry (EntryRef::get) — the common fold of one file; anything else takes the <true, true> form.
 // A survivor is the tuple AS IT CAME (16 bytes: nothing is decoded for the few lanes of a wave that append one — the winner is,
