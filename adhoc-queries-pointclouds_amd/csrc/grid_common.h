@@ -9,7 +9,9 @@
 // A hash table in HBM costs one random 128-byte line per matched point (round 1: 29 ms per 163 M-point file at 10 m).
 // Here the random access happens in LDS, and what travels through HBM in between is written and read in order:
 //   pass 0  (per scan, asynchronous, ONE reading of the points)  k_p0_part: a tile of 5120 points becomes one
-//           BLOCK of tuples {x, y, z, index, class | entry [, colour]} (20 or 24 bytes), sorted in LDS by the level-1
+//           BLOCK of tuples — 16 bytes, 16-byte aligned: {x, y, z relative to the query box's low corner, place in the
+//           pending stream}, the class byte (and the second level's 16 selector bits) in the coordinates' spare top bytes;
+//           24 bytes {x, y, z, place, class | colour} when there is no room or a colour column —, sorted in LDS by the level-1
 //           bin of the tuple's cell key (top 9 bits of hash(key)) and written to its own place — tile t's block is at
 //           t x 5120 tuples — as one sequential stream, next to a 513-entry directory row (where each bin starts in
 //           the block).  No histogram pass, no cursors, no atomics in global memory, nothing read back (round 2
@@ -25,8 +27,11 @@
 //           bin b" into addresses by binary search, so the consumers still see dense chunks.  One workgroup per
 //           partition folds its tuples into an open-addressing table in LDS — atomicMin on the f64 distance bits, then
 //           on the file order among the tuples at the minimum, then the winner parks its payload — and writes one
-//           32-byte record + key per cell, coalesced.  A coarse grid folds its level-1 bins directly (k_fold<BIG>:
-//           a CU's whole LDS as one 6400-slot table); a denser grid first gets a second partition level (k_level2:
+//           32-byte record + key per cell, coalesced.  A coarse grid folds its level-1 bins directly, as a STREAM
+//           (k_fold_stream, grid_fold_stream.hip: a CU's whole LDS as one 6400-slot table of {key, best distance}; no
+//           window, no barrier inside a bin; a tuple above its cell's minimum is out, the others go to a survivor list
+//           and one exact pass picks the earliest at the minimum; k_fold<BIG> — three barriers per chunk — is its
+//           fallback for bins whose survivors outgrow the list); a denser grid first gets a second partition level (k_level2:
 //           one pass into fixed regions with slack, fan-out chosen from a measured estimate of the distinct cells per
 //           bin) and folds the small partitions two workgroups to a CU (k_fold_dense; k_fold<SMALL> for what that
 //           leaves: earlier winners, partitions longer than a chunk).
@@ -34,7 +39,10 @@
 // it is bound by memory unless the cell arithmetic is cut down (cell_fast); loads and stores share one in-order
 // counter, so a prefetch must be waited for before the stores behind it are issued; pointers loaded from memory make
 // flat loads, which also hold every LDS wait; a device-scope fence writes the L2 back; registers spilled to scratch are
-// HBM traffic (the dense fold: 4.8 GB each way per file until it ran with more registers and fewer waves).
+// HBM traffic (the dense fold: 4.8 GB each way per file until it ran with more registers and fewer waves).  Round 4: a wave64
+// vector instruction occupies its SIMD for four cycles — the folds are bound by their instruction COUNT (0.5 - 0.75 of the issue
+// slots), and a third of it was overhead: scalars parked in vector lanes (karg), a search per tuple (wave_max_scan), 64-bit
+// multiplies (cell_hash); a load in a branch, or behind a store, waits for everything in flight.
 // The folded winners are kept grouped by partition, so a later fold (more scans into the same collector: sequential
 // mode shares one grid, main.rs:129-133; a file streamed in chunks) merges them with the new tuples partition by
 // partition: an old winner is earlier in file order than every new tuple and its distance is recomputed from its
@@ -55,8 +63,8 @@
 // Everything the grid collector's translation units share: constants, the tuple and directory layouts, the cell / key /
 // distance arithmetic (THE definition every pass uses), the fragment-window reader, and the kernels' parameter blocks.
 // The kernels live in grid_pass0.hip (one reading of the points), grid_dir.hip (directory transposition, prefixes, compaction,
-// density probe), grid_level2.hip (second partition level), grid_fold.hip (the LDS folds), grid_finish.hip (exact replay of
-// aliased keys, drain); grid_host.hip drives them.
+// density probe), grid_level2.hip (second partition level), grid_fold_stream.hip (coarse grids: the streaming fold), grid_fold.hip
+// (the other LDS folds), grid_finish.hip (exact replay of aliased keys, drain); grid_host.hip drives them.
 namespace pcqgrid {
 using namespace pcqdev;
 
