@@ -344,6 +344,9 @@ extern "C" int pcq_set_option(pcq_ctx *ctx, const char *key, int64_t value) {
     } else if (!strcmp(key, "host_in_place")) {
         if (value < 0 || value > 2) return pcq_fail(PCQ_ERR_ARG, "host_in_place must be 0 (never), 1 (always) or 2 (until the copy path is set up)");
         ctx->host_in_place = (int)value;
+    } else if (!strcmp(key, "emit_park_max")) {
+        if (value < 0 || value > 256) return pcq_fail(PCQ_ERR_ARG, "emit_park_max must be 0..256");
+        ctx->emit_park_max = (int)value;
     } else if (!strcmp(key, "emit_sparse_max")) {
         if (value < 0 || value > 2048) return pcq_fail(PCQ_ERR_ARG, "emit_sparse_max must be 0..2048");
         ctx->emit_sparse_max = (int)value;
@@ -408,6 +411,7 @@ extern "C" int pcq_get_option(pcq_ctx *ctx, const char *key, int64_t *value) {
     else if (!strcmp(key, "grid_stream")) *value = ctx->grid_stream;
     else if (!strcmp(key, "grid_block_pad")) *value = ctx->grid_block_pad;
     else if (!strcmp(key, "host_in_place")) *value = ctx->host_in_place;
+    else if (!strcmp(key, "emit_park_max")) *value = ctx->emit_park_max;
     else if (!strcmp(key, "emit_sparse_max")) *value = ctx->emit_sparse_max;
     else if (!strcmp(key, "grid_deferred")) *value = ctx->grid_deferred;
     else if (!strcmp(key, "grid_last_tuples")) *value = ctx->grid_last_tuples;

@@ -174,6 +174,7 @@ struct pcq_ctx {
     std::thread copy_warm;              // the thread that sets it up: one pinned megabyte through hipMemcpyAsync, beside the first file's scan
     std::atomic<int> copy_warm_state{0};  // 0 not started, 1 under way, 2 done
     void *copy_warm_h = nullptr, *copy_warm_d = nullptr;
+    int emit_park_max = 256;            // option: a tile with at most this many matches leaves them as 16-byte words for the emit (0 = never; <= 256)
     int emit_sparse_max = 64;           // option: a tile of 2048 points with at most this many matches is written by k_emit_sparse (0 = never)
     bool scanned_before = false;        // (PCQ_TIMING: the first host / file scan of a context prints where its time goes)
     int grid_block_pad = 0;             // option: 16-byte units between the end of a tile's block of tuples and the next block

@@ -150,26 +150,65 @@ __device__ __forceinline__ void tile_load_and_test(const DevCols &c, const DevPr
 // It also leaves the tile's MATCH BITS: bits[tile * 32 + k], bit b = point k * 64 + b of the tile matched (row j of wave w
 // is the tile's points j * 256 + w * 64 ..: word j * 4 + w — file order).  256 bytes per tile, 1 % of what the pass reads;
 // the sparse emit below works from them alone.
+// PARK (round 4): a THIN tile — 1 .. park_max matches, a box that keeps a tenth of a file in random order — leaves its matches
+// themselves behind, {x, y, z, class} as one 16-byte word each, in file order, at park[tile * park_max ..): the emit then reads
+// 16 bytes per MATCH instead of the tile's 13 bytes per POINT a second time (k_emit_parked).  The class bytes of all eight points
+// are asked for together (no load in a branch); the ranks come from the tile's 32 mask words, summed by one wave.  Only for
+// predicates on the positions and files without a colour block (park == nullptr otherwise): a class predicate would have to
+// read positions it does not need, a colour block makes the parked word 24 bytes.
 template <int KIND>
-__global__ __launch_bounds__(BLOCK) void k_tile_counts(DevCols c, DevPred pr, uint64_t *__restrict__ counts, uint64_t *__restrict__ bits) {
+__global__ __launch_bounds__(BLOCK) void k_tile_counts(DevCols c, DevPred pr, uint64_t *__restrict__ counts, uint64_t *__restrict__ bits,
+                                                       uint4 *__restrict__ park, uint32_t park_max) {
     __shared__ uint32_t s_w[WAVES];
     __shared__ uint64_t s_bits[EMIT_ITEMS * WAVES];
+    __shared__ uint32_t s_front[EMIT_ITEMS * WAVES];
     TileIn<KIND, false> T;
     tile_load_and_test<KIND, false, false>(c, pr, (uint64_t)blockIdx.x * EMIT_TILE, T);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t masks[EMIT_ITEMS];
     uint32_t cnt = 0;
 #pragma unroll
     for (int j = 0; j < EMIT_ITEMS; j++) {
-        const uint64_t m = __ballot(T.passes[j]);  // wave-uniform
-        cnt += (uint32_t)__popcll(m);
-        if ((threadIdx.x & 63) == 0) s_bits[j * WAVES + (threadIdx.x >> 6)] = m;
+        masks[j] = __ballot(T.passes[j]);  // wave-uniform
+        cnt += (uint32_t)__popcll(masks[j]);
+        if (lane == 0) s_bits[j * WAVES + wave] = masks[j];
     }
-    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = cnt;
+    if (lane == 0) s_w[wave] = cnt;
     __syncthreads();
     if (threadIdx.x < EMIT_ITEMS * WAVES) bits[(uint64_t)blockIdx.x * (EMIT_ITEMS * WAVES) + threadIdx.x] = s_bits[threadIdx.x];
-    if (threadIdx.x == 0) {
-        uint32_t t = 0;
-        for (int w = 0; w < WAVES; w++) t += s_w[w];
-        counts[blockIdx.x] = t;
+    uint32_t total = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; w++) total += s_w[w];
+    if (threadIdx.x == 0) counts[blockIdx.x] = total;
+    if (KIND == PCQ_PRED_CLASS || !park || total == 0 || total > park_max) return;  // (the same for the whole workgroup)
+    uint32_t cls[EMIT_ITEMS];
+    {
+        const uint8_t *clsp = c.cls ? c.cls : c.xyz;
+        const uint64_t stride = c.cls ? c.cls_stride : 0;
+        const uint32_t mask = c.cls ? 0xffu : 0u;
+#pragma unroll
+        for (int j = 0; j < EMIT_ITEMS; j++) {
+            const uint64_t i0 = (uint64_t)blockIdx.x * EMIT_TILE + (uint64_t)j * BLOCK + threadIdx.x, i = i0 < c.n ? i0 : c.n - 1;
+            cls[j] = clsp[i * stride] & mask;  // last.rs:138-142
+        }
+    }
+    if (wave == 0) {  // matches in front of (row j, wave w), in file order: word j * WAVES + w
+        const uint32_t v = lane < (uint32_t)(EMIT_ITEMS * WAVES) ? (uint32_t)__popcll(s_bits[lane]) : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < EMIT_ITEMS * WAVES; off <<= 1) {
+            const uint32_t up = __shfl_up(incl, off, 64);
+            if (lane >= (uint32_t)off) incl += up;
+        }
+        if (lane < (uint32_t)(EMIT_ITEMS * WAVES)) s_front[lane] = incl - v;
+    }
+    __syncthreads();
+    uint4 *dst = park + (uint64_t)blockIdx.x * park_max;
+#pragma unroll
+    for (int j = 0; j < EMIT_ITEMS; j++) {
+        if (!T.passes[j]) continue;
+        const uint32_t rank = s_front[j * WAVES + wave] + (uint32_t)__popcll(masks[j] & ((1ull << lane) - 1ull));
+        dst[rank] = make_uint4((uint32_t)T.rps[j].x, (uint32_t)T.rps[j].y, (uint32_t)T.rps[j].z, cls[j]);
     }
 }
 
@@ -342,6 +381,47 @@ __global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, co
     }
 }
 
+// A PARKED tile (k_tile_counts left its 1 .. park_max <= 256 matches as 16-byte words): thread t builds record t, the records are
+// assembled in the LDS image and leave as 16-byte stores, exactly like a flush of k_emit_points — 16 bytes read per match, nothing
+// of the tile's 2048 points.
+__global__ __launch_bounds__(BLOCK) void k_emit_parked(DevCols c, const uint64_t *__restrict__ offsets, const uint4 *__restrict__ park,
+                                                       const uint64_t *__restrict__ d_npoints_in, uint8_t *__restrict__ out31, uint32_t park_max) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_stage[(BLOCK * 31 + 16) / 4 + 16];
+    const uint32_t tile = blockIdx.x;
+    const uint64_t before = offsets[tile], in_tile = offsets[tile + 1] - before;
+    if (in_tile == 0 || in_tile > park_max) return;  // (the same for the whole workgroup)
+    uint4 rec = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < in_tile) rec = park[(uint64_t)tile * park_max + threadIdx.x];
+    const uint64_t gbyte0 = (*d_npoints_in + before) * 31ull;
+    const uint32_t pad = (uint32_t)(gbyte0 & 15), total_b = pad + (uint32_t)in_tile * 31u;
+    for (uint32_t t = threadIdx.x; t < total_b / 4 + 10; t += BLOCK) s_stage[t] = 0;
+    __syncthreads();
+    if (threadIdx.x < in_tile) {
+        pcq_point pt;
+        pt.x = world((int32_t)rec.x, c.scale[0], c.offset[0]);  // last.rs:156-160
+        pt.y = world((int32_t)rec.y, c.scale[1], c.offset[1]);
+        pt.z = world((int32_t)rec.z, c.scale[2], c.offset[2]);
+        pt.r = pt.g = pt.b = 0;
+        pt.classification = (uint8_t)rec.w;
+        or_point31(s_stage, pad + 31u * threadIdx.x, pt);
+    }
+    __syncthreads();
+    uint8_t *gdst = out31 + (gbyte0 - pad);  // 16-byte aligned (out31 comes from the pool)
+    const uint8_t *stage8 = reinterpret_cast<const uint8_t *>(s_stage);
+    for (uint32_t b0 = threadIdx.x * 16u; b0 < total_b; b0 += BLOCK * 16u) {
+        const uint32_t b1 = b0 + 16u;
+        if (b0 >= pad && b1 <= total_b) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const uint4 v = *reinterpret_cast<const uint4 *>(stage8 + b0);
+            u32x4 w = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(w, reinterpret_cast<u32x4 *>(gdst + b0));
+        } else {
+            const uint32_t lo = b0 > pad ? b0 : pad, hi = b1 < total_b ? b1 : total_b;
+            for (uint32_t k = lo; k < hi; k++) gdst[k] = stage8[k];
+        }
+    }
+}
+
 // The same for a tile with FEW matches (a box that keeps a per cent of a file in random order: 20 of a tile's 2048 points).
 // k_emit_points pays a tile's fixed work whatever it keeps — both readings of all 2048 positions, five barriers, the LDS
 // image: 0.72 ms for 1.6 M records against 0.29 ms for the count pass alone.  Here ONE WAVE takes a tile and only its match
@@ -350,11 +430,11 @@ __global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, co
 template <bool RGB>
 __global__ __launch_bounds__(BLOCK) void k_emit_sparse(DevCols c, const uint64_t *__restrict__ offsets, const uint64_t *__restrict__ bits,
                                                        const uint64_t *__restrict__ d_npoints_in, uint8_t *__restrict__ out31, uint32_t ntiles,
-                                                       uint32_t sparse_max) {
+                                                       uint32_t parked_max, uint32_t sparse_max) {
     const uint32_t lane = threadIdx.x & 63, tile = blockIdx.x * WAVES + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
     const uint64_t before = offsets[tile], in_tile = offsets[tile + 1] - before;
-    if (in_tile == 0 || in_tile > sparse_max) return;  // (the same for the whole wave)
+    if (in_tile <= parked_max || in_tile > sparse_max) return;  // (the same for the whole wave; parked_max = 0: nothing is parked)
     const uint64_t word = bits[(uint64_t)tile * (EMIT_ITEMS * WAVES) + (lane >> 1)];
     uint32_t m = (uint32_t)(word >> (32 * (lane & 1)));
     const uint32_t mine = (uint32_t)__popc(m);
@@ -405,30 +485,38 @@ int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pre
     const uint64_t ntiles = (cols.n + EMIT_TILE - 1) / EMIT_TILE;
     const uint64_t npieces = (ntiles + SCAN_PIECE - 1) / SCAN_PIECE;
     if (npieces > 1024) return pcq_fail(PCQ_ERR_ARG, "scan chunk too large (%llu points)", (unsigned long long)cols.n);
-    int rc = pcq_ensure_partials(ctx, (size_t)(2 * ntiles + npieces + 2 + ntiles * (EMIT_ITEMS * WAVES)));  // counts | offsets (+ total) | piece sums | match bits
+    // thin tiles park their matches (k_tile_counts): positions predicate, no colour block; 16 bytes x park_max per tile (a sixth of the input)
+    const uint32_t park_max = pred.kind != PCQ_PRED_CLASS && !cols.rgb && cols.xyz && ctx->emit_park_max > 0 ? (uint32_t)ctx->emit_park_max : 0u;
+    const size_t base_words = (size_t)(2 * ntiles + npieces + 2 + ntiles * (EMIT_ITEMS * WAVES));  // counts | offsets (+ total) | piece sums | match bits
+    int rc = pcq_ensure_partials(ctx, base_words + 2 + (size_t)ntiles * park_max * 2);             // | parked matches (16-byte aligned)
     if (rc) return rc;
     uint64_t *counts = ctx->d_partials, *offsets = counts + ntiles, *pieces = offsets + ntiles + 1, *bits = pieces + npieces + 1;
+    uint4 *park = park_max ? reinterpret_cast<uint4 *>(((uintptr_t)(ctx->d_partials + base_words) + 15) & ~(uintptr_t)15) : nullptr;
     const uint32_t sparse_max = ctx->emit_sparse_max < 0 ? 0u : (uint32_t)ctx->emit_sparse_max;
     const dim3 g((unsigned)ntiles), b(BLOCK);
-    if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_BOUNDS>, g, b, 0, s, cols, pred, counts, bits);
-    else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_CLASS>, g, b, 0, s, cols, pred, counts, bits);
-    else hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_BOUNDS_F64>, g, b, 0, s, cols, pred, counts, bits);
+    if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_BOUNDS>, g, b, 0, s, cols, pred, counts, bits, park, park_max);
+    else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_CLASS>, g, b, 0, s, cols, pred, counts, bits, park, park_max);
+    else hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_BOUNDS_F64>, g, b, 0, s, cols, pred, counts, bits, park, park_max);
     hipLaunchKernelGGL(k_scan_piece_sums, dim3((unsigned)npieces), dim3(1024), 0, s, counts, (uint32_t)ntiles, pieces);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, pieces, (uint32_t)npieces);
     hipLaunchKernelGGL(k_scan_pieces, dim3((unsigned)npieces), dim3(1024), 0, s, counts, (uint32_t)ntiles, pieces, offsets);
+    const uint32_t skip_max = park_max > sparse_max ? park_max : sparse_max;  // tiles k_emit_points leaves to the two writers below
 #define PCQ_EMIT(KIND)                                                                                                                                   \
     do {                                                                                                                                                 \
-        if (cols.rgb) hipLaunchKernelGGL((k_emit_points<KIND, true>), g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles, sparse_max); \
-        else hipLaunchKernelGGL((k_emit_points<KIND, false>), g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles, sparse_max);  \
+        if (cols.rgb) hipLaunchKernelGGL((k_emit_points<KIND, true>), g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles, skip_max); \
+        else hipLaunchKernelGGL((k_emit_points<KIND, false>), g, b, 0, s, cols, pred, offsets, d_npoints_in, d_npoints_out, d_out31, (uint32_t)ntiles, skip_max);  \
     } while (0)
     if (pred.kind == PCQ_PRED_BOUNDS) PCQ_EMIT(PCQ_PRED_BOUNDS);
     else if (pred.kind == PCQ_PRED_CLASS) PCQ_EMIT(PCQ_PRED_CLASS);
     else PCQ_EMIT(PCQ_PRED_BOUNDS_F64);
 #undef PCQ_EMIT
-    if (sparse_max) {  // tiles with 1 .. sparse_max matches: a wave each, from the match bits (same stream: behind the scan of the offsets)
+    if (park_max) {  // tiles with 1 .. park_max matches: from the 16-byte words the count pass left
+        hipLaunchKernelGGL(k_emit_parked, g, b, 0, s, cols, offsets, park, d_npoints_in, d_out31, park_max);
+    }
+    if (sparse_max > park_max) {  // tiles with 1 .. sparse_max matches: a wave each, from the match bits (same stream: behind the scan of the offsets)
         const dim3 gs((unsigned)((ntiles + WAVES - 1) / WAVES));
-        if (cols.rgb) hipLaunchKernelGGL(k_emit_sparse<true>, gs, b, 0, s, cols, offsets, bits, d_npoints_in, d_out31, (uint32_t)ntiles, sparse_max);
-        else hipLaunchKernelGGL(k_emit_sparse<false>, gs, b, 0, s, cols, offsets, bits, d_npoints_in, d_out31, (uint32_t)ntiles, sparse_max);
+        if (cols.rgb) hipLaunchKernelGGL(k_emit_sparse<true>, gs, b, 0, s, cols, offsets, bits, d_npoints_in, d_out31, (uint32_t)ntiles, park_max, sparse_max);
+        else hipLaunchKernelGGL(k_emit_sparse<false>, gs, b, 0, s, cols, offsets, bits, d_npoints_in, d_out31, (uint32_t)ntiles, park_max, sparse_max);
     }
     PCQ_HIP(hipGetLastError());
     return PCQ_OK;

@@ -190,11 +190,13 @@ def test_buffer_collector_dev_matches_oracle(oracle, gpu_ctx, fmt, n):
 
 
 @pytest.mark.parametrize("fmt", [1, 2, 3])
-@pytest.mark.parametrize("sparse_max", [0, 1, 9, 256, 2048])
-def test_buffer_collector_sparse_and_dense_tiles_write_the_same_records(oracle, gpu_ctx, fmt, sparse_max):
-    """The emit has two writers per scan: k_emit_points (a tile's whole image through LDS) for tiles with more than
-    `emit_sparse_max` matches and k_emit_sparse (one wave per tile, from the match bits the count pass leaves) for the others.
-    Whatever the threshold — never, one match, a few, the default, always — the records and their order are the oracle's:
+@pytest.mark.parametrize("sparse_max,park_max", [(0, 0), (1, 0), (9, 0), (256, 0), (2048, 0), (64, 256), (0, 256), (64, 1), (300, 37)])
+def test_buffer_collector_sparse_and_dense_tiles_write_the_same_records(oracle, gpu_ctx, fmt, sparse_max, park_max):
+    """The emit has three writers per scan: k_emit_points (a tile's whole image through LDS) for tiles with many matches,
+    k_emit_parked for tiles with at most `emit_park_max` matches (bounds queries on files without a colour block: the count
+    pass left the matches themselves, 16 bytes each) and k_emit_sparse (one wave per tile, from the match bits the count pass
+    leaves) for tiles with at most `emit_sparse_max` where nothing is parked.
+    Whatever the thresholds — never, one match, a few, the defaults, always — the records and their order are the oracle's:
     boxes that keep about 1 / 1000, 1 %, 10 %, a half and all of a file in random order, class queries, two scans appended
     into one collector (a record base that is no multiple of 16), a file whose last tile is ragged."""
     n = 2048 * 9 + 777
@@ -204,6 +206,7 @@ def test_buffer_collector_sparse_and_dense_tiles_write_the_same_records(oracle, 
     f = DevFile(gpu_ctx, image, hdr)
     lo, hi = np.array(hdr.min), np.array(hdr.max)
     gpu_ctx.set_option("emit_sparse_max", sparse_max)
+    gpu_ctx.set_option("emit_park_max", park_max)
     try:
         ob, gb = oracle.buffer_collector(), gpu_ctx.buffer_collector()
         for frac in (0.001, 0.01, 0.1, 0.5, 1.0):
@@ -226,6 +229,7 @@ def test_buffer_collector_sparse_and_dense_tiles_write_the_same_records(oracle, 
         ob.free(), gb.free()
     finally:
         gpu_ctx.set_option("emit_sparse_max", 64)
+        gpu_ctx.set_option("emit_park_max", 256)
         f.free()
 
 

@@ -11,6 +11,8 @@ q, n = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 163_000_000
 with pkg.Context(0) as ctx:
     if os.environ.get("EMIT_SPARSE_MAX") is not None:  # threshold of the sparse writer (0 = dense writer only)
         ctx.set_option("emit_sparse_max", int(os.environ["EMIT_SPARSE_MAX"]))
+    if os.environ.get("EMIT_PARK_MAX") is not None:
+        ctx.set_option("emit_park_max", int(os.environ["EMIT_PARK_MAX"]))
     spec = specs.synth_ca13(points_per_file=n)[5]
     xyz, cls = ctx.alloc(12 * n), ctx.alloc(n)
     ctx.synth_fill(spec, 0, n, xyz, cls)

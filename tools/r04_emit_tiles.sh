@@ -3,9 +3,12 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r04
 O=gpurun_out/r04/emit_tiles.log; : > $O
-for sorted in "" 1; do for frac in 1.0 0.1 0.01; do for smax in 64 0 256; do
-  echo "== SORTED=${sorted:-0} FRAC=$frac EMIT_SPARSE_MAX=$smax ==" >> $O
-  EMIT_SPARSE_MAX=$smax SORTED=$sorted FRAC=$frac timeout -k 10 300 python tools/emit_probe.py ca13_XL 163000000 4 >> $O 2>&1 || exit 1
+# writers: "park sparse" = emit_park_max emit_sparse_max — 256 64 shipped; 0 64 = one wave per thin tile from the match bits (the round's first
+# step); 0 0 = round 3's kernels; 0 256 = the one-wave writer up to 256 matches
+for sorted in "" 1; do for frac in 1.0 0.1 0.01; do for w in "256 64" "0 64" "0 0" "0 256"; do
+  set -- $w
+  echo "== SORTED=${sorted:-0} FRAC=$frac EMIT_PARK_MAX=$1 EMIT_SPARSE_MAX=$2 ==" >> $O
+  EMIT_PARK_MAX=$1 EMIT_SPARSE_MAX=$2 SORTED=$sorted FRAC=$frac timeout -k 10 300 python tools/emit_probe.py ca13_XL 163000000 4 >> $O 2>&1 || exit 1
 done; done; done
 cd /tmp && export TMPDIR=/tmp
 for q in ca13_XL ca13_S; do

@@ -132,8 +132,13 @@ if os.path.exists(f"{O}/experiments/product.txt"):
 if os.path.exists(f"{O}/emit_tiles.log"):
     L = [f"# round 4 (git {head}): buffer collector on one 163 M-point ca13 file, boxes that keep 100 % / 10 % / 1 % of the file's x range (FRAC), the file in",
          "# generator order (SORTED=0: every 2048-point tile holds a few matches) and sorted along x (SORTED=1: the matches are one run of the file, the",
-         "# emit skips every other tile); tools/emit_probe.py through tools/r04_emit_tiles.sh.  The kernel lines at the end: SORTED=1 FRAC=0.1 under",
-         "# rocprofv3 --kernel-trace --stats.  GB/s = algorithmic bytes (13 B read per point + 31 B written per match) / wall time.", ""]
+         "# emit skips every other tile); tools/emit_probe.py through tools/r04_emit_tiles.sh, four writer settings each:",
+         "#   EMIT_PARK_MAX=256 EMIT_SPARSE_MAX=64  shipped: a tile with at most 256 matches leaves them as 16-byte words in the count pass (k_emit_parked)",
+         "#   EMIT_PARK_MAX=0   EMIT_SPARSE_MAX=64  the round's first step: one wave per tile with at most 64 matches, from the match bits (k_emit_sparse)",
+         "#   EMIT_PARK_MAX=0   EMIT_SPARSE_MAX=0   round 3's kernels",
+         "#   EMIT_PARK_MAX=0   EMIT_SPARSE_MAX=256 the one-wave writer up to 256 matches (slower at 10 % kept: dropped)",
+         "# The kernel lines at the end: SORTED=1 FRAC=0.1 under rocprofv3 --kernel-trace --stats.  GB/s = algorithmic bytes (13 B read per point + 31 B",
+         "# written per match) / wall time.", ""]
     L += [l.rstrip() for l in open(f"{O}/emit_tiles.log") if "amdgpu.ids" not in l]
     open(f"{P}/r04_emit_tiles.log", "w").write("\n".join(L) + "\n")
 
