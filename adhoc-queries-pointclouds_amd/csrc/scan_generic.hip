@@ -154,9 +154,10 @@ __device__ __forceinline__ void tile_load_and_test(const DevCols &c, const DevPr
 // themselves behind, {x, y, z, class} as one 16-byte word each, in file order, at park[tile * park_max ..): the emit then reads
 // 16 bytes per MATCH instead of the tile's 13 bytes per POINT a second time (k_emit_parked).  The class bytes of all eight points
 // are asked for together (no load in a branch); the ranks come from the tile's 32 mask words, summed by one wave.  Only for
-// predicates on the positions and files without a colour block (park == nullptr otherwise): a class predicate would have to
-// read positions it does not need, a colour block makes the parked word 24 bytes.
-template <int KIND>
+// predicates on the positions (park == nullptr otherwise): a class predicate would have to read positions it does not need.
+// RGB: the file has a colour block — a second word {red | green << 16, blue, 0, 0} per match, the colours of the tile asked for
+// with the class bytes.
+template <int KIND, bool RGB>
 __global__ __launch_bounds__(BLOCK) void k_tile_counts(DevCols c, DevPred pr, uint64_t *__restrict__ counts, uint64_t *__restrict__ bits,
                                                        uint4 *__restrict__ park, uint32_t park_max) {
     __shared__ uint32_t s_w[WAVES];
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(BLOCK) void k_tile_counts(DevCols c, DevPred pr, ui
     for (int w = 0; w < WAVES; w++) total += s_w[w];
     if (threadIdx.x == 0) counts[blockIdx.x] = total;
     if (KIND == PCQ_PRED_CLASS || !park || total == 0 || total > park_max) return;  // (the same for the whole workgroup)
-    uint32_t cls[EMIT_ITEMS];
+    uint32_t cls[EMIT_ITEMS], rg[EMIT_ITEMS], bl[EMIT_ITEMS];
     {
         const uint8_t *clsp = c.cls ? c.cls : c.xyz;
         const uint64_t stride = c.cls ? c.cls_stride : 0;
@@ -190,6 +191,12 @@ __global__ __launch_bounds__(BLOCK) void k_tile_counts(DevCols c, DevPred pr, ui
         for (int j = 0; j < EMIT_ITEMS; j++) {
             const uint64_t i0 = (uint64_t)blockIdx.x * EMIT_TILE + (uint64_t)j * BLOCK + threadIdx.x, i = i0 < c.n ? i0 : c.n - 1;
             cls[j] = clsp[i * stride] & mask;  // last.rs:138-142
+            rg[j] = bl[j] = 0;
+            if (RGB) {  // last.rs:145-153
+                const uint8_t *q = c.rgb + i * c.rgb_stride;
+                rg[j] = (uint32_t)ld_u16(q) | ((uint32_t)ld_u16(q + 2) << 16);
+                bl[j] = ld_u16(q + 4);
+            }
         }
     }
     if (wave == 0) {  // matches in front of (row j, wave w), in file order: word j * WAVES + w
@@ -203,12 +210,13 @@ __global__ __launch_bounds__(BLOCK) void k_tile_counts(DevCols c, DevPred pr, ui
         if (lane < (uint32_t)(EMIT_ITEMS * WAVES)) s_front[lane] = incl - v;
     }
     __syncthreads();
-    uint4 *dst = park + (uint64_t)blockIdx.x * park_max;
+    uint4 *dst = park + (uint64_t)blockIdx.x * park_max * (RGB ? 2 : 1);
 #pragma unroll
     for (int j = 0; j < EMIT_ITEMS; j++) {
         if (!T.passes[j]) continue;
         const uint32_t rank = s_front[j * WAVES + wave] + (uint32_t)__popcll(masks[j] & ((1ull << lane) - 1ull));
         dst[rank] = make_uint4((uint32_t)T.rps[j].x, (uint32_t)T.rps[j].y, (uint32_t)T.rps[j].z, cls[j]);
+        if (RGB) dst[park_max + rank] = make_uint4(rg[j], bl[j], 0u, 0u);
     }
 }
 
@@ -383,15 +391,20 @@ __global__ __launch_bounds__(BLOCK) void k_emit_points(DevCols c, DevPred pr, co
 
 // A PARKED tile (k_tile_counts left its 1 .. park_max <= 256 matches as 16-byte words): thread t builds record t, the records are
 // assembled in the LDS image and leave as 16-byte stores, exactly like a flush of k_emit_points — 16 bytes read per match, nothing
-// of the tile's 2048 points.
+// of the tile's 2048 points (RGB: 32).
+template <bool RGB>
 __global__ __launch_bounds__(BLOCK) void k_emit_parked(DevCols c, const uint64_t *__restrict__ offsets, const uint4 *__restrict__ park,
                                                        const uint64_t *__restrict__ d_npoints_in, uint8_t *__restrict__ out31, uint32_t park_max) {
     __shared__ __attribute__((aligned(16))) uint32_t s_stage[(BLOCK * 31 + 16) / 4 + 16];
     const uint32_t tile = blockIdx.x;
     const uint64_t before = offsets[tile], in_tile = offsets[tile + 1] - before;
     if (in_tile == 0 || in_tile > park_max) return;  // (the same for the whole workgroup)
-    uint4 rec = make_uint4(0, 0, 0, 0);
-    if (threadIdx.x < in_tile) rec = park[(uint64_t)tile * park_max + threadIdx.x];
+    uint4 rec = make_uint4(0, 0, 0, 0), col = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x < in_tile) {
+        const uint4 *src = park + (uint64_t)tile * park_max * (RGB ? 2 : 1);
+        rec = src[threadIdx.x];
+        if (RGB) col = src[park_max + threadIdx.x];
+    }
     const uint64_t gbyte0 = (*d_npoints_in + before) * 31ull;
     const uint32_t pad = (uint32_t)(gbyte0 & 15), total_b = pad + (uint32_t)in_tile * 31u;
     for (uint32_t t = threadIdx.x; t < total_b / 4 + 10; t += BLOCK) s_stage[t] = 0;
@@ -401,7 +414,7 @@ __global__ __launch_bounds__(BLOCK) void k_emit_parked(DevCols c, const uint64_t
         pt.x = world((int32_t)rec.x, c.scale[0], c.offset[0]);  // last.rs:156-160
         pt.y = world((int32_t)rec.y, c.scale[1], c.offset[1]);
         pt.z = world((int32_t)rec.z, c.scale[2], c.offset[2]);
-        pt.r = pt.g = pt.b = 0;
+        pt.r = (uint16_t)col.x, pt.g = (uint16_t)(col.x >> 16), pt.b = (uint16_t)col.y;
         pt.classification = (uint8_t)rec.w;
         or_point31(s_stage, pad + 31u * threadIdx.x, pt);
     }
@@ -485,18 +498,21 @@ int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pre
     const uint64_t ntiles = (cols.n + EMIT_TILE - 1) / EMIT_TILE;
     const uint64_t npieces = (ntiles + SCAN_PIECE - 1) / SCAN_PIECE;
     if (npieces > 1024) return pcq_fail(PCQ_ERR_ARG, "scan chunk too large (%llu points)", (unsigned long long)cols.n);
-    // thin tiles park their matches (k_tile_counts): positions predicate, no colour block; 16 bytes x park_max per tile (a sixth of the input)
-    const uint32_t park_max = pred.kind != PCQ_PRED_CLASS && !cols.rgb && cols.xyz && ctx->emit_park_max > 0 ? (uint32_t)ctx->emit_park_max : 0u;
+    // thin tiles park their matches (k_tile_counts): positions predicate; 16 (with a colour block: 32) bytes x park_max per tile, a sixth of the input
+    const uint32_t park_max = pred.kind != PCQ_PRED_CLASS && cols.xyz && ctx->emit_park_max > 0 ? (uint32_t)ctx->emit_park_max : 0u;
     const size_t base_words = (size_t)(2 * ntiles + npieces + 2 + ntiles * (EMIT_ITEMS * WAVES));  // counts | offsets (+ total) | piece sums | match bits
-    int rc = pcq_ensure_partials(ctx, base_words + 2 + (size_t)ntiles * park_max * 2);             // | parked matches (16-byte aligned)
+    int rc = pcq_ensure_partials(ctx, base_words + 2 + (size_t)ntiles * park_max * (cols.rgb ? 4 : 2));  // | parked matches (16-byte aligned)
     if (rc) return rc;
     uint64_t *counts = ctx->d_partials, *offsets = counts + ntiles, *pieces = offsets + ntiles + 1, *bits = pieces + npieces + 1;
     uint4 *park = park_max ? reinterpret_cast<uint4 *>(((uintptr_t)(ctx->d_partials + base_words) + 15) & ~(uintptr_t)15) : nullptr;
     const uint32_t sparse_max = ctx->emit_sparse_max < 0 ? 0u : (uint32_t)ctx->emit_sparse_max;
     const dim3 g((unsigned)ntiles), b(BLOCK);
-    if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_BOUNDS>, g, b, 0, s, cols, pred, counts, bits, park, park_max);
-    else if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_CLASS>, g, b, 0, s, cols, pred, counts, bits, park, park_max);
-    else hipLaunchKernelGGL(k_tile_counts<PCQ_PRED_BOUNDS_F64>, g, b, 0, s, cols, pred, counts, bits, park, park_max);
+    const bool park_rgb = park_max && cols.rgb;
+    if (pred.kind == PCQ_PRED_CLASS) hipLaunchKernelGGL((k_tile_counts<PCQ_PRED_CLASS, false>), g, b, 0, s, cols, pred, counts, bits, park, park_max);
+    else if (pred.kind == PCQ_PRED_BOUNDS && park_rgb) hipLaunchKernelGGL((k_tile_counts<PCQ_PRED_BOUNDS, true>), g, b, 0, s, cols, pred, counts, bits, park, park_max);
+    else if (pred.kind == PCQ_PRED_BOUNDS) hipLaunchKernelGGL((k_tile_counts<PCQ_PRED_BOUNDS, false>), g, b, 0, s, cols, pred, counts, bits, park, park_max);
+    else if (park_rgb) hipLaunchKernelGGL((k_tile_counts<PCQ_PRED_BOUNDS_F64, true>), g, b, 0, s, cols, pred, counts, bits, park, park_max);
+    else hipLaunchKernelGGL((k_tile_counts<PCQ_PRED_BOUNDS_F64, false>), g, b, 0, s, cols, pred, counts, bits, park, park_max);
     hipLaunchKernelGGL(k_scan_piece_sums, dim3((unsigned)npieces), dim3(1024), 0, s, counts, (uint32_t)ntiles, pieces);
     hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, pieces, (uint32_t)npieces);
     hipLaunchKernelGGL(k_scan_pieces, dim3((unsigned)npieces), dim3(1024), 0, s, counts, (uint32_t)ntiles, pieces, offsets);
@@ -511,7 +527,8 @@ int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pre
     else PCQ_EMIT(PCQ_PRED_BOUNDS_F64);
 #undef PCQ_EMIT
     if (park_max) {  // tiles with 1 .. park_max matches: from the 16-byte words the count pass left
-        hipLaunchKernelGGL(k_emit_parked, g, b, 0, s, cols, offsets, park, d_npoints_in, d_out31, park_max);
+        if (cols.rgb) hipLaunchKernelGGL(k_emit_parked<true>, g, b, 0, s, cols, offsets, park, d_npoints_in, d_out31, park_max);
+        else hipLaunchKernelGGL(k_emit_parked<false>, g, b, 0, s, cols, offsets, park, d_npoints_in, d_out31, park_max);
     }
     if (sparse_max > park_max) {  // tiles with 1 .. sparse_max matches: a wave each, from the match bits (same stream: behind the scan of the offsets)
         const dim3 gs((unsigned)((ntiles + WAVES - 1) / WAVES));

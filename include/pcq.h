@@ -275,7 +275,7 @@ int pcq_bind_thread_near_device(pcq_ctx *ctx);
  * "grid_f2" (tests: the second-level fan-out a fold starts from; 0 = from the measured estimate), "host_in_place" (host / file
  * scans with a count or grid collector read the pinned staging ring in place over PCIe: 0 never, 1 always, 2 = while the
  * process's copy path is being set up — the default), "emit_park_max" / "emit_sparse_max" (buffer collector: a 2048-point tile with at
- * most that many matches leaves them as 16-byte words in the count pass — default 256, bounds queries on files without a colour block —
+ * most that many matches leaves them as 16-byte words in the count pass — default 256, bounds queries —
  * or is written by one wave from the count pass's match bits — default 64; 0 = never), "grid_tuple16" / "grid_stream" (tests: force
  * the grid collector's tuple size — 1 = 16 bytes with the selector, 2 = without, 0 = 24 bytes — and the coarse fold's form —
  * 1 = k_fold_stream, 0 = k_fold<BIG>; same results in every combination).  pcq_get_option also
