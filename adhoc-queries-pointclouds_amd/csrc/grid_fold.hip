@@ -406,7 +406,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     __shared__ uint64_t s_dist[NSLOT];
     __shared__ uint64_t s_ord[NSLOT];
     __shared__ uint32_t s_aliasbits[(NSLOT + 31) / 32];
-    __shared__ uint32_t s_ncell, s_tie, s_wsum[NT / 64];
+    __shared__ uint32_t s_tie, s_wsum[NT / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint8_t *tuples = P.tuples;
     const bool wide = WIDE && P.wide;
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
     const uint32_t *off = P.off;
     for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
     for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
-    if (threadIdx.x == 0) s_ncell = 0, s_tie = 0;
+    if (threadIdx.x == 0) s_tie = 0;
     unsigned long long winners = 0;  // thread 0: this workgroup's winners
 
     // Three partitions deep: the current one (range, output base, and — 16-byte tuples — its tuples, asked for a whole
@@ -526,7 +526,6 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
         // every tuple that has no slot yet and only then looks at the answers — one LDS round trip per round instead of one
         // per tuple and round (inserting them one after the other was a fifth of the kernel: three dependent chains).
         int slot[FOLD_K];
-        uint32_t fresh_cells = 0;
         {
             uint32_t ps[FOLD_K], pstep[FOLD_K];
             bool todo[FOLD_K];
@@ -550,7 +549,6 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
                 for (int k = 0; k < FOLD_K; k++) {
                     if (!todo[k]) continue;
                     if (prev[k] == PCQ_EMPTY_KEY || prev[k] == key[k]) {
-                        fresh_cells += prev[k] == PCQ_EMPTY_KEY ? 1 : 0;
                         slot[k] = (int)ps[k];
                         todo[k] = false;
                     } else {
@@ -567,30 +565,11 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
             }
         }
         ST(3);  // phase 1: insert, minimum distance
-        {  // cells of the partition, counted per wave; beyond LIMIT the partition is given up (like k_fold: the same fan-out rule)
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) fresh_cells += __shfl_xor(fresh_cells, o, 64);
-            if (lane == 0 && fresh_cells) atomicAdd(&s_ncell, fresh_cells);
-        }
-        // (one barrier and the sum itself: __syncthreads_or is three barriers, and computes a flat thread number out of
-        // threadIdx.y and .z, which then live — in scratch — through the whole kernel)
-        __syncthreads();
-        if (s_ncell > (uint32_t)LIMIT) {  // more cells than the table holds: the host repeats the fold with more partitions
-            for (int t = threadIdx.x; t < NSLOT; t += NT) s_key[t] = PCQ_EMPTY_KEY, s_dist[t] = ~0ull, s_ord[t] = ~0ull;
-            for (int t = threadIdx.x; t < (NSLOT + 31) / 32; t += NT) s_aliasbits[t] = 0;
-            __syncthreads();  // (everybody has read the count)
-            if (threadIdx.x == 0) {
-                s_ncell = 0;
-                P.wcount[p] = 0;
-                atomicAdd(&P.stats[1], 1ull);
-            }
-            cur_lo = nxt_lo, cur_cnt = nxt_cnt, cur_out = nxt_out;
-            if (pnn < nparts) range_take(&nxt_lo, &nxt_cnt, &nxt_out);
-#pragma unroll
-            for (int k = 0; k < FOLD_K; k++) rcur[k] = rnxt[k];
-            continue;
-        }
-        ST(4);  // cell count + barrier
+        // (No count of the cells: a partition this kernel takes has at most CHUNK tuples, hence at most CHUNK <= LIMIT cells — it
+        // cannot outgrow the table; longer partitions went to the defer list above.)
+        static_assert(NT * FOLD_K <= LIMIT, "a chunk's tuples fit the table as cells");
+        __syncthreads();  // every minimum is final
+        ST(4);  // barrier: every minimum is final
         // phase 2: among the tuples at the minimum, the earliest in file order.  Two tuples of one cell at exactly the same
         // distance are rare (a point stored twice), so every tuple at its cell's minimum is taken for the winner and ranked at
         // once — ONE barrier for the order and the ranks —; a tuple that finds another one's order in its slot raises s_tie,
@@ -673,7 +652,6 @@ __global__ __launch_bounds__(NT, MIN_WAVES) void k_fold_dense(DenseParams P, uin
             s_key[sl] = PCQ_EMPTY_KEY, s_dist[sl] = ~0ull, s_ord[sl] = ~0ull;
         }
         if (threadIdx.x == 0) {
-            s_ncell = 0;
             P.wcount[p] = total;
             winners += total;
         }
