@@ -16,4 +16,13 @@ bash tools/r04_grid_counters.sh fin "100 10" coherent > $O/final_counters_cohere
     PCQ_LAB=stamps PCQ_TIMING=1 timeout -k 10 300 python3 tools/grid_probe.py ca13_XL $cell 163000000 3 2>&1 | grep -E "stamps|cells" | tail -4
   done; done
 } > $O/final_stamps.txt 2>&1
+{
+  echo "# the same four cases WITHOUT the profiler (tools/grid_probe.py alone; the kernel trace costs the fold's wall clock 0.2-0.4 ms)"
+  for order in random coherent; do for cell in 100 10; do
+    if [ $order = coherent ]; then export COHERENT=10; else unset COHERENT; fi
+    echo "== $order order, $cell m"
+    timeout -k 10 300 python3 tools/grid_probe.py ca13_XL $cell 163000000 5 2>&1 | grep cells | tail -4
+  done; done
+} > $O/final_unprofiled.txt 2>&1
 grep -v "rocprim\|copyBuffer" $O/final_kernel_stats.txt
+cat $O/final_unprofiled.txt

@@ -40,7 +40,9 @@ if os.path.exists(f"{O}/fin_random_100.log"):
         L += ["  " + l.strip() for l in open(f"{O}/fin_{order}_{cell}.log") if "cells" in l]
         L += kstats(f"{O}/prof_fin_{order}_{cell}/g_kernel_stats.csv")
         L.append("")
-    open(f"{P}/r04_grid_kernel_stats.txt", "w").write("\n".join(L))
+    if os.path.exists(f"{O}/final_unprofiled.txt"):
+        L += [l.rstrip() for l in open(f"{O}/final_unprofiled.txt")]
+    open(f"{P}/r04_grid_kernel_stats.txt", "w").write("\n".join(L) + "\n")
 
 
 def counters(order, cell):
