@@ -261,7 +261,8 @@ int pcq_ensure_partials(pcq_ctx *ctx, size_t n) {
         ctx->partials_cap = 0;
     }
     size_t cap = 4096;
-    while (cap < n) cap <<= 1;
+    while (cap < n && cap < ((size_t)1 << 22)) cap <<= 1;
+    if (cap < n) cap = (n + (((size_t)1 << 22) - 1)) & ~(((size_t)1 << 22) - 1);  // beyond 32 MB: whole 32 MB steps, not the next power of two
     PCQ_HIP(hipMalloc((void **)&ctx->d_partials, cap * sizeof(uint64_t)));
     ctx->partials_cap = cap;
     return PCQ_OK;

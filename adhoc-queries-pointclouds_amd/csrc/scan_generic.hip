@@ -499,9 +499,14 @@ int pcq_launch_emit_points(pcq_ctx *ctx, const DevCols &cols, const DevPred &pre
     const uint64_t npieces = (ntiles + SCAN_PIECE - 1) / SCAN_PIECE;
     if (npieces > 1024) return pcq_fail(PCQ_ERR_ARG, "scan chunk too large (%llu points)", (unsigned long long)cols.n);
     // thin tiles park their matches (k_tile_counts): positions predicate; 16 (with a colour block: 32) bytes x park_max per tile, a sixth of the input
-    const uint32_t park_max = pred.kind != PCQ_PRED_CLASS && cols.xyz && ctx->emit_park_max > 0 ? (uint32_t)ctx->emit_park_max : 0u;
+    uint32_t park_max = pred.kind != PCQ_PRED_CLASS && cols.xyz && ctx->emit_park_max > 0 ? (uint32_t)ctx->emit_park_max : 0u;
     const size_t base_words = (size_t)(2 * ntiles + npieces + 2 + ntiles * (EMIT_ITEMS * WAVES));  // counts | offsets (+ total) | piece sums | match bits
     int rc = pcq_ensure_partials(ctx, base_words + 2 + (size_t)ntiles * park_max * (cols.rgb ? 4 : 2));  // | parked matches (16-byte aligned)
+    if (rc && park_max) {  // no room for the parked matches (a sixth of the input): the thin tiles are read a second time instead
+        (void)hipGetLastError();
+        park_max = 0;
+        rc = pcq_ensure_partials(ctx, base_words + 2);
+    }
     if (rc) return rc;
     uint64_t *counts = ctx->d_partials, *offsets = counts + ntiles, *pieces = offsets + ntiles + 1, *bits = pieces + npieces + 1;
     uint4 *park = park_max ? reinterpret_cast<uint4 *>(((uintptr_t)(ctx->d_partials + base_words) + 15) & ~(uintptr_t)15) : nullptr;
