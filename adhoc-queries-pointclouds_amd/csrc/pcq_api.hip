@@ -1023,7 +1023,10 @@ extern "C" int pcq_prepare_host_scans(pcq_ctx *ctx) {
     if (ctx->stage_warm.joinable() || ctx->h_stage[0]) return PCQ_OK;  // under way, or nothing left to prepare
     ctx->stage_warm = std::thread([ctx] {
         (void)hipSetDevice(ctx->device);
-        (void)ensure_stage_now(ctx, (size_t)ctx->chunk_points * 12 + 4096, 2);  // (what a scan of positions + classes asks for: scan_host_impl)
+        // (what a scan of positions + classes asks for: scan_host_impl.  BOTH pairs: with only the first one pinned here the scan pins
+        // the second on a thread of its own while a third sets the copy path up, and its first launch waits for the two of them inside
+        // the runtime — first file 14 -> 17.7 ms, profiles/r04_cli_first_file.log)
+        (void)ensure_stage_now(ctx, (size_t)ctx->chunk_points * 12 + 4096, 2);
         ensure_copy_pool(ctx);
     });
     return PCQ_OK;

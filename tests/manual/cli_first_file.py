@@ -19,9 +19,9 @@ d = tempfile.mkdtemp(prefix="pcq_first_", dir="/tmp")
 for i, s in enumerate(specs.synth_ca13(points_per_file=20_000_000, files=16)):
     o.synth_write(s, os.path.join(d, f"tile{i:02d}.last"), threads=32)
 xl = "643431.76;3883547.565;-46194.145;736910.93;3977026.735;47285.025"
-for rep in range(9):
+for rep in range(6):
     time.sleep(1.0)
-    mode = str((2, 0, 1)[rep % 3])  # in turn: in place while the copy path is set up (2, the default) / never (0) / always (1)
+    mode = "2"  # (the default: in place while the copy path is set up; 0 = never, 1 = always: see profiles/r04_cli_first_file.log)
     r = subprocess.run([QUERY, "-i", d, "--optimized", "--parallel", "--bounds", xl], capture_output=True, text=True,
                        env=dict(os.environ, PCQ_TIMING="1", PCQ_EXIT="fast", PCQ_HOST_IN_PLACE=mode))
     print("PCQ_HOST_IN_PLACE=" + mode)
